@@ -1,0 +1,211 @@
+/*
+ * vkr_postfx.h — C-ABI of the MI355X post-process hot path (Hi-Z / SSR / GTAO / TAA).
+ *
+ * One entry point per reference compute/fragment *program* (src/shaders/config.json)
+ * on the hot path.  Arguments follow the reference shader's binding order: POD image
+ * views for sampled / storage images, a pointer to the exact UBO struct the reference
+ * uploads, the exact push-constant struct, then the HIP stream.  Plain pointers and
+ * sizes only; no torch / Vulkan / glm types.
+ *
+ * Conventions
+ *   - all image memory is device (HBM) memory, pitch-linear, rows 256-B aligned,
+ *     4 / 8 bytes per texel in the reference's storage format (vkr_format);
+ *   - every call is asynchronous on `stream`; returns 0 or a non-zero hipError_t-style
+ *     code (message via vkr_last_error()); nothing is allocated inside a call;
+ *   - UBO / push-constant structs are read on the host at call time (they become
+ *     kernel arguments), so they may live on the caller's stack;
+ *   - a `vkr_img` is a *view*: mip 0 of the view is the first mip the reference binds
+ *     (e.g. GTAO binds depth image-mip 1 as a 1-mip view, gtao.cpp:119);
+ *   - multi-GPU tiling: an image may hold only a window of the frame.  `full_width/
+ *     full_height` is the whole frame's extent at view-mip 0, `origin_x/origin_y` the
+ *     window's position in it.  Single GPU: origin 0, full == width/height.  Output
+ *     images define the set of pixels a kernel computes (their window).
+ */
+#ifndef VKR_POSTFX_H_INCLUDED
+#define VKR_POSTFX_H_INCLUDED
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VKR_MAX_MIPS 16
+#define VKR_HALTON_SEQ_SIZE 128  /* advanced_ssr.cpp:6, trace.comp:18 */
+
+/* Storage formats used by the path (scene_renderer.cpp:13-43, gtao.cpp:26-47,
+ * advanced_ssr.cpp:62-92, taa.cpp:6).  Values are ours, not VkFormat. */
+typedef enum vkr_format {
+  VKR_FMT_UNDEFINED      = 0,
+  VKR_FMT_D24_UNORM_S8   = 1,  /* uint32: depth in bits 0..23, stencil 24..31      */
+  VKR_FMT_RG16_UNORM     = 2,  /* 2 x uint16                                       */
+  VKR_FMT_RG16_SFLOAT    = 3,  /* 2 x fp16                                         */
+  VKR_FMT_RGBA8_SRGB     = 4,  /* 4 x uint8, rgb sRGB-encoded, a linear            */
+  VKR_FMT_RGBA8_UNORM    = 5,  /* 4 x uint8                                        */
+  VKR_FMT_RGBA16_UNORM   = 6,  /* 4 x uint16                                       */
+  VKR_FMT_RGBA16_SFLOAT  = 7,  /* 4 x fp16                                         */
+  VKR_FMT_R16_SFLOAT     = 8,  /* 1 x fp16                                         */
+  VKR_FMT_R32_SFLOAT     = 9,  /* 1 x fp32                                         */
+  VKR_FMT_R8_UNORM       = 10  /* 1 x uint8 (create_gtao_texture, gtao.cpp:10)     */
+} vkr_format;
+
+/* bytes per texel of a vkr_format (0 for unknown) */
+uint32_t vkr_format_bytes(uint32_t format);
+
+typedef struct vkr_img {
+  void*    base;                       /* device pointer, start of view-mip 0       */
+  uint32_t format;                     /* vkr_format                                */
+  uint32_t mip_count;                  /* mips in this view (>=1)                   */
+  uint32_t width, height;              /* extent of view-mip 0 held in memory       */
+  uint32_t full_width, full_height;    /* extent of view-mip 0 of the whole frame   */
+  int32_t  origin_x, origin_y;         /* window origin inside the frame, view-mip 0*/
+  uint32_t pitch_bytes[VKR_MAX_MIPS];  /* row pitch of each mip                     */
+  uint64_t mip_offset[VKR_MAX_MIPS];   /* byte offset of each mip from `base`       */
+} vkr_img;
+
+/* 4x4 column-major float matrix, memory-compatible with glm::mat4 */
+typedef struct vkr_mat4 { float m[16]; } vkr_mat4;
+
+/* ---- UBO structs, byte-compatible with what the reference uploads ------------------ */
+
+/* GTAOParams, gtao.hpp:12-18 / main.comp:7-13 */
+typedef struct vkr_gtao_params {
+  vkr_mat4 normal_mat;
+  float fovy, aspect, znear, zfar;
+} vkr_gtao_params;
+
+/* push constants of gtao_compute_main, gtao.cpp:101-113 / main.comp:20-26 */
+typedef struct vkr_gtao_push {
+  float    angle_offset;
+  float    weight_ratio;
+  uint32_t use_mis;
+  uint32_t two_directions;
+  uint32_t reflections_only;
+} vkr_gtao_push;
+
+/* push constants of gtao_filter, gtao.cpp:210-215 / filter.comp:12-15 */
+typedef struct vkr_gtao_filter_push { float znear, zfar; } vkr_gtao_filter_push;
+
+/* AccumConstants, gtao.cpp:300-305 / accum.comp:16-21 */
+typedef struct vkr_gtao_accum_params {
+  vkr_mat4 inverse_camera;
+  vkr_mat4 prev_inverse_camera;
+  vkr_mat4 mvp;
+  float    fovy_aspect_znear_zfar[4];
+} vkr_gtao_accum_params;
+
+typedef struct vkr_gtao_accum_push { uint32_t clear_history; } vkr_gtao_accum_push;
+
+/* TraceParams, advanced_ssr.cpp:138-145 / trace.comp:9-16 (std140: mat4, uint, 4 floats) */
+typedef struct vkr_trace_params {
+  vkr_mat4 normal_mat;
+  uint32_t frame_random;
+  float fovy, aspect, znear, zfar;
+} vkr_trace_params;
+
+typedef struct vkr_trace_push  { float max_roughness; } vkr_trace_push;     /* trace.comp:24-26  */
+typedef struct vkr_filter_push { uint32_t render_flags; } vkr_filter_push;  /* filter.comp:28-30 */
+#define VKR_NORMALIZE_REFLECTIONS  1u   /* filter.comp:22-24 */
+#define VKR_ACCUMULATE_REFLECTIONS 2u
+#define VKR_BILATERAL_FILTER       4u
+
+/* blur.comp:16-20 / advanced_ssr.cpp:388-392 */
+typedef struct vkr_blur_push {
+  float    max_roughness;
+  uint32_t accumulate;
+  uint32_t disable_blur;
+} vkr_blur_push;
+
+/* ReprojectConsts (blur.comp:22-26) == TAAUniforms (resolve.comp:11-15, taa.cpp:24-28) */
+typedef struct vkr_reproject_params {
+  vkr_mat4 inverse_camera;
+  vkr_mat4 prev_inverse_camera;
+  float    fovy_aspect_znear_zfar[4];
+} vkr_reproject_params;
+
+/* SSRParams of the simple SSR pass, ssr.hpp:8-15 / ssr/shader.frag:9-16 */
+typedef struct vkr_ssr_params {
+  vkr_mat4 normal_mat;
+  float fovy, aspect, znear, zfar;
+} vkr_ssr_params;
+
+/* Parameters of the synthetic G-buffer generator (replaces the raster stage
+ * scene_renderer.cpp:140-220 + gbuf/opaque_taa.{vert,frag}). */
+typedef struct vkr_synth_params {
+  vkr_mat4 camera_to_world;   /* inverse view matrix of the frame being generated    */
+  vkr_mat4 prev_mvp;          /* projection * previous view (velocity, opaque_taa.vert)*/
+  vkr_mat4 mvp;               /* projection * current view                           */
+  float    fovy, aspect, znear, zfar;
+  uint32_t seed;              /* PCG32 stream for the checker / per-object material  */
+  uint32_t flags;             /* bit0: depth only (used for prev_depth)              */
+} vkr_synth_params;
+#define VKR_SYNTH_DEPTH_ONLY 1u
+
+/* ---- entry points ------------------------------------------------------------------- */
+
+const char* vkr_version(void);
+const char* vkr_last_error(void);
+
+/* program "downsample_gbuffer": downsample_pass.cpp:25-92 + downsample_gbuffer.frag:12-37.
+ * depth: full image (view mip 0 = image mip 0, >=2 mips); writes depth mip 1.           */
+int vkr_downsample_gbuffer(const vkr_img* depth, const vkr_img* normal, const vkr_img* velocity,
+                           const vkr_img* out_normal, const vkr_img* out_velocity, void* stream);
+
+/* program "depth_mips": downsample_pass.cpp:94-131 + depth_mips.frag:7-15.
+ * Builds mips src_mip+1 .. mip_count-1, each the 2x2 min of its parent.                 */
+int vkr_depth_mips(const vkr_img* depth, uint32_t src_mip, void* stream);
+
+/* program "pdf_preintegrate": advanced_ssr.cpp:95-114 + preintegrate.comp:45-84          */
+int vkr_pdf_preintegrate(const vkr_img* out_pdf, void* stream);
+
+/* program "sssr_trace": advanced_ssr.cpp:147-214 + trace.comp (bindings 0..7)            */
+int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                   const vkr_trace_params* params, const float* halton_vec4 /*device, 128 x vec4*/,
+                   const vkr_img* out_ray, const vkr_img* out_occlusion, const vkr_img* pdf_tex,
+                   const vkr_trace_push* push, void* stream);
+
+/* program "sssr_filter": advanced_ssr.cpp:308-369 + filter.comp (bindings 0..6)          */
+int vkr_sssr_filter(const vkr_img* rays, const vkr_img* depth, const vkr_img* albedo,
+                    const vkr_img* normal, const vkr_img* material, const vkr_img* out_reflections,
+                    const vkr_trace_params* params, const vkr_filter_push* push, void* stream);
+
+/* program "sssr_blur": advanced_ssr.cpp:371-438 + blur.comp (bindings 0..8)              */
+int vkr_sssr_blur(const vkr_img* depth, const vkr_img* normal, const vkr_img* reflections,
+                  const vkr_img* material, const vkr_img* history, const vkr_img* velocity,
+                  const vkr_img* history_depth, const vkr_img* out_blurred,
+                  const vkr_reproject_params* params, const vkr_blur_push* push, void* stream);
+
+/* program "gtao_compute_main": gtao.cpp:84-148 + gtao/main.comp (bindings 0..5)          */
+int vkr_gtao_main(const vkr_img* depth, const vkr_gtao_params* params, const vkr_img* normal,
+                  const vkr_img* material, const vkr_img* pdf_tex, const vkr_img* gtao_inout,
+                  const vkr_gtao_push* push, void* stream);
+
+/* program "gtao_filter": gtao.cpp:198-239 + gtao/filter.comp (bindings 0..2)             */
+int vkr_gtao_filter(const vkr_img* depth, const vkr_img* raw_gtao, const vkr_img* out_filtered,
+                    const vkr_gtao_filter_push* push, void* stream);
+
+/* program "gtao_accumulate": gtao.cpp:286-347 + gtao/accum.comp (bindings 0..6)          */
+int vkr_gtao_accumulate(const vkr_img* depth, const vkr_img* prev_depth, const vkr_img* current_ao,
+                        const vkr_img* out_accumulated, const vkr_img* velocity, const vkr_img* history,
+                        const vkr_gtao_accum_params* params, const vkr_gtao_accum_push* push,
+                        void* stream);
+
+/* program "taa_resolve": taa.cpp:19-63 + taa/resolve.comp (bindings 0..6)                */
+int vkr_taa_resolve(const vkr_img* history_color, const vkr_img* history_depth,
+                    const vkr_img* current_depth, const vkr_img* velocity, const vkr_img* color,
+                    const vkr_img* out_color, const vkr_reproject_params* params, void* stream);
+
+/* synthetic G-buffer generator (no reference program).  Any of the
+ * colour outputs may be NULL when VKR_SYNTH_DEPTH_ONLY is set.                          */
+int vkr_synth_gbuffer(const vkr_img* depth, const vkr_img* normal, const vkr_img* albedo,
+                      const vkr_img* material, const vkr_img* velocity,
+                      const vkr_synth_params* params, void* stream);
+
+/* float4 streaming-read microbenchmark: the measured-roofline denominator of
+ * SURVEY.md 8(d).  Reads `bytes` from `src`, writes one float per block to `sink`.      */
+int vkr_stream_read(const void* src, uint64_t bytes, float* sink, uint32_t sink_len, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKR_POSTFX_H_INCLUDED */

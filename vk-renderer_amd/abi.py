@@ -1,0 +1,198 @@
+"""ctypes mirror of include/vkr_postfx.h (the C-ABI of the HIP hot path).
+
+Struct layouts must stay byte-identical to the header; tests/test_abi.py checks the
+sizes against values the shared library reports and that every declared symbol is
+exported.  Nothing here computes anything: it only declares types and loads libraries.
+"""
+import ctypes as C
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRODUCT_LIB = os.path.join(ROOT, "vk-renderer_amd", "csrc", "libvkr_postfx.so")
+HOST_LIB = os.path.join(ROOT, "vk-renderer_amd", "host", "libvkr_host.so")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "libvkr_oracle.so")
+
+VKR_MAX_MIPS = 16
+HALTON_SEQ_SIZE = 128
+
+# vkr_format
+FMT_D24_UNORM_S8 = 1
+FMT_RG16_UNORM = 2
+FMT_RG16_SFLOAT = 3
+FMT_RGBA8_SRGB = 4
+FMT_RGBA8_UNORM = 5
+FMT_RGBA16_UNORM = 6
+FMT_RGBA16_SFLOAT = 7
+FMT_R16_SFLOAT = 8
+FMT_R32_SFLOAT = 9
+FMT_R8_UNORM = 10
+FORMAT_BYTES = {1: 4, 2: 4, 3: 4, 4: 4, 5: 4, 6: 8, 7: 8, 8: 2, 9: 4, 10: 1}
+
+NORMALIZE_REFLECTIONS = 1
+ACCUMULATE_REFLECTIONS = 2
+BILATERAL_FILTER = 4
+SYNTH_DEPTH_ONLY = 1
+
+
+class VkrImg(C.Structure):
+    _fields_ = [
+        ("base", C.c_void_p),
+        ("format", C.c_uint32),
+        ("mip_count", C.c_uint32),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("full_width", C.c_uint32),
+        ("full_height", C.c_uint32),
+        ("origin_x", C.c_int32),
+        ("origin_y", C.c_int32),
+        ("pitch_bytes", C.c_uint32 * VKR_MAX_MIPS),
+        ("mip_offset", C.c_uint64 * VKR_MAX_MIPS),
+    ]
+
+
+class Mat4(C.Structure):
+    _fields_ = [("m", C.c_float * 16)]
+
+    @staticmethod
+    def from_np(a):
+        """a: 4x4 numpy array in maths (row, col) convention -> column-major storage."""
+        import numpy as np
+
+        m = Mat4()
+        flat = np.asarray(a, dtype=np.float32).T.reshape(-1)
+        for i in range(16):
+            m.m[i] = float(flat[i])
+        return m
+
+
+class GtaoParams(C.Structure):
+    _fields_ = [("normal_mat", Mat4), ("fovy", C.c_float), ("aspect", C.c_float), ("znear", C.c_float), ("zfar", C.c_float)]
+
+
+class GtaoPush(C.Structure):
+    _fields_ = [("angle_offset", C.c_float), ("weight_ratio", C.c_float), ("use_mis", C.c_uint32),
+                ("two_directions", C.c_uint32), ("reflections_only", C.c_uint32)]
+
+
+class GtaoFilterPush(C.Structure):
+    _fields_ = [("znear", C.c_float), ("zfar", C.c_float)]
+
+
+class GtaoAccumParams(C.Structure):
+    _fields_ = [("inverse_camera", Mat4), ("prev_inverse_camera", Mat4), ("mvp", Mat4),
+                ("fovy_aspect_znear_zfar", C.c_float * 4)]
+
+
+class GtaoAccumPush(C.Structure):
+    _fields_ = [("clear_history", C.c_uint32)]
+
+
+class TraceParams(C.Structure):
+    _fields_ = [("normal_mat", Mat4), ("frame_random", C.c_uint32), ("fovy", C.c_float), ("aspect", C.c_float),
+                ("znear", C.c_float), ("zfar", C.c_float)]
+
+
+class TracePush(C.Structure):
+    _fields_ = [("max_roughness", C.c_float)]
+
+
+class FilterPush(C.Structure):
+    _fields_ = [("render_flags", C.c_uint32)]
+
+
+class BlurPush(C.Structure):
+    _fields_ = [("max_roughness", C.c_float), ("accumulate", C.c_uint32), ("disable_blur", C.c_uint32)]
+
+
+class ReprojectParams(C.Structure):
+    _fields_ = [("inverse_camera", Mat4), ("prev_inverse_camera", Mat4), ("fovy_aspect_znear_zfar", C.c_float * 4)]
+
+
+class SsrParams(C.Structure):
+    _fields_ = [("normal_mat", Mat4), ("fovy", C.c_float), ("aspect", C.c_float), ("znear", C.c_float), ("zfar", C.c_float)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("camera_to_world", Mat4), ("prev_mvp", Mat4), ("mvp", Mat4), ("fovy", C.c_float), ("aspect", C.c_float),
+                ("znear", C.c_float), ("zfar", C.c_float), ("seed", C.c_uint32), ("flags", C.c_uint32)]
+
+
+P = C.POINTER
+_IMG = P(VkrImg)
+
+# name -> argument types *without* the trailing stream (the oracle's vkr_ref_* twins
+# take the same arguments minus the stream, on host memory).
+ENTRY_ARGS = {
+    "downsample_gbuffer": [_IMG, _IMG, _IMG, _IMG, _IMG],
+    "depth_mips": [_IMG, C.c_uint32],
+    "pdf_preintegrate": [_IMG],
+    "sssr_trace": [_IMG, _IMG, _IMG, P(TraceParams), C.c_void_p, _IMG, _IMG, _IMG, P(TracePush)],
+    "sssr_filter": [_IMG, _IMG, _IMG, _IMG, _IMG, _IMG, P(TraceParams), P(FilterPush)],
+    "sssr_blur": [_IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, P(ReprojectParams), P(BlurPush)],
+    "gtao_main": [_IMG, P(GtaoParams), _IMG, _IMG, _IMG, _IMG, P(GtaoPush)],
+    "gtao_filter": [_IMG, _IMG, _IMG, P(GtaoFilterPush)],
+    "gtao_accumulate": [_IMG, _IMG, _IMG, _IMG, _IMG, _IMG, P(GtaoAccumParams), P(GtaoAccumPush)],
+    "taa_resolve": [_IMG, _IMG, _IMG, _IMG, _IMG, _IMG, P(ReprojectParams)],
+    "synth_gbuffer": [_IMG, _IMG, _IMG, _IMG, _IMG, P(SynthParams)],
+}
+
+
+class ExtensionMissing(RuntimeError):
+    pass
+
+
+def _load(path, what):
+    if not os.path.exists(path):
+        raise ExtensionMissing(
+            f"{what} not built: {path} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` first."
+        )
+    return C.CDLL(path)
+
+
+_product = None
+_oracle = None
+
+
+def product():
+    """The HIP C-ABI library.  Fails loudly when it is missing — there is no fallback."""
+    global _product
+    if _product is None:
+        lib = _load(PRODUCT_LIB, "HIP extension libvkr_postfx.so")
+        for name, args in ENTRY_ARGS.items():
+            fn = getattr(lib, "vkr_" + name)
+            fn.argtypes = args + [C.c_void_p]
+            fn.restype = C.c_int
+        lib.vkr_stream_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.vkr_stream_read.restype = C.c_int
+        lib.vkr_version.restype = C.c_char_p
+        lib.vkr_last_error.restype = C.c_char_p
+        lib.vkr_format_bytes.argtypes = [C.c_uint32]
+        lib.vkr_format_bytes.restype = C.c_uint32
+        _product = lib
+    return _product
+
+
+def oracle():
+    """CPU restatement of the reference shaders.  TEST INFRASTRUCTURE: only tests/,
+    __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this."""
+    global _oracle
+    if _oracle is None:
+        lib = _load(ORACLE_LIB, "oracle libvkr_oracle.so")
+        for name, args in ENTRY_ARGS.items():
+            fn = getattr(lib, "vkr_ref_" + name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        lib.vkr_ref_halton23.argtypes = [C.c_void_p, C.c_uint32]
+        lib.vkr_ref_halton23.restype = None
+        lib.vkr_ref_threads.restype = C.c_int
+        lib.vkr_ref_set_threads.argtypes = [C.c_int]
+        _oracle = lib
+    return _oracle
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        msg = ""
+        if lib is not None and hasattr(lib, "vkr_last_error"):
+            msg = (lib.vkr_last_error() or b"").decode()
+        raise RuntimeError(f"vkr call failed with code {rc}: {msg}")

@@ -1,0 +1,242 @@
+"""The post-process chain as a flat sequence of C-ABI calls on one set of images.
+
+This is the thin Python driver used by the parity tests and `smoke()`: it allocates the
+resource set of Gbuffer / GTAO / AdvancedSSR / TAA (scene_renderer.cpp:8-44, gtao.cpp:17-47,
+advanced_ssr.cpp:62-92, taa.cpp:3-12) and issues the passes in the frame order of
+main.cpp:345-391.  `backend` is either the HIP library (abi.product(), device memory) or —
+in tests only — the oracle (abi.oracle(), host memory); both expose the same entry points.
+The production host layer with the reference's pass structs lives in host/ (C++).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .camera import FrameSetup
+from .images import ImageBuf, depth_mip_count
+
+PDF_LUT_SIZE = 1024
+
+
+class PostFxChain:
+    def __init__(self, width, height, backend="product", device=None, setup=None, window=None):
+        """window: None (single GPU) or (ox, oy, w, h) full-res window of the frame held by this instance."""
+        self.W, self.H = width, height
+        self.backend = backend
+        if backend == "product":
+            self.lib = abi.product()
+            self.prefix = "vkr_"
+            if device is None:
+                device = "cuda"
+            self.stream = self._stream_ptr(device)
+        else:
+            self.lib = abi.oracle()
+            self.prefix = "vkr_ref_"
+            device = None
+            self.stream = None
+        self.device = device
+        self.setup = setup or FrameSetup(width, height)
+        if window is None:
+            window = (0, 0, width, height)
+        ox, oy, ww, wh = window
+        assert ox % 2 == 0 and oy % 2 == 0 and ww % 2 == 0 and wh % 2 == 0
+        self.window = window
+        L = depth_mip_count(width, height)
+        self.L = L
+        full, org = (width, height), (ox, oy)
+        half, horg = (width // 2, height // 2), (ox // 2, oy // 2)
+        w2, h2 = ww // 2, wh // 2
+
+        def img(fmt, w, h, mips=1, f=full, o=org, fill=0):
+            return ImageBuf(fmt, w, h, mips, device=device, full=f, origin=o, fill=fill)
+
+        # Gbuffer (scene_renderer.cpp:8-44).  Tiled instances keep only mips 0..1 of the window;
+        # the Hi-Z pyramid SSR marches (image mips 1..L-1 of the whole frame) is `pyramid`.
+        tiled = (ww, wh) != (width, height)
+        self.tiled = tiled
+        dm = 2 if tiled else L
+        self.depth = img(abi.FMT_D24_UNORM_S8, ww, wh, dm)
+        self.prev_depth = img(abi.FMT_D24_UNORM_S8, ww, wh, dm)
+        self.normal = img(abi.FMT_RG16_UNORM, ww, wh)
+        self.albedo = img(abi.FMT_RGBA8_SRGB, ww, wh)
+        self.material = img(abi.FMT_RGBA8_SRGB, ww, wh)
+        self.velocity = img(abi.FMT_RG16_SFLOAT, ww, wh)
+        self.dn = img(abi.FMT_RG16_UNORM, w2, h2, f=half, o=horg)
+        self.dv = img(abi.FMT_RG16_SFLOAT, w2, h2, f=half, o=horg)
+        # GTAO (gtao.cpp:26-38)
+        self.raw = img(abi.FMT_RGBA16_SFLOAT, w2, h2, f=half, o=horg)
+        self.filtered = img(abi.FMT_R16_SFLOAT, w2, h2, f=half, o=horg)
+        self.acc_ao = img(abi.FMT_RG16_SFLOAT, w2, h2, f=half, o=horg)
+        self.acc_hist = img(abi.FMT_RG16_SFLOAT, w2, h2, f=half, o=horg)
+        # AdvancedSSR (advanced_ssr.cpp:62-92)
+        self.rays = img(abi.FMT_RGBA16_UNORM, w2, h2, f=half, o=horg)
+        self.reflections = img(abi.FMT_RGBA8_UNORM, w2, h2, f=half, o=horg)
+        self.blurred = img(abi.FMT_RGBA8_UNORM, w2, h2, f=half, o=horg)
+        self.blurred_hist = img(abi.FMT_RGBA8_UNORM, w2, h2, f=half, o=horg)
+        self.pdf = ImageBuf(abi.FMT_R32_SFLOAT, PDF_LUT_SIZE, PDF_LUT_SIZE, device=device)
+        self.halton = self._make_halton()
+        # TAA (taa.cpp:6-9)
+        self.taa_hist = img(abi.FMT_RGBA16_SFLOAT, ww, wh)
+        self.taa_target = img(abi.FMT_RGBA16_SFLOAT, ww, wh)
+        self.frame_index = 0
+
+    # ---- plumbing -------------------------------------------------------------------
+    @staticmethod
+    def _stream_ptr(device):
+        import torch
+
+        return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def _make_halton(self):
+        """advanced_ssr.cpp:22-34,54-58: 128 x vec4 UBO, xy = Halton(2,3) of index i+1 (float-floor quirk)."""
+        def elem(index, base):
+            f, r, cur = np.float32(1.0), np.float32(0.0), index
+            while True:
+                f = np.float32(f / np.float32(base))
+                r = np.float32(r + np.float32(f * np.float32(cur % base)))
+                cur = int(np.floor(np.float32(np.float32(cur) / np.float32(base))))
+                if cur <= 0:
+                    break
+            return r
+
+        h = np.zeros((abi.HALTON_SEQ_SIZE, 4), dtype=np.float32)
+        for i in range(abi.HALTON_SEQ_SIZE):
+            h[i, 0], h[i, 1] = elem(i + 1, 2), elem(i + 1, 3)
+        self.halton_host = h
+        if self.device is None:
+            return h
+        import torch
+
+        return torch.from_numpy(h).to(self.device)
+
+    def _halton_ptr(self):
+        if self.device is None:
+            return C.c_void_p(self.halton.ctypes.data)
+        return C.c_void_p(self.halton.data_ptr())
+
+    def call(self, name, *args):
+        fn = getattr(self.lib, self.prefix + name)
+        if self.backend == "product":
+            rc = fn(*args, self.stream)
+        else:
+            rc = fn(*args)
+        abi.check(rc, self.lib if self.backend == "product" else None)
+
+    def sync(self):
+        if self.device is not None:
+            import torch
+
+            torch.cuda.synchronize(self.device)
+
+    # ---- G-buffer ---------------------------------------------------------------------
+    def synth(self):
+        s = self.setup
+        p = s.synth()
+        self.call("synth_gbuffer", C.byref(self.depth.desc(0, 1)), C.byref(self.normal.desc()), C.byref(self.albedo.desc()),
+                  C.byref(self.material.desc()), C.byref(self.velocity.desc()), C.byref(p))
+        pp = s.synth(prev=True, depth_only=True)
+        self.call("synth_gbuffer", C.byref(self.prev_depth.desc(0, 1)), None, None, None, None, C.byref(pp))
+
+    def build_prev_hiz(self):
+        """prev_depth's mips: what last frame's DownsamplePass left in the image that is now prev_depth (main.cpp:416)."""
+        scratch_n = ImageBuf(abi.FMT_RG16_UNORM, self.dn.width, self.dn.height, device=self.device)
+        scratch_v = ImageBuf(abi.FMT_RG16_SFLOAT, self.dn.width, self.dn.height, device=self.device)
+        n0 = ImageBuf(abi.FMT_RG16_UNORM, self.normal.width, self.normal.height, device=self.device)
+        v0 = ImageBuf(abi.FMT_RG16_SFLOAT, self.normal.width, self.normal.height, device=self.device)
+        self.call("downsample_gbuffer", C.byref(self.prev_depth.desc()), C.byref(n0.desc()), C.byref(v0.desc()),
+                  C.byref(scratch_n.desc()), C.byref(scratch_v.desc()))
+        self.call("depth_mips", C.byref(self.prev_depth.desc()), 1)
+        self.sync()
+
+    def init_histories(self):
+        """TAA history = current colour, AO history (1, 1/255), SSR history 0."""
+        col = self.albedo.decode()[..., :3]
+        th = np.zeros((self.albedo.height, self.albedo.width, 4), dtype=np.float16)
+        th[..., :3] = col.astype(np.float16)
+        host = ImageBuf(abi.FMT_RGBA16_SFLOAT, self.taa_hist.width, self.taa_hist.height)
+        host.set_raw(th)
+        self.taa_hist.upload(host.host)
+        ah = np.zeros((self.acc_hist.height, self.acc_hist.width, 2), dtype=np.float16)
+        ah[..., 0] = 1.0
+        ah[..., 1] = np.float16(1.0 / 255.0)
+        host = ImageBuf(abi.FMT_RG16_SFLOAT, self.acc_hist.width, self.acc_hist.height)
+        host.set_raw(ah)
+        self.acc_hist.upload(host.host)
+
+    # ---- passes, in frame order (main.cpp:347-391) ----------------------------------------
+    def downsample(self):
+        self.call("downsample_gbuffer", C.byref(self.depth.desc()), C.byref(self.normal.desc()), C.byref(self.velocity.desc()),
+                  C.byref(self.dn.desc()), C.byref(self.dv.desc()))
+        self.call("depth_mips", C.byref(self.depth.desc()), 1)
+
+    def preintegrate_pdf(self):
+        self.call("pdf_preintegrate", C.byref(self.pdf.desc()))
+
+    def ssr_trace(self, frame_random=None, max_roughness=1.0):
+        tp = self.setup.trace_params(frame_random)
+        push = abi.TracePush(max_roughness)
+        # advanced_ssr.cpp:186: depth view = mips 1..L-1
+        self.call("sssr_trace", C.byref(self.depth.desc(1, self.depth.mips - 1)), C.byref(self.dn.desc()),
+                  C.byref(self.material.desc()), C.byref(tp), self._halton_ptr(), C.byref(self.rays.desc()),
+                  C.byref(self.raw.desc()), C.byref(self.pdf.desc()), C.byref(push))
+
+    def ssr_filter(self, render_flags=7):
+        tp = self.setup.trace_params()
+        push = abi.FilterPush(render_flags)
+        nm = min(10, self.depth.mips)  # advanced_ssr.cpp:342: mips 0..9
+        self.call("sssr_filter", C.byref(self.rays.desc()), C.byref(self.depth.desc(0, nm)), C.byref(self.albedo.desc()),
+                  C.byref(self.normal.desc()), C.byref(self.material.desc()), C.byref(self.reflections.desc()),
+                  C.byref(tp), C.byref(push))
+
+    def ssr_blur(self, max_roughness=1.0, accumulate=1, disable_blur=0):
+        rp = self.setup.reproject_params()
+        push = abi.BlurPush(max_roughness, accumulate, disable_blur)
+        nm = min(10, self.depth.mips)
+        self.call("sssr_blur", C.byref(self.depth.desc(0, nm)), C.byref(self.normal.desc()), C.byref(self.reflections.desc()),
+                  C.byref(self.material.desc()), C.byref(self.blurred_hist.desc()), C.byref(self.dv.desc()),
+                  C.byref(self.prev_depth.desc(0, nm)), C.byref(self.blurred.desc()), C.byref(rp), C.byref(push))
+
+    def gtao_main(self, **push_kw):
+        gp = self.setup.gtao_params()
+        push = self.setup.gtao_push(**push_kw)
+        # gtao.cpp:119: depth image-mip 1 bound as a 1-mip view
+        self.call("gtao_main", C.byref(self.depth.desc(1, 1)), C.byref(gp), C.byref(self.normal.desc()),
+                  C.byref(self.material.desc()), C.byref(self.pdf.desc()), C.byref(self.raw.desc()), C.byref(push))
+
+    def gtao_filter(self):
+        push = self.setup.gtao_filter_push()
+        self.call("gtao_filter", C.byref(self.depth.desc(1, 1)), C.byref(self.raw.desc()), C.byref(self.filtered.desc()),
+                  C.byref(push))
+
+    def gtao_accumulate(self, clear_history=0):
+        ap = self.setup.gtao_accum_params()
+        push = abi.GtaoAccumPush(clear_history)
+        self.call("gtao_accumulate", C.byref(self.depth.desc(1, 1)), C.byref(self.prev_depth.desc(1, 1)),
+                  C.byref(self.filtered.desc()), C.byref(self.acc_ao.desc()), C.byref(self.dv.desc()),
+                  C.byref(self.acc_hist.desc()), C.byref(ap), C.byref(push))
+
+    def taa(self, color=None):
+        rp = self.setup.reproject_params()
+        color = color or self.albedo  # colour input until the deferred composite exists
+        self.call("taa_resolve", C.byref(self.taa_hist.desc()), C.byref(self.prev_depth.desc()), C.byref(self.depth.desc()),
+                  C.byref(self.velocity.desc()), C.byref(color.desc()), C.byref(self.taa_target.desc()), C.byref(rp))
+
+    def frame(self):
+        """One steady-state frame of the chain: D1 D2 S1 S2 S3 G1 G2 G3 T (main.cpp:347-391)."""
+        self.downsample()
+        self.ssr_trace(frame_random=self.frame_index % 16)  # advanced_ssr.cpp:168-171
+        self.ssr_filter()
+        self.ssr_blur()
+        self.gtao_main()
+        self.gtao_filter()
+        self.gtao_accumulate()
+        self.taa()
+        self.frame_index += 1
+
+    def swap_histories(self):
+        """main.cpp:416-420 minus depth<->prev_depth (the benchmark G-buffer is static)."""
+        self.taa_hist, self.taa_target = self.taa_target, self.taa_hist
+        self.blurred, self.blurred_hist = self.blurred_hist, self.blurred
+        self.acc_ao, self.acc_hist = self.acc_hist, self.acc_ao
+
+    OUTPUTS = ("dn", "dv", "depth", "rays", "raw", "reflections", "blurred", "filtered", "acc_ao", "taa_target")
