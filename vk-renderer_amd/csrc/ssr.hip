@@ -1,0 +1,438 @@
+// ssr.hip — stochastic Hi-Z screen-space reflections: programs "pdf_preintegrate",
+// "sssr_trace", "sssr_filter", "sssr_blur".
+//
+// Reference: src/advanced_ssr.cpp:95-114,147-214,308-438 and
+// shaders/advanced_ssr/{preintegrate,trace,filter,blur}.comp, include/screen_trace.glsl.
+// Roofline: HBM in the compulsory-bytes model (10.3 / 16 / 14 B per full-res pixel), but the
+// march is a chain of <= 80 dependent texel fetches per ray and the blur up to 23x23 taps,
+// so trace is latency-bound and blur ALU/LDS-bound.
+#include "vkr_host.hpp"
+
+namespace vkr {
+
+// ---- pdf_preintegrate (preintegrate.comp:45-65,77-84) ------------------------------------
+__global__ __launch_bounds__(256) void k_pdf_preintegrate(Tex out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= out.w || y >= out.h) return;
+  const int STEP_COUNT = 2000;
+  const float a = (2.0f * ((float)x + 0.5f)) / (float)out.fw - 1.0f;
+  const float b = ((float)y + 0.5f) / (float)out.fh;
+  const float p = b - a, q = b + a;
+  const float dt = 2.0f / (float)STEP_COUNT;
+  float sum = 0.0f;
+  for (int i = 0; i < STEP_COUNT; i++) {
+    const float t = -1.0f + dt * ((float)i + 0.5f);
+    const float L = p * t + q;
+    const float nom = (1.0f - t) * L;
+    const float denom = (1.0f + t * t) - (0.5f * L) * L;
+    sum += (L > 0.0f) ? nom / (denom * denom) : 0.0f;
+  }
+  *texel_ptr<float>(out, x, y) = (2.0f / (float)STEP_COUNT) * sum;
+}
+
+// ---- sssr_trace ------------------------------------------------------------------------------
+struct TraceArgs {
+  Pyramid depth;       // view mips 0.. = image mips 1.. (advanced_ssr.cpp:186)
+  Tex normal;          // downsampled normals, RG16_UNORM
+  Tex material;        // full-res RGBA8_SRGB, bilinear at half-res uv
+  Tex pdf;
+  Tex out_ray, out_occ;
+  const float4* halton;
+  Mat4 normal_mat;
+  Proj pr;
+  uint32_t frame_random;
+  float max_roughness;
+};
+
+// trace.comp:143-154
+VKR_DEV f3 get_tangent(f3 n) {
+  float max_xy = vmax(fabsf(n.x), fabsf(n.y));
+  f3 t = (max_xy < 0.00001f) ? mk3(1, 0, 0) : mk3(n.y, -n.x, 0);
+  return normalize(t);
+}
+
+// brdf.glsl:135-155; cos/sin(phi) in double, rounded once (they steer the march)
+VKR_DEV f3 sampleGGXVNDF(f3 Ve, float alpha_x, float alpha_y, float U1, float U2) {
+  f3 Vh = normalize(mk3(alpha_x * Ve.x, alpha_y * Ve.y, Ve.z));
+  float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+  f3 T1 = lensq > 0.0f ? mk3(-Vh.y, Vh.x, 0.0f) * (1.0f / sqrtf(lensq)) : mk3(1, 0, 0);
+  f3 T2 = cross(Vh, T1);
+  float r = sqrtf(U1);
+  float phi = (2.0f * VKR_PI) * U2;
+  float t1 = r * (float)cos((double)phi);
+  float t2 = r * (float)sin((double)phi);
+  float s = 0.5f * (1.0f + Vh.z);
+  t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
+  f3 Nh = (t1 * T1 + t2 * T2) + sqrtf(vmax(0.0f, (1.0f - t1 * t1) - t2 * t2)) * Vh;
+  return normalize(mk3(alpha_x * Nh.x, alpha_y * Nh.y, vmax(0.0f, Nh.z)));
+}
+
+// texelFetch(depth_tex, ivec2(p), mip) on the pyramid: beyond the last mip or out of the
+// (floored) mip extent -> 0
+VKR_DEV float pyramid_fetch(const Pyramid& pyr, int gx, int gy, int mip) {
+  if (mip < 0 || mip >= pyr.count) return 0.0f;
+  return fetch<FmtD24>(pyr.mip[mip], gx, gy);
+}
+
+// One thread per ray; a wave covers an 8x8 pixel tile (block 8x8x4 tiles) so that the
+// rays of a wave start in neighbouring texels and share cache lines while they stay coherent.
+__global__ __launch_bounds__(256) void k_sssr_trace(TraceArgs a) {
+  // 256 threads = 4 waves; wave w owns the 8x8 tile (blockIdx.x*4 + w, blockIdx.y)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lx = (blockIdx.x * 4 + wave) * 8 + (lane & 7);
+  const int ly = blockIdx.y * 8 + (lane >> 3);
+  if (lx >= a.out_ray.w || ly >= a.out_ray.h) return;
+  const int gx = a.out_ray.ox + lx, gy = a.out_ray.oy + ly;
+  const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
+  const f2 screen_uv = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
+  const Proj pr = a.pr;
+
+  // trace.comp:49-58
+  float roughness = sample<FmtSRGB8>(a.material, screen_uv).y;
+  const float mg = mixf(0.0f, a.max_roughness, roughness);
+  roughness = mg * mg;
+  const Tex& depth0 = a.depth.mip[0];
+  const float pixel_depth = sample<FmtD24>(depth0, screen_uv);
+  const f3 pixel_normal_world = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
+  const f3 pixel_normal = normalize(xyz(mul(a.normal_mat, mk4(pixel_normal_world.x, pixel_normal_world.y, pixel_normal_world.z, 0.0f))));
+  const f3 view_vec = reconstruct_view_vec(screen_uv, pixel_depth, pr);
+
+  // trace.comp:61-63,156-158: rand() -> Halton index; sin evaluated in double
+  const float rdot = dot(screen_uv, mk2(12.9898f, 78.233f));
+  const float rnd01 = fractf((float)sin((double)rdot) * 43758.5453f);
+  const uint32_t base_index = f2u(rnd01 * (float)VKR_HALTON_SEQ_SIZE);
+  const uint32_t index = (base_index + a.frame_random) & (VKR_HALTON_SEQ_SIZE - 1);
+  const float4 hv = a.halton[index];
+
+  // trace.comp:65-77
+  f3 tangent = get_tangent(pixel_normal);
+  const f3 bitangent = normalize(cross(pixel_normal, tangent));
+  tangent = normalize(cross(bitangent, pixel_normal));
+  f3 view_dir = -normalize(view_vec);
+  view_dir = mk3(dot(view_dir, tangent), dot(view_dir, bitangent), dot(view_dir, pixel_normal));
+  const f3 brdf_norm = sampleGGXVNDF(view_dir, roughness, roughness, hv.x, hv.y);
+  const f3 N = (brdf_norm.x * tangent + brdf_norm.y * bitangent) + brdf_norm.z * pixel_normal;
+  const f3 R = reflect(view_vec, N);
+
+  // trace.comp:79-84
+  f3 ray_start = project_view_vec(view_vec + 0.001f * pixel_normal, pr);
+  ray_start.z -= 0.0001f;
+  f3 ray_dir = project_view_vec(view_vec + R, pr);
+  ray_dir = ray_dir - ray_start;
+  ray_dir = ray_dir * ((1.0f - ray_start.z) / ray_dir.z);
+
+  // ---- hierarchical_raymarch_find_hor (trace.comp:206-268, screen_trace.glsl:8-49) ----
+  const f3 origin = ray_start, direction = ray_dir;
+  const f3 inv_direction = mk3(direction.x != 0.0f ? 1.0f / direction.x : 3.402823466e+38f,
+                               direction.y != 0.0f ? 1.0f / direction.y : 3.402823466e+38f,
+                               direction.z != 0.0f ? 1.0f / direction.z : 3.402823466e+38f);
+  const f2 screen_size = mk2((float)depth0.fw, (float)depth0.fh);
+  f2 res = screen_size;  // most_detailed_mip = 0: screen_size * 0.5^0
+  f2 res_inv = mk2(1.0f / res.x, 1.0f / res.y);
+  f2 uv_offset = mk2(0.005f / screen_size.x, 0.005f / screen_size.y);
+  uv_offset.x = direction.x < 0.0f ? -uv_offset.x : uv_offset.x;
+  uv_offset.y = direction.y < 0.0f ? -uv_offset.y : uv_offset.y;
+  const f2 floor_offset = mk2(direction.x < 0.0f ? 0.0f : 1.0f, direction.y < 0.0f ? 0.0f : 1.0f);
+
+  float current_t;
+  f3 position;
+  {  // initial_advance_ray
+    f2 cur_pos = res * xy(origin);
+    f2 xy_plane = mk2(floorf(cur_pos.x), floorf(cur_pos.y)) + floor_offset;
+    xy_plane = xy_plane * res_inv + uv_offset;
+    f2 t = (xy_plane - xy(origin)) * xy(inv_direction);
+    current_t = vmin(t.x, t.y);
+    position = origin + current_t * direction;
+  }
+  float h = 0.0f;
+  int current_mip = 0;
+  int i = 0;
+#pragma unroll 1
+  while (i < 80 && current_mip >= 0) {
+    const f2 mip_pos = res * xy(position);
+    const float surface_z = pyramid_fetch(a.depth, f2i(mip_pos.x), f2i(mip_pos.y), current_mip);
+    // advance_ray (screen_trace.glsl:17-45)
+    f2 xy_plane = mk2(floorf(mip_pos.x), floorf(mip_pos.y)) + floor_offset;
+    xy_plane = xy_plane * res_inv + uv_offset;
+    f3 t = (mk3(xy_plane.x, xy_plane.y, surface_z) - origin) * inv_direction;
+    t.z = direction.z > 0.0f ? t.z : 3.402823466e+38f;
+    const float t_min = vmin(vmin(t.x, t.y), t.z);
+    const bool above_surface = surface_z > position.z;
+    const bool skipped_tile = (t_min != t.z) && above_surface;
+    current_t = above_surface ? t_min : current_t;
+    position = origin + current_t * direction;
+    // trace.comp:245-250: the first 15 steps stay on the finest mip
+    const bool mip0sample = i < 15;
+    current_mip += mip0sample ? 0 : (skipped_tile ? 1 : -1);
+    const float rs = mip0sample ? 1.0f : (skipped_tile ? 0.5f : 2.0f);
+    const float ri = mip0sample ? 1.0f : (skipped_tile ? 2.0f : 0.5f);
+    res = res * rs;
+    res_inv = res_inv * ri;
+    ++i;
+    // trace.comp:253-262: horizon tracking
+    if (current_mip <= 1) {
+      const f3 v = reconstruct_view_vec(xy(position), surface_z, pr) - view_vec;
+      const float h2 = dot(pixel_normal, normalize(v));
+      if (length(v) < 0.3f) h = vmax(h, h2);
+    }
+  }
+  bool valid_hit = true;  // i <= 80 always (trace.comp:265)
+  const f3 out_ray = position;
+
+  // trace.comp:94-118
+  {
+    const f2 ray_step = mk2(fabsf(out_ray.x - ray_start.x) * tex_size.x, fabsf(out_ray.y - ray_start.y) * tex_size.y);
+    if (vmax(ray_step.x, ray_step.y) < 2.0f) valid_hit = false;
+  }
+  if (valid_hit) {
+    const f3 hnw = decode_normal(sample<FmtRG16U>(a.normal, xy(out_ray)));
+    const f3 hit_normal = xyz(mul(a.normal_mat, mk4(hnw.x, hnw.y, hnw.z, 0.0f)));
+    if (dot(hit_normal, R) > 0.0f || dot(pixel_normal, R) < 0.0f) valid_hit = false;
+  }
+  if (valid_hit) {
+    const float hit_depth = sample<FmtD24>(depth0, xy(out_ray));
+    const float hit_z = linearize_depth2(hit_depth, pr.znear, pr.zfar);
+    const float ray_z = linearize_depth2(out_ray.z, pr.znear, pr.zfar);
+    if (ray_z > hit_z + 0.3f || ray_z < hit_z - 0.1f) valid_hit = false;
+  }
+  {  // RGBA16_UNORM store (advanced_ssr.cpp:62)
+    uint2 o;
+    o.x = float_to_unorm16(out_ray.x) | (float_to_unorm16(out_ray.y) << 16);
+    o.y = float_to_unorm16(out_ray.z) | (float_to_unorm16(valid_hit ? pixel_depth : 1.0f) << 16);
+    *texel_ptr<uint2>(a.out_ray, lx, ly) = o;
+  }
+  // trace.comp:123-139: (occlusion, pdf) into gtao.raw.  h was reset to 0 inside the march,
+  // so the `no_occlusion` (h == -1) case of the reference never fires.
+  {
+    const f3 w0 = -normalize(view_vec);
+    const f3 slice_normal = normalize(cross(w0, R));
+    const f3 normal_projected = pixel_normal - dot(pixel_normal, slice_normal) * slice_normal;
+    const f3 X = normalize(cross(slice_normal, w0));
+    const float n = VKR_PI / 2.0f - acosf(dot(normalize(normal_projected), X));
+    float hh = acosf(h);
+    hh = vmin(n + vmin(hh - n, VKR_PI / 2.0f), hh);
+    const float pdf = sampleGGXdirPDF(a.pdf, w0, pixel_normal, R, roughness);
+    const float occlusion = arc_occlusion(hh, n, length(normal_projected));
+    const float result = is_nan(occlusion) ? 0.0f : occlusion;
+    uint2 o;
+    o.x = float_to_half_bits(result) | (float_to_half_bits(pdf) << 16);
+    o.y = 0u;
+    *texel_ptr<uint2>(a.out_occ, lx, ly) = o;
+  }
+}
+
+// ---- sssr_filter (filter.comp:36-149, FULL_RES 0) -----------------------------------------------
+struct FilterArgs {
+  Tex rays, depth1, albedo, normal, material, out;
+  Mat4 normal_mat;
+  Proj pr;
+  uint32_t render_flags;
+};
+
+__global__ __launch_bounds__(256) void k_sssr_filter(FilterArgs a) {
+  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+  if (lx >= a.out.w || ly >= a.out.h) return;
+  const int gx = a.out.ox + lx, gy = a.out.oy + ly;
+  const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
+  const f2 screen_uv = mk2((float)gx / tex_size.x, (float)gy / tex_size.y);  // no +0.5 (filter.comp:39)
+  const f3 material = sample<FmtSRGB8>(a.material, screen_uv);
+  const float metallic = material.z, roughness = material.y;
+  const f3 albedo = sample<FmtSRGB8>(a.albedo, screen_uv);
+  const f3 F0 = F0_approximation(albedo, metallic);
+  f3 color_sum = mk3(0, 0, 0), weight_sum = mk3(0, 0, 0);
+  const float center_depth = fetch<FmtD24>(a.depth1, gx, gy);
+  const int taps = (a.render_flags & VKR_NORMALIZE_REFLECTIONS) ? 5 : 1;
+  const int offs[5][2] = {{0, 0}, {-1, 0}, {0, 1}, {1, 0}, {0, -1}};
+  for (int k = 0; k < taps; k++) {
+    const int px = gx + offs[k][0], py = gy + offs[k][1];
+    const f4 trace_result = fetch<FmtRGBA16U>(a.rays, px, py);
+    const f2 pixel_uv = mk2((float)px / tex_size.x, (float)py / tex_size.y);
+    const float pixel_depth = fetch<FmtD24>(a.depth1, px, py);
+    const f3 view_vec = reconstruct_view_vec(pixel_uv, pixel_depth, a.pr);
+    const f3 pnw = decode_normal(sample<FmtRG16U>(a.normal, pixel_uv));
+    const f3 Nn = xyz(mul(a.normal_mat, mk4(pnw.x, pnw.y, pnw.z, 0.0f)));
+    const f3 hit_vec = reconstruct_view_vec(mk2(trace_result.x, trace_result.y), trace_result.z, a.pr);
+    const f3 radiance = (trace_result.w != 1.0f) ? sample<FmtSRGB8>(a.albedo, mk2(trace_result.x, trace_result.y)) : mk3(0, 0, 0);
+    const f3 V = -normalize(view_vec);
+    const f3 L = normalize(hit_vec - view_vec);
+    // ray_weight (filter.comp:97-108), literal swapped argument order of brdfG1
+    const f3 H = normalize(V + L);
+    const f3 F = fresnelSchlick(vmax(dot(H, V), 0.0f), F0);
+    const float alpha2 = roughness * roughness;
+    const float NdotL = vmax(dot(Nn, L), 0.0f), NdotV = vmax(dot(Nn, V), 0.0f);
+    const float G2 = brdfG2(NdotL, NdotV, alpha2);
+    const float G1 = brdfG1(NdotV, alpha2);
+    f3 weight = (F * G2) / G1;
+    float bilateral_weight = 1.0f;
+    if (a.render_flags & VKR_BILATERAL_FILTER)
+      bilateral_weight = vmax(1.0f - (1000.0f * fabsf(center_depth - pixel_depth)) / center_depth, 0.0f);
+    weight = weight * bilateral_weight;
+    color_sum = color_sum + weight * radiance;
+    weight_sum = weight_sum + weight;
+  }
+  if (vmax(weight_sum.x, vmax(weight_sum.y, weight_sum.z)) < 0.001f) weight_sum = mk3(1, 1, 1);
+  color_sum = color_sum / weight_sum;
+  *texel_ptr<uint32_t>(a.out, lx, ly) =
+      float_to_unorm8(color_sum.x) | (float_to_unorm8(color_sum.y) << 8) | (float_to_unorm8(color_sum.z) << 16);
+}
+
+// ---- sssr_blur (blur.comp:31-115) ------------------------------------------------------------------
+struct BlurArgs {
+  Tex depth1, normal, refl, material, history, velocity, hist_depth1, out;
+  Mat4 inverse_camera, prev_inverse_camera;
+  Proj pr;
+  float max_roughness;
+  uint32_t accumulate, disable_blur;
+};
+
+__global__ __launch_bounds__(256) void k_sssr_blur(BlurArgs a) {
+  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+  if (lx >= a.out.w || ly >= a.out.h) return;
+  const int gx = a.out.ox + lx, gy = a.out.oy + ly;
+  const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
+  const f2 screen_uv = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
+  float roughness = sample<FmtSRGB8>(a.material, screen_uv).y;
+  roughness = mixf(0.0f, a.max_roughness, roughness);
+  const float center_depth = fetch<FmtD24>(a.depth1, gx, gy);
+  const f3 center_normal = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
+  float sigma = mixf(0.4f, 4.0f, roughness);
+  if (a.disable_blur != 0) sigma = 0.35f;
+  float weight_sum = 0.0f;
+  f3 color = mk3(0, 0, 0);
+  const int r = f2i(floorf(3.0f * sigma - 0.01f));
+  const float g = 1.0f / (((2.0f * VKR_PI) * sigma) * sigma);
+  const float e = (2.0f * sigma) * sigma;
+#pragma unroll 1
+  for (int i = -r; i <= r; i++) {
+#pragma unroll 1
+    for (int j = -r; j <= r; j++) {
+      const int px = gx + i, py = gy + j;
+      const f2 uv = mk2((float)px / tex_size.x, (float)py / tex_size.y);
+      const float pixel_depth = fetch<FmtD24>(a.depth1, px, py);
+      const f3 pixel_normal = decode_normal(sample<FmtRG16U>(a.normal, uv));
+      const float bilateral_weight = vmax(1.0f - (1000.0f * fabsf(center_depth - pixel_depth)) / center_depth, 0.0f);
+      const float normal_weight = vmax(dot(center_normal, pixel_normal), 0.0f);
+      float w = g * expf((float)(-(i * i + j * j)) / e);
+      w *= bilateral_weight;
+      w *= normal_weight;
+      color = color + fetch<FmtRGBA8>(a.refl, px, py) * w;
+      weight_sum += w;
+    }
+  }
+  color = color / vmax(weight_sum, 0.001f);
+
+  bool reprojected = false;
+  const f2 velocity = sample<FmtRG16F>(a.velocity, screen_uv);
+  const float delta_len = length(velocity);
+  const f2 prev_uv = screen_uv + velocity;
+  if (prev_uv.x >= 0.0f && prev_uv.y >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y <= 1.0f) {
+    const f3 vc = reconstruct_view_vec(screen_uv, sample<FmtD24>(a.depth1, screen_uv), a.pr);
+    const f3 v_world_cur = xyz(mul(a.inverse_camera, mk4(vc.x, vc.y, vc.z, 1.0f)));
+    const f3 vp = reconstruct_view_vec(prev_uv, sample<FmtD24>(a.hist_depth1, prev_uv), a.pr);
+    const f3 v_world_prev = xyz(mul(a.prev_inverse_camera, mk4(vp.x, vp.y, vp.z, 1.0f)));
+    const f3 v_camera = xyz(mul(a.inverse_camera, mk4(0, 0, 0, 1)));
+    const float error = length(v_world_cur - v_world_prev);
+    const float pixel_dist = length(v_world_cur - v_camera);
+    reprojected = (delta_len < 0.0001f) || (error < vclamp((0.1f * pixel_dist) * delta_len, 0.01f, 0.1f));
+  }
+  if (a.accumulate == 0) reprojected = false;
+  if (reprojected) {
+    const f3 history_color = sample<FmtRGBA8>(a.history, screen_uv);  // screen_uv, not prev_uv (blur.comp:103)
+    color = mix3(history_color, color, 0.1f);
+  }
+  *texel_ptr<uint32_t>(a.out, lx, ly) =
+      float_to_unorm8(color.x) | (float_to_unorm8(color.y) << 8) | (float_to_unorm8(color.z) << 16);
+}
+
+}  // namespace vkr
+
+using namespace vkr;
+
+extern "C" int vkr_pdf_preintegrate(const vkr_img* out_pdf, void* stream) {
+  Tex out;
+  VKR_TRY(make_tex(out_pdf, 0, VKR_FMT_R32_SFLOAT, "pdf_preintegrate.out", &out));
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_pdf_preintegrate, grid2d(out.w, out.h, block), block, 0, (hipStream_t)stream, out);
+  return launch_status("pdf_preintegrate");
+}
+
+static void load_proj(Proj& pr, float fovy, float aspect, float znear, float zfar) {
+  pr.tg = tanf(fovy / 2.0f);
+  pr.aspect = aspect; pr.znear = znear; pr.zfar = zfar;
+}
+
+extern "C" int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                              const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                              const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_trace_push* push,
+                              void* stream) {
+  if (!params || !push || !halton_vec4 || !depth) { set_error("sssr_trace: NULL argument"); return VKR_ERR_NULL; }
+  if (((uintptr_t)halton_vec4 % 16) != 0) { set_error("sssr_trace: halton buffer must be 16-byte aligned"); return VKR_ERR_LAYOUT; }
+  TraceArgs a;
+  if (depth->mip_count < 1 || depth->mip_count > VKR_MAX_MIPS) { set_error("sssr_trace: bad depth mip count"); return VKR_ERR_MIPS; }
+  a.depth.count = (int)depth->mip_count;
+  for (int i = 0; i < a.depth.count; i++) VKR_TRY(make_tex(depth, i, VKR_FMT_D24_UNORM_S8, "sssr_trace.depth", &a.depth.mip[i]));
+  for (int i = a.depth.count; i < 16; i++) a.depth.mip[i] = a.depth.mip[0];
+  VKR_TRY(make_tex(normal, 0, VKR_FMT_RG16_UNORM, "sssr_trace.normal", &a.normal));
+  VKR_TRY(make_tex(material, 0, VKR_FMT_RGBA8_SRGB, "sssr_trace.material", &a.material));
+  VKR_TRY(make_tex(pdf_tex, 0, VKR_FMT_R32_SFLOAT, "sssr_trace.pdf", &a.pdf));
+  VKR_TRY(make_tex(out_ray, 0, VKR_FMT_RGBA16_UNORM, "sssr_trace.out_ray", &a.out_ray));
+  VKR_TRY(make_tex(out_occlusion, 0, VKR_FMT_RGBA16_SFLOAT, "sssr_trace.out_occlusion", &a.out_occ));
+  if (!same_window(a.out_ray, a.out_occ)) { set_error("sssr_trace: ray / occlusion outputs differ in extent"); return VKR_ERR_EXTENT; }
+  a.halton = (const float4*)halton_vec4;
+  load_mat(a.normal_mat, params->normal_mat);
+  load_proj(a.pr, params->fovy, params->aspect, params->znear, params->zfar);
+  a.frame_random = params->frame_random;
+  a.max_roughness = push->max_roughness;
+  dim3 block(256, 1);
+  dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 7) / 8);
+  hipLaunchKernelGGL(k_sssr_trace, grid, block, 0, (hipStream_t)stream, a);
+  return launch_status("sssr_trace");
+}
+
+extern "C" int vkr_sssr_filter(const vkr_img* rays, const vkr_img* depth, const vkr_img* albedo, const vkr_img* normal,
+                               const vkr_img* material, const vkr_img* out_reflections, const vkr_trace_params* params,
+                               const vkr_filter_push* push, void* stream) {
+  if (!params || !push) { set_error("sssr_filter: NULL argument"); return VKR_ERR_NULL; }
+  FilterArgs a;
+  VKR_TRY(make_tex(rays, 0, VKR_FMT_RGBA16_UNORM, "sssr_filter.rays", &a.rays));
+  VKR_TRY(make_tex(depth, 1, VKR_FMT_D24_UNORM_S8, "sssr_filter.depth (level 1)", &a.depth1));  // filter.comp:75,121
+  VKR_TRY(make_tex(albedo, 0, VKR_FMT_RGBA8_SRGB, "sssr_filter.albedo", &a.albedo));
+  VKR_TRY(make_tex(normal, 0, VKR_FMT_RG16_UNORM, "sssr_filter.normal", &a.normal));
+  VKR_TRY(make_tex(material, 0, VKR_FMT_RGBA8_SRGB, "sssr_filter.material", &a.material));
+  VKR_TRY(make_tex(out_reflections, 0, VKR_FMT_RGBA8_UNORM, "sssr_filter.out", &a.out));
+  load_mat(a.normal_mat, params->normal_mat);
+  load_proj(a.pr, params->fovy, params->aspect, params->znear, params->zfar);
+  a.render_flags = push->render_flags;
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_sssr_filter, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  return launch_status("sssr_filter");
+}
+
+extern "C" int vkr_sssr_blur(const vkr_img* depth, const vkr_img* normal, const vkr_img* reflections,
+                             const vkr_img* material, const vkr_img* history, const vkr_img* velocity,
+                             const vkr_img* history_depth, const vkr_img* out_blurred,
+                             const vkr_reproject_params* params, const vkr_blur_push* push, void* stream) {
+  if (!params || !push) { set_error("sssr_blur: NULL argument"); return VKR_ERR_NULL; }
+  BlurArgs a;
+  VKR_TRY(make_tex(depth, 1, VKR_FMT_D24_UNORM_S8, "sssr_blur.depth (level 1)", &a.depth1));  // blur.comp:42,62,111
+  VKR_TRY(make_tex(normal, 0, VKR_FMT_RG16_UNORM, "sssr_blur.normal", &a.normal));
+  VKR_TRY(make_tex(reflections, 0, VKR_FMT_RGBA8_UNORM, "sssr_blur.reflections", &a.refl));
+  VKR_TRY(make_tex(material, 0, VKR_FMT_RGBA8_SRGB, "sssr_blur.material", &a.material));
+  VKR_TRY(make_tex(history, 0, VKR_FMT_RGBA8_UNORM, "sssr_blur.history", &a.history));
+  VKR_TRY(make_tex(velocity, 0, VKR_FMT_RG16_SFLOAT, "sssr_blur.velocity", &a.velocity));
+  VKR_TRY(make_tex(history_depth, 1, VKR_FMT_D24_UNORM_S8, "sssr_blur.history_depth (level 1)", &a.hist_depth1));
+  VKR_TRY(make_tex(out_blurred, 0, VKR_FMT_RGBA8_UNORM, "sssr_blur.out", &a.out));
+  load_mat(a.inverse_camera, params->inverse_camera);
+  load_mat(a.prev_inverse_camera, params->prev_inverse_camera);
+  load_proj(a.pr, params->fovy_aspect_znear_zfar[0], params->fovy_aspect_znear_zfar[1], params->fovy_aspect_znear_zfar[2],
+            params->fovy_aspect_znear_zfar[3]);
+  a.max_roughness = push->max_roughness;
+  a.accumulate = push->accumulate;
+  a.disable_blur = push->disable_blur;
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_sssr_blur, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  return launch_status("sssr_blur");
+}

@@ -1,0 +1,265 @@
+// vkr_device.hpp — device-side vocabulary of the HIP hot path (gfx950).
+//
+// * f2/f3/f4 value types with one frozen IEEE-754 binary32 operation order
+//   (no FMA contraction: the library is built with -ffp-contract=off) so hit/no-hit
+//   and horizon-break decisions are reproducible bit-for-bit;
+// * Tex: one mip of a pitch-linear image window in HBM; typed texel loaders for the
+//   reference's storage formats (scene_renderer.cpp:13-43, gtao.cpp:26-47,
+//   advanced_ssr.cpp:62-92, taa.cpp:6);
+// * bilinear / texelFetch with gpu::DEFAULT_SAMPLER semantics
+//   (src/gpu/samplers.hpp:36-55): linear, clamp-to-edge, LOD 0 of the bound view;
+//   out-of-frame texelFetch returns 0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace vkr {
+
+#define VKR_DEV __device__ __forceinline__
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+struct i2 { int x, y; };
+
+VKR_DEV f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+VKR_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+VKR_DEV f4 mk4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+VKR_DEV f3 xyz(f4 v) { return mk3(v.x, v.y, v.z); }
+VKR_DEV f2 xy(f3 v) { return mk2(v.x, v.y); }
+VKR_DEV f2 xy(f4 v) { return mk2(v.x, v.y); }
+
+VKR_DEV f2 operator+(f2 a, f2 b) { return mk2(a.x + b.x, a.y + b.y); }
+VKR_DEV f2 operator-(f2 a, f2 b) { return mk2(a.x - b.x, a.y - b.y); }
+VKR_DEV f2 operator*(f2 a, f2 b) { return mk2(a.x * b.x, a.y * b.y); }
+VKR_DEV f2 operator/(f2 a, f2 b) { return mk2(a.x / b.x, a.y / b.y); }
+VKR_DEV f2 operator*(f2 a, float s) { return mk2(a.x * s, a.y * s); }
+VKR_DEV f2 operator*(float s, f2 a) { return mk2(s * a.x, s * a.y); }
+VKR_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+VKR_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+VKR_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+VKR_DEV f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+VKR_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+VKR_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+VKR_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+VKR_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+VKR_DEV f4 operator/(f4 a, float s) { return mk4(a.x / s, a.y / s, a.z / s, a.w / s); }
+
+// IEEE minNum / maxNum (v_min_f32 / v_max_f32)
+VKR_DEV float vmin(float a, float b) { return fminf(a, b); }
+VKR_DEV float vmax(float a, float b) { return fmaxf(a, b); }
+VKR_DEV float vclamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+VKR_DEV int iclamp(int x, int lo, int hi) { return min(max(x, lo), hi); }
+VKR_DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+VKR_DEV f2 mix2(f2 a, f2 b, float t) { return mk2(mixf(a.x, b.x, t), mixf(a.y, b.y, t)); }
+VKR_DEV f3 mix3(f3 a, f3 b, float t) { return mk3(mixf(a.x, b.x, t), mixf(a.y, b.y, t), mixf(a.z, b.z, t)); }
+VKR_DEV f4 mix4(f4 a, f4 b, float t) { return mk4(mixf(a.x, b.x, t), mixf(a.y, b.y, t), mixf(a.z, b.z, t), mixf(a.w, b.w, t)); }
+VKR_DEV f3 min3(f3 a, f3 b) { return mk3(vmin(a.x, b.x), vmin(a.y, b.y), vmin(a.z, b.z)); }
+VKR_DEV f3 max3(f3 a, f3 b) { return mk3(vmax(a.x, b.x), vmax(a.y, b.y), vmax(a.z, b.z)); }
+VKR_DEV float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
+VKR_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+VKR_DEV float length(f2 a) { return sqrtf(dot(a, a)); }
+VKR_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
+VKR_DEV f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+VKR_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+VKR_DEV f3 reflect(f3 I, f3 N) { return I - (2.0f * dot(N, I)) * N; }
+VKR_DEV bool is_nan(float a) { return a != a; }
+VKR_DEV float fractf(float a) { return a - floorf(a); }
+// float -> int: truncate, NaN -> 0, saturate at +-2^30 (a following +1 cannot overflow)
+VKR_DEV int f2i(float f) { return (f != f) ? 0 : (int)fminf(fmaxf(f, -1073741824.0f), 1073741824.0f); }
+VKR_DEV uint32_t f2u(float f) { return (f != f) ? 0u : (uint32_t)fminf(fmaxf(f, 0.0f), 1073741824.0f); }
+
+#define VKR_PI 3.1415926535897932384626433832795f
+
+struct Mat4 { float m[16]; };  // column-major
+VKR_DEV f4 mul(const Mat4& M, f4 v) {
+  f4 r;
+  r.x = ((M.m[0] * v.x + M.m[4] * v.y) + M.m[8] * v.z) + M.m[12] * v.w;
+  r.y = ((M.m[1] * v.x + M.m[5] * v.y) + M.m[9] * v.z) + M.m[13] * v.w;
+  r.z = ((M.m[2] * v.x + M.m[6] * v.y) + M.m[10] * v.z) + M.m[14] * v.w;
+  r.w = ((M.m[3] * v.x + M.m[7] * v.y) + M.m[11] * v.z) + M.m[15] * v.w;
+  return r;
+}
+
+// ---- storage codecs -------------------------------------------------------------------
+#include "srgb_tables.inc"
+VKR_DEV float srgb8_to_float(uint32_t c) { return __uint_as_float(k_srgb_decode_bits[c]); }
+VKR_DEV uint32_t float_to_srgb8(float x) {
+  if (x != x) return 0u;
+  int lo = 0, hi = 255;  // largest i with thresh[i] <= x
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (__uint_as_float(k_srgb_thresh_bits[mid]) <= x) lo = mid; else hi = mid - 1;
+  }
+  return (uint32_t)lo;
+}
+VKR_DEV float d24_to_float(uint32_t t) { return (float)(t & 0xFFFFFFu) / 16777215.0f; }
+VKR_DEV float unorm16_to_float(uint32_t v) { return (float)v / 65535.0f; }
+VKR_DEV float unorm8_to_float(uint32_t v) { return (float)v / 255.0f; }
+VKR_DEV uint32_t float_to_unorm16(float f) { return (uint32_t)rintf(vclamp(f, 0.0f, 1.0f) * 65535.0f); }
+VKR_DEV uint32_t float_to_unorm8(float f) { return (uint32_t)rintf(vclamp(f, 0.0f, 1.0f) * 255.0f); }
+VKR_DEV float half_bits_to_float(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)h)); }
+VKR_DEV uint32_t float_to_half_bits(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
+
+// ---- image windows ----------------------------------------------------------------------
+// One mip level of an image window.  (w,h): extent held in memory; (fw,fh): extent of the
+// whole frame at this mip; (ox,oy): window origin in the frame.
+struct Tex {
+  const uint8_t* p;
+  int pitch;
+  int w, h;
+  int fw, fh;
+  int ox, oy;
+};
+struct Pyramid {
+  Tex mip[16];
+  int count;
+};
+
+struct FmtD24 { typedef float T; static VKR_DEV T zero() { return 0.0f; }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return d24_to_float(*(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4)); }
+  static VKR_DEV T lerp(T a, T b, float f) { return mixf(a, b, f); } };
+struct FmtR32F { typedef float T; static VKR_DEV T zero() { return 0.0f; }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return *(const float*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4); }
+  static VKR_DEV T lerp(T a, T b, float f) { return mixf(a, b, f); } };
+struct FmtR16F { typedef float T; static VKR_DEV T zero() { return 0.0f; }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return half_bits_to_float(*(const uint16_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 2)); }
+  static VKR_DEV T lerp(T a, T b, float f) { return mixf(a, b, f); } };
+struct FmtRG16U { typedef f2 T; static VKR_DEV T zero() { return mk2(0, 0); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint32_t v = *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);
+    return mk2(unorm16_to_float(v & 0xFFFFu), unorm16_to_float(v >> 16)); }
+  static VKR_DEV T lerp(T a, T b, float f) { return mix2(a, b, f); } };
+struct FmtRG16F { typedef f2 T; static VKR_DEV T zero() { return mk2(0, 0); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint32_t v = *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);
+    return mk2(half_bits_to_float(v & 0xFFFFu), half_bits_to_float(v >> 16)); }
+  static VKR_DEV T lerp(T a, T b, float f) { return mix2(a, b, f); } };
+// rgb of an RGBA8_SRGB texel (alpha is never consumed on this path)
+struct FmtSRGB8 { typedef f3 T; static VKR_DEV T zero() { return mk3(0, 0, 0); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint32_t v = *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);
+    return mk3(srgb8_to_float(v & 0xFFu), srgb8_to_float((v >> 8) & 0xFFu), srgb8_to_float((v >> 16) & 0xFFu)); }
+  static VKR_DEV T lerp(T a, T b, float f) { return mix3(a, b, f); } };
+struct FmtRGBA8 { typedef f3 T; static VKR_DEV T zero() { return mk3(0, 0, 0); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint32_t v = *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);
+    return mk3(unorm8_to_float(v & 0xFFu), unorm8_to_float((v >> 8) & 0xFFu), unorm8_to_float((v >> 16) & 0xFFu)); }
+  static VKR_DEV T lerp(T a, T b, float f) { return mix3(a, b, f); } };
+struct FmtRGBA16U { typedef f4 T; static VKR_DEV T zero() { return mk4(0, 0, 0, 0); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint2 v = *(const uint2*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 8);
+    return mk4(unorm16_to_float(v.x & 0xFFFFu), unorm16_to_float(v.x >> 16), unorm16_to_float(v.y & 0xFFFFu), unorm16_to_float(v.y >> 16)); }
+  static VKR_DEV T lerp(T a, T b, float f) { return mix4(a, b, f); } };
+struct FmtRGBA16F { typedef f4 T; static VKR_DEV T zero() { return mk4(0, 0, 0, 0); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint2 v = *(const uint2*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 8);
+    return mk4(half_bits_to_float(v.x & 0xFFFFu), half_bits_to_float(v.x >> 16), half_bits_to_float(v.y & 0xFFFFu), half_bits_to_float(v.y >> 16)); }
+  static VKR_DEV T lerp(T a, T b, float f) { return mix4(a, b, f); } };
+
+// texelFetch at frame coordinates: outside the frame -> 0; inside the frame but outside
+// the window (tiling with too small a halo) -> clamped to the window.
+template <class F> VKR_DEV typename F::T fetch(const Tex& t, int gx, int gy) {
+  if (gx < 0 || gy < 0 || gx >= t.fw || gy >= t.fh) return F::zero();
+  int lx = iclamp(gx - t.ox, 0, t.w - 1), ly = iclamp(gy - t.oy, 0, t.h - 1);
+  return F::load(t, lx, ly);
+}
+template <class F> VKR_DEV typename F::T fetch_clamped(const Tex& t, int gx, int gy) {
+  gx = iclamp(gx, 0, t.fw - 1);
+  gy = iclamp(gy, 0, t.fh - 1);
+  int lx = iclamp(gx - t.ox, 0, t.w - 1), ly = iclamp(gy - t.oy, 0, t.h - 1);
+  return F::load(t, lx, ly);
+}
+// texture()/textureLod()/textureOffset(): bilinear, clamp-to-edge
+template <class F> VKR_DEV typename F::T sample(const Tex& t, f2 uv, int offx = 0, int offy = 0) {
+  float x = uv.x * (float)t.fw - 0.5f, y = uv.y * (float)t.fh - 0.5f;
+  float x0f = floorf(x), y0f = floorf(y);
+  float fx = x - x0f, fy = y - y0f;
+  int x0 = f2i(x0f) + offx, y0 = f2i(y0f) + offy;
+  typename F::T t00 = fetch_clamped<F>(t, x0, y0), t10 = fetch_clamped<F>(t, x0 + 1, y0);
+  typename F::T t01 = fetch_clamped<F>(t, x0, y0 + 1), t11 = fetch_clamped<F>(t, x0 + 1, y0 + 1);
+  return F::lerp(F::lerp(t00, t10, fx), F::lerp(t01, t11, fx), fy);
+}
+
+template <class T> VKR_DEV T* texel_ptr(const Tex& t, int lx, int ly) { return (T*)(const_cast<uint8_t*>(t.p) + (size_t)ly * t.pitch) + lx; }
+
+// ---- shared shader helpers (gbuffer_encode.glsl / brdf.glsl), literal operation order -------
+struct Proj { float tg, aspect, znear, zfar; };  // tg = tanf(fovy/2) evaluated on the host
+
+// gbuffer_encode.glsl:5-7
+VKR_DEV float sign_nz(float k) { return (k >= 0.0f) ? 1.0f : -1.0f; }
+// gbuffer_encode.glsl:17-27
+VKR_DEV f2 encode_normal(f3 v) {
+  float l1norm = (fabsf(v.x) + fabsf(v.y)) + fabsf(v.z);
+  float inv = 1.0f / l1norm;
+  f2 r = mk2(v.x * inv, v.y * inv);
+  if (v.z < 0.0f) r = mk2((1.0f - fabsf(r.y)) * sign_nz(r.x), (1.0f - fabsf(r.x)) * sign_nz(r.y));
+  return mk2(0.5f * r.x + 0.5f, 0.5f * r.y + 0.5f);
+}
+// gbuffer_encode.glsl:29-37
+VKR_DEV f3 decode_normal(f2 uv) {
+  uv = mk2(2.0f * uv.x - 1.0f, 2.0f * uv.y - 1.0f);
+  f3 v = mk3(uv.x, uv.y, (1.0f - fabsf(uv.x)) - fabsf(uv.y));
+  if (v.z < 0.0f) {
+    float nx = (1.0f - fabsf(v.y)) * sign_nz(v.x);
+    float ny = (1.0f - fabsf(v.x)) * sign_nz(v.y);
+    v.x = nx; v.y = ny;
+  }
+  return normalize(v);
+}
+// gbuffer_encode.glsl:53-56
+VKR_DEV float linearize_depth2(float d, float n, float f) { return (n * f) / (d * (f - n) - f); }
+// gbuffer_encode.glsl:58-69
+VKR_DEV f3 reconstruct_view_vec(f2 uv, float d, const Proj& pr) {
+  float z = linearize_depth2(d, pr.znear, pr.zfar);
+  float xd = 2.0f * uv.x - 1.0f, yd = 2.0f * uv.y - 1.0f;
+  float x = -(xd) * ((z * pr.aspect) * pr.tg);
+  float y = -(yd) * (z * pr.tg);
+  return mk3(x, y, z);
+}
+// gbuffer_encode.glsl:71-73
+VKR_DEV float encode_depth(float z, float n, float f) { return f / (f - n) + (f * n) / (z * (f - n)); }
+// gbuffer_encode.glsl:75-84
+VKR_DEV f3 project_view_vec(f3 v, const Proj& pr) {
+  float n = pr.znear, f = pr.zfar, z = v.z;
+  float depth = f / (f - n) + (f * n) / (z * (f - n));
+  float pu = v.x / ((-v.z * pr.tg) * pr.aspect);
+  float pv = v.y / (-z * pr.tg);
+  return mk3(0.5f * pu + 0.5f, 0.5f * pv + 0.5f, depth);
+}
+
+// brdf.glsl:6-13
+VKR_DEV f3 fresnelSchlick(float cos_theta, f3 F0) {
+  float p = powf(vclamp(1.0f - cos_theta, 0.0f, 1.0f), 5.0f);
+  return F0 + (mk3(1.0f, 1.0f, 1.0f) - F0) * p;
+}
+VKR_DEV f3 F0_approximation(f3 albedo, float metallic) { return mix3(mk3(0.04f, 0.04f, 0.04f), albedo, metallic); }
+// brdf.glsl:43-56
+VKR_DEV float brdfG1(float alpha2, float NdotV) {
+  float NdotV2 = NdotV * NdotV;
+  float tgv2 = (1.0f - NdotV2) / NdotV2;
+  return 2.0f / (1.0f + sqrtf(1.0f + alpha2 * tgv2));
+}
+VKR_DEV float brdfG2(float NdotV, float NdotL, float alpha2) {
+  float NdotV2 = NdotV * NdotV, NdotL2 = NdotL * NdotL;
+  float L1 = sqrtf(1.0f + (alpha2 * (1.0f - NdotV2)) / NdotV2);
+  float L2 = sqrtf(1.0f + (alpha2 * (1.0f - NdotL2)) / NdotL2);
+  return 2.0f / (L1 + L2);
+}
+// brdf.glsl:107-128 (live #else branch)
+VKR_DEV float sampleGGXdirPDF(const Tex& pdf_tex, f3 V, f3 N, f3 L, float alpha) {
+  f3 Y = normalize(cross(V, N));
+  f3 X = normalize(cross(Y, V));
+  alpha = vclamp(alpha, 0.0f, 0.9f);
+  f3 Lproj = normalize(L - V * dot(V, L));
+  float cos_theta = dot(X, Lproj);
+  const float cos_phin = dot(N, X);
+  const float sin_phin = sqrtf(1.0f - cos_phin * cos_phin);
+  const float alpha2 = alpha * alpha;
+  const float coef = sqrtf(1.0f - alpha2);
+  const float a = ((0.5f * coef) * cos_phin) * cos_theta + 0.5f;
+  const float b = coef * sin_phin;
+  return alpha2 / ((2.0f * VKR_PI) * coef) * sample<FmtR32F>(pdf_tex, mk2(a, b));
+}
+
+// the cosine-weighted horizon arc shared by main.comp:246-248 and trace.comp:127-134
+VKR_DEV float arc_occlusion(float h, float n, float len_np) {
+  return (((1.0f / VKR_PI) * len_np) * 0.25f) * vmax((-cosf(2.0f * h - n) + cosf(n)) + (2.0f * h) * sinf(n), 0.0f);
+}
+
+}  // namespace vkr
