@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the post-process hot path (Hi-Z + SSR + GTAO + TAA composite).
+
+One "step" = one steady-state frame of the chain of main.cpp:347-391 on a resident synthetic
+G-buffer: DownsampleGbuffer, DownsampleDepth x (L-2), SSSR_trace, SSSR_filter, SSSR_blur,
+GTAO_main, GTAO_filter, GTAO_accumulate, TAA, then the history remaps of main.cpp:416-420.
+N = 1 runs BASELINE.json configs[1] (3840x2160).  N > 1 (launched by torch.distributed.run, one
+rank per GPU) tiles a larger frame, one 3840x2160 tile per GPU ("weak" scaling), exchanging the
+Hi-Z pyramid / hit-colour surfaces and history halos over RCCL every frame.
+
+Prints ONE JSON line on rank 0.  `value` = full-resolution pixels of the whole frame processed
+per second (all ranks), with every input resident in HBM when the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import vk_renderer_amd  # noqa: E402,F401
+from vk_renderer_amd import abi, host  # noqa: E402
+from vk_renderer_amd.camera import FrameSetup  # noqa: E402
+from vk_renderer_amd.tiling import TiledFrame, grid_for  # noqa: E402
+
+METRIC = "Mpixels/s (GTAO+Hi-Z+SSR+TAA composite) at 4K; achieved HBM GB/s vs peak"
+TILE_W, TILE_H = 3840, 2160
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+# Algorithmic bytes per FULL-RES pixel of each task: surface-compulsory model of SURVEY.md 8(d)
+# (every input surface read once, every output written once, at storage-format size).
+BYTES_PER_PX = {
+    "DownsampleGbuffer": 15.0,
+    "DownsampleDepth": 1.667,  # all (L-2) launches together
+    "SSSR_trace": 10.333,
+    "SSSR_filter": 16.0,
+    "SSSR_blur": 14.0,
+    "GTAO_main": 13.0,
+    "GTAO_filter": 3.5,
+    "GTAO_accumulate": 5.5,
+    "TAA": 32.0,
+}
+COMPOSITE_BYTES_PER_PX = 111.0
+
+
+def measured_read_bandwidth(device):
+    """float4 streaming-read microbenchmark (vkr_stream_read): GB/s actually reachable on this device."""
+    lib = abi.product()
+    n = 2 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device)
+    src.random_(0, 255)
+    sink = torch.zeros(4096, dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream(device)
+    best = 0.0
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        abi.check(lib.vkr_stream_read(src.data_ptr(), n, sink.data_ptr(), 4096, stream.cuda_stream), lib)
+        e1.record(stream)
+        e1.synchronize()
+        best = max(best, n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src
+    return best
+
+
+def cpu_baseline(frame, setup, threads=None):
+    """The oracle (CPU restatement of the reference shaders, "port") timed on this host on ONE full
+    frame of the same 3840x2160 workload, from the same G-buffer bytes."""
+    from vk_renderer_amd.chain import PostFxChain
+
+    ref = PostFxChain(setup.width, setup.height, backend="oracle", setup=setup)
+    cores = ref.lib.vkr_ref_threads()
+    for name in ("depth", "prev_depth", "normal", "albedo", "material", "velocity", "pdf", "taa_hist", "acc_hist", "blurred_hist"):
+        getattr(ref, name).upload(frame.download(name).host)
+    t0 = time.perf_counter()
+    ref.frame()
+    dt = time.perf_counter() - t0
+    return {
+        "value": setup.width * setup.height / dt / 1e6,
+        "unit": "Mpixels/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"1 frame of the same {setup.width}x{setup.height} chain (CPU restatement of reference shaders, OpenMP, {dt:.1f} s)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--tile", type=str, default=f"{TILE_W}x{TILE_H}", help="per-GPU tile, WxH")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    tw, th = (int(v) for v in args.tile.lower().split("x"))
+    cols, rows = grid_for(world)
+    W, H = tw * cols, th * rows
+    setup = FrameSetup(W, H)
+    tiled = TiledFrame(setup, rank, world, cols, rows, device)
+    frame = tiled.frame
+
+    tiled.prepare()  # LUT, G-buffer (tile + halo), prev depth, histories
+    for _ in range(args.warmup):
+        tiled.step()
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    frame.enable_task_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tiled.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    task_times = frame.collect_task_times()
+    frame.enable_task_timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        px = W * H
+        tile_px = tiled.window[2] * tiled.window[3]  # pixels this rank's kernels actually process (tile + halo)
+        per_pass_ms = {k: v[0] / args.steps for k, v in task_times.items()}
+        dominant = max(per_pass_ms, key=per_pass_ms.get)
+        launches_per_step = task_times[dominant][1] / args.steps
+        avg_launch_ms = task_times[dominant][0] / task_times[dominant][1]
+        algo_bytes_launch = BYTES_PER_PX[dominant] * tile_px / launches_per_step
+        achieved = algo_bytes_launch / (avg_launch_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(dominant)
+        out = {
+            "metric": METRIC,
+            "value": px * args.steps / elapsed / 1e6,
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{W}x{H} synthetic G-buffer: Hi-Z downsample + SSR (trace, filter, blur) + GTAO (main, filter, accumulate) + TAA",
+                "frame": [W, H],
+                "tile_per_gpu": [tw, th],
+                "grid": [cols, rows],
+                "halo_px": tiled.halo,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dominant,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "avg_launch_ms": avg_launch_ms,
+                "algorithmic_bytes_per_launch": algo_bytes_launch,
+            },
+            "composite_gbps": COMPOSITE_BYTES_PER_PX * px * args.steps / elapsed / 1e9,
+            "per_pass_ms": per_pass_ms,
+            "per_pass_gbps": {k: BYTES_PER_PX[k] * tile_px / (v * 1e-3) / 1e9 for k, v in per_pass_ms.items() if k in BYTES_PER_PX and v > 0},
+            "exchange_ms": tiled.exchange_ms(args.steps),
+            "measured_read_gbps": measured_read_bandwidth(device),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frame, setup)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

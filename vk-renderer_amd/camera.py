@@ -64,14 +64,18 @@ class FrameSetup:
                  prev_delta=(0.02, 0.0, 0.01), prev_yaw_delta=0.2):
         self.width, self.height = width, height
         self.aspect = float(width) / float(height)
-        self.proj = perspective_rh_zo(FOVY, self.aspect, ZNEAR, ZFAR)
-        self.view = camera_view(eye, yaw)
+        # glm computes in float32; here every *input* matrix is rounded to float32 first and every
+        # derived matrix is evaluated in float64 from those and rounded once (host/glm_compat.hpp does
+        # the same), so the Python and the C++ host layers hand bit-identical uniforms to the kernels.
+        f32 = lambda m: np.asarray(m, dtype=np.float32).astype(np.float64)
+        self.proj = f32(perspective_rh_zo(FOVY, self.aspect, ZNEAR, ZFAR))
+        self.view = f32(camera_view(eye, yaw))
         peye = tuple(e + d for e, d in zip(eye, prev_delta))
-        self.prev_view = camera_view(peye, yaw + prev_yaw_delta)
-        self.mvp = self.proj @ self.view
-        self.prev_mvp = self.proj @ self.prev_view
-        self.inv_view = np.linalg.inv(self.view)
-        self.prev_inv_view = np.linalg.inv(self.prev_view)
+        self.prev_view = f32(camera_view(peye, yaw + prev_yaw_delta))
+        self.mvp = f32(self.proj @ self.view)
+        self.prev_mvp = f32(self.proj @ self.prev_view)
+        self.inv_view = f32(np.linalg.inv(self.view))
+        self.prev_inv_view = f32(np.linalg.inv(self.prev_view))
         self.normal_mat = self.inv_view.T  # transpose(inverse(view)), main.cpp:368
         self.prev_normal_mat = self.prev_inv_view.T
         self.frame_random = frame_random

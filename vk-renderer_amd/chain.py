@@ -19,7 +19,7 @@ PDF_LUT_SIZE = 1024
 
 
 class PostFxChain:
-    def __init__(self, width, height, backend="product", device=None, setup=None, window=None):
+    def __init__(self, width, height, backend="product", device=None, setup=None, window=None, force_tiled=None):
         """window: None (single GPU) or (ox, oy, w, h) full-res window of the frame held by this instance."""
         self.W, self.H = width, height
         self.backend = backend
@@ -50,11 +50,11 @@ class PostFxChain:
         def img(fmt, w, h, mips=1, f=full, o=org, fill=0):
             return ImageBuf(fmt, w, h, mips, device=device, full=f, origin=o, fill=fill)
 
-        # Gbuffer (scene_renderer.cpp:8-44).  Tiled instances keep only mips 0..1 of the window;
-        # the Hi-Z pyramid SSR marches (image mips 1..L-1 of the whole frame) is `pyramid`.
-        tiled = (ww, wh) != (width, height)
+        # Gbuffer (scene_renderer.cpp:8-44).  Tiled: SSR marches `frame_hiz` (whole-frame image mips 1..L-1)
+        # instead of the window-local chain, whose mips >= 2 are then unused.
+        tiled = (ww, wh) != (width, height) if force_tiled is None else bool(force_tiled)
         self.tiled = tiled
-        dm = 2 if tiled else L
+        dm = depth_mip_count(ww, wh)  # Gbuffer(graph, w, h) sizes the chain from the extent it is given
         self.depth = img(abi.FMT_D24_UNORM_S8, ww, wh, dm)
         self.prev_depth = img(abi.FMT_D24_UNORM_S8, ww, wh, dm)
         self.normal = img(abi.FMT_RG16_UNORM, ww, wh)
@@ -79,6 +79,11 @@ class PostFxChain:
         self.taa_hist = img(abi.FMT_RGBA16_SFLOAT, ww, wh)
         self.taa_target = img(abi.FMT_RGBA16_SFLOAT, ww, wh)
         self.frame_index = 0
+        if tiled:
+            # whole-frame copies for reads with unbounded reach, filled by tiling.TiledFrame
+            self.frame_hiz = ImageBuf(abi.FMT_D24_UNORM_S8, width // 2, height // 2, L - 1, device=device)
+            self.frame_normals = ImageBuf(abi.FMT_RG16_UNORM, width // 2, height // 2, device=device)
+            self.frame_albedo = ImageBuf(abi.FMT_RGBA8_SRGB, width, height, device=device)
 
     # ---- plumbing -------------------------------------------------------------------
     @staticmethod
@@ -169,14 +174,20 @@ class PostFxChain:
                   C.byref(self.dn.desc()), C.byref(self.dv.desc()))
         self.call("depth_mips", C.byref(self.depth.desc()), 1)
 
+    def hiz_tail(self, gathered_mips):
+        """tiled: view mips 0..gathered-1 of frame_hiz arrived by all-gather; rebuild the rest locally"""
+        self.call("depth_mips", C.byref(self.frame_hiz.desc()), gathered_mips - 1)
+
     def preintegrate_pdf(self):
         self.call("pdf_preintegrate", C.byref(self.pdf.desc()))
 
     def ssr_trace(self, frame_random=None, max_roughness=1.0):
         tp = self.setup.trace_params(frame_random)
         push = abi.TracePush(max_roughness)
-        # advanced_ssr.cpp:186: depth view = mips 1..L-1
-        self.call("sssr_trace", C.byref(self.depth.desc(1, self.depth.mips - 1)), C.byref(self.dn.desc()),
+        # advanced_ssr.cpp:186: depth view = mips 1..L-1 (tiled: the gathered whole-frame pyramid)
+        hiz = self.frame_hiz.desc() if self.tiled else self.depth.desc(1, self.depth.mips - 1)
+        dn = self.frame_normals.desc() if self.tiled else self.dn.desc()
+        self.call("sssr_trace", C.byref(hiz), C.byref(dn),
                   C.byref(self.material.desc()), C.byref(tp), self._halton_ptr(), C.byref(self.rays.desc()),
                   C.byref(self.raw.desc()), C.byref(self.pdf.desc()), C.byref(push))
 
@@ -184,7 +195,8 @@ class PostFxChain:
         tp = self.setup.trace_params()
         push = abi.FilterPush(render_flags)
         nm = min(10, self.depth.mips)  # advanced_ssr.cpp:342: mips 0..9
-        self.call("sssr_filter", C.byref(self.rays.desc()), C.byref(self.depth.desc(0, nm)), C.byref(self.albedo.desc()),
+        albedo = self.frame_albedo if self.tiled else self.albedo
+        self.call("sssr_filter", C.byref(self.rays.desc()), C.byref(self.depth.desc(0, nm)), C.byref(albedo.desc()),
                   C.byref(self.normal.desc()), C.byref(self.material.desc()), C.byref(self.reflections.desc()),
                   C.byref(tp), C.byref(push))
 

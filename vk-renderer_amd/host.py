@@ -1,0 +1,181 @@
+"""ctypes binding of the C++ host mirror (host/libvkr_host.so): the reference's pass structs
+(Gbuffer, DownsamplePass, AdvancedSSR, GTAO, TAA) on the rendergraph mirror, driven one stage at
+a time.  Device memory for every graph image comes from torch through the allocator hook, so
+the launcher can hand the same memory to torch.distributed (RCCL) without copies."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+STAGE_LUT, STAGE_GBUFFER, STAGE_PREV_DEPTH, STAGE_DOWNSAMPLE = 1, 2, 4, 8
+STAGE_HIZ_TAIL, STAGE_SSR, STAGE_GTAO, STAGE_TAA = 16, 32, 64, 128
+STAGE_CHAIN = STAGE_DOWNSAMPLE | STAGE_SSR | STAGE_GTAO | STAGE_TAA
+
+
+class HostConfig(C.Structure):
+    _fields_ = [("full_width", C.c_uint32), ("full_height", C.c_uint32), ("origin_x", C.c_int32), ("origin_y", C.c_int32),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("tiled", C.c_uint32), ("stream", C.c_void_p)]
+
+
+class HostCamera(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("prev_view", C.c_float * 16), ("projection", C.c_float * 16),
+                ("fovy", C.c_float), ("aspect", C.c_float), ("znear", C.c_float), ("zfar", C.c_float)]
+
+
+_ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_uint64, C.c_void_p)
+_FREE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = abi._load(abi.HOST_LIB, "host library libvkr_host.so")
+        l.vkrh_create.argtypes = [C.POINTER(HostConfig)]
+        l.vkrh_create.restype = C.c_void_p
+        l.vkrh_destroy.argtypes = [C.c_void_p]
+        l.vkrh_last_error.restype = C.c_char_p
+        l.vkrh_set_camera.argtypes = [C.c_void_p, C.POINTER(HostCamera)]
+        l.vkrh_pin_randoms.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32]
+        l.vkrh_set_gtao_mode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        l.vkrh_run.argtypes = [C.c_void_p, C.c_uint32]
+        l.vkrh_end_frame.argtypes = [C.c_void_p, C.c_uint32]
+        l.vkrh_image.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(abi.VkrImg)]
+        l.vkrh_last_tasks.argtypes = [C.c_void_p]
+        l.vkrh_last_tasks.restype = C.c_char_p
+        l.vkrh_enable_task_timing.argtypes = [C.c_void_p, C.c_uint32]
+        l.vkrh_collect_task_times.argtypes = [C.c_void_p]
+        l.vkrh_collect_task_times.restype = C.c_char_p
+        l.vkrh_set_allocator.argtypes = [_ALLOC, _FREE, C.c_void_p]
+        _lib = l
+    return _lib
+
+
+class TorchAllocator:
+    """Backs graph images with torch uint8 tensors (keeps them alive until the graph frees them)."""
+
+    def __init__(self, device):
+        import torch
+
+        self.torch = torch
+        self.device = device
+        self.live = {}
+        self._alloc = _ALLOC(self.alloc)
+        self._free = _FREE(self.free)
+
+    def alloc(self, nbytes, _user):
+        t = self.torch.zeros((int(nbytes),), dtype=self.torch.uint8, device=self.device)
+        self.live[t.data_ptr()] = t
+        return t.data_ptr()
+
+    def free(self, ptr, _user):
+        self.live.pop(ptr, None)
+
+    def install(self):
+        lib().vkrh_set_allocator(self._alloc, self._free, None)
+
+    def tensor_at(self, ptr):
+        """(tensor, byte offset) of the allocation containing `ptr`."""
+        for base, t in self.live.items():
+            if base <= ptr < base + t.numel():
+                return t, ptr - base
+        raise KeyError(hex(ptr))
+
+
+def _mat16(m):
+    a = (C.c_float * 16)()
+    flat = np.asarray(m, dtype=np.float32).T.reshape(-1)
+    for i in range(16):
+        a[i] = float(flat[i])
+    return a
+
+
+class HostFrame:
+    def __init__(self, setup, device="cuda", window=None, tiled=False, stream=None):
+        import torch
+
+        self.setup = setup
+        W, H = setup.width, setup.height
+        ox, oy, ww, wh = window or (0, 0, W, H)
+        self.allocator = TorchAllocator(device)
+        self.allocator.install()
+        if stream is None:
+            stream = torch.cuda.current_stream(device).cuda_stream
+        cfg = HostConfig(W, H, ox, oy, ww, wh, 1 if tiled else 0, C.c_void_p(stream))
+        self.h = lib().vkrh_create(C.byref(cfg))
+        if not self.h:
+            raise RuntimeError("vkrh_create failed: " + lib().vkrh_last_error().decode())
+        cam = HostCamera()
+        cam.view, cam.prev_view, cam.projection = _mat16(setup.view), _mat16(setup.prev_view), _mat16(setup.proj)
+        cam.fovy, cam.aspect, cam.znear, cam.zfar = [float(v) for v in setup.fazz]
+        self._check(lib().vkrh_set_camera(self.h, C.byref(cam)))
+        self.pin_randoms()
+        self._check(lib().vkrh_set_gtao_mode(self.h, setup.use_mis, 0))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("host frame error: " + lib().vkrh_last_error().decode())
+
+    def pin_randoms(self, angle_jitter=0.0, gtao_frame_count=0, ssr_counter=0):
+        """angle_offset = table[frame_count % 12]/360 + jitter (gtao.cpp:109-111); SURVEY 8(d) pins 60/360 + 0."""
+        self._check(lib().vkrh_pin_randoms(self.h, angle_jitter, gtao_frame_count, ssr_counter))
+
+    def run(self, mask):
+        self._check(lib().vkrh_run(self.h, mask))
+
+    def end_frame(self, swap_depth=False):
+        self._check(lib().vkrh_end_frame(self.h, 1 if swap_depth else 0))
+
+    def image(self, name, base_mip=0, mip_count=0):
+        d = abi.VkrImg()
+        self._check(lib().vkrh_image(self.h, name.encode(), base_mip, mip_count, C.byref(d)))
+        return d
+
+    def enable_task_timing(self, on=True):
+        self._check(lib().vkrh_enable_task_timing(self.h, 1 if on else 0))
+
+    def collect_task_times(self):
+        """{task name: (total_ms, launches)} measured with HIP events on the frame's stream since the last call."""
+        txt = lib().vkrh_collect_task_times(self.h)
+        if txt is None:
+            raise RuntimeError("host frame error: " + lib().vkrh_last_error().decode())
+        out = {}
+        for line in txt.decode().splitlines():
+            name, ms, n = line.rsplit(" ", 2)
+            out[name] = (float(ms), int(n))
+        return out
+
+    def last_tasks(self):
+        return lib().vkrh_last_tasks(self.h).decode().split()
+
+    def download(self, name):
+        """Copies the named image into a host ImageBuf with the same layout rules (tests)."""
+        from .images import ImageBuf
+
+        d = self.image(name)
+        buf = ImageBuf(d.format, d.width, d.height, d.mip_count, full=(d.full_width, d.full_height), origin=(d.origin_x, d.origin_y))
+        for i in range(d.mip_count):
+            assert buf.pitch[i] == d.pitch_bytes[i] and buf.offset[i] == d.mip_offset[i], "layout rules diverged"
+        t, off = self.allocator.tensor_at(d.base)
+        buf.upload(t[off: off + buf.nbytes].cpu().numpy())
+        return buf
+
+    def upload(self, name, host_bytes):
+        import torch
+
+        d = self.image(name)
+        t, off = self.allocator.tensor_at(d.base)
+        src = torch.from_numpy(np.ascontiguousarray(host_bytes, dtype=np.uint8).reshape(-1))
+        t[off: off + src.numel()].copy_(src)
+
+    def close(self):
+        if self.h:
+            lib().vkrh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

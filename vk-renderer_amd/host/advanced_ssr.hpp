@@ -1,0 +1,85 @@
+// advanced_ssr.hpp — stochastic Hi-Z screen-space reflections, public interface of
+// src/advanced_ssr.hpp:7-113.  Implemented: run() = trace -> filter -> blur (advanced_ssr.cpp:551-553),
+// preintegrate_pdf, remap_images, the getters.  The reference's disabled experiments (tile
+// classification, indirect trace, tile regression; advanced_ssr.cpp:547-550) and preintegrate_brdf
+// (consumed only by deferred shading) are outside the hot path.
+#ifndef ADVANCED_SSR_HPP_INCLUDED
+#define ADVANCED_SSR_HPP_INCLUDED
+
+#include <vector>
+
+#include "rendergraph/rendergraph.hpp"
+#include "scene_renderer.hpp"
+
+struct AdvancedSSRParams {
+  glm::mat4 normal_mat;
+  float fovy;
+  float aspect;
+  float znear;
+  float zfar;
+};
+
+std::vector<glm::vec4> halton23_seq(uint32_t count);
+
+struct AdvancedSSR {
+  AdvancedSSR(rendergraph::RenderGraph &graph, uint32_t w, uint32_t h);
+  void run(
+    rendergraph::RenderGraph &graph,
+    const AdvancedSSRParams &params,
+    const DrawTAAParams &taa_params,
+    const Gbuffer &gbuff,
+    rendergraph::ImageResourceId ssr_occlusion);
+
+  void preintegrate_pdf(rendergraph::RenderGraph &graph);
+  void preintegrate_brdf(rendergraph::RenderGraph &graph);
+  void remap_images(rendergraph::RenderGraph &graph) { graph.remap(blurred_reflection, blurred_reflection_history); }
+
+  rendergraph::ImageResourceId get_ouput() const { return reflections; }
+  rendergraph::ImageResourceId get_rays() const { return rays; }
+  rendergraph::ImageResourceId get_blurred() const { return blurred_reflection; }
+  rendergraph::ImageResourceId get_blurred_history() const { return blurred_reflection_history; }
+  rendergraph::ImageResourceId get_occlusion() const { return rays_occlusion; }
+  rendergraph::ImageResourceId get_preintegrated_pdf() const { return preintegrated_pdf; }
+  rendergraph::ImageResourceId get_preintegrated_brdf() const { return preintegrated_brdf; }
+
+  // headless equivalents of the ImGui controls (advanced_ssr.cpp:556-567)
+  struct Settings {
+    float max_rougness = 1.f;
+    float glossy_roughness_value = 0.5f;
+    bool normalize_reflections = true;
+    bool accumulate_reflections = true;
+    bool bilateral_filter = true;
+    bool update_random = true;
+    bool use_blur = true;
+    int max_accumulated_rays = 16;
+  };
+  Settings &get_settings() { return settings; }
+  void set_counter(uint32_t c) { counter = c; }
+
+private:
+  gpu::BufferPtr halton_buffer;
+
+  gpu::ComputePipeline trace_pass;
+  gpu::ComputePipeline filter_pass;
+  gpu::ComputePipeline blur_pass;
+  gpu::ComputePipeline preintegrate_pass;
+
+  VkSampler sampler;
+
+  rendergraph::ImageResourceId rays;
+  rendergraph::ImageResourceId reflections;
+  rendergraph::ImageResourceId blurred_reflection;
+  rendergraph::ImageResourceId blurred_reflection_history;
+  rendergraph::ImageResourceId rays_occlusion;
+  rendergraph::ImageResourceId preintegrated_pdf;
+  rendergraph::ImageResourceId preintegrated_brdf;
+
+  uint32_t counter {0u};
+  Settings settings;
+
+  void run_trace_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion);
+  void run_filter_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff);
+  void run_blur_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const DrawTAAParams &taa_params, const Gbuffer &gbuff);
+};
+
+#endif

@@ -1,0 +1,196 @@
+// frame.cpp — see frame.hpp.  C++ exceptions thrown by the pass / graph code (the reference's
+// only error channel, gpu/common.cpp:6-12) are turned into status codes at this C boundary.
+#include "frame.hpp"
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+#include "advanced_ssr.hpp"
+#include "downsample_pass.hpp"
+#include "gtao.hpp"
+#include "scene_renderer.hpp"
+#include "synthetic_gbuffer.hpp"
+#include "taa.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+struct GraphInit {  // orders construction: the frame window must be set before any pass creates images
+  GraphInit(rendergraph::RenderGraph& g, const vkrh_config& c) {
+    g.set_frame_window(c.full_width, c.full_height, c.origin_x, c.origin_y, c.width, c.height);
+  }
+};
+
+struct PostFxFrame {
+  vkrh_config cfg;
+  rendergraph::RenderGraph graph;
+  GraphInit init;
+  Gbuffer gbuffer;
+  DownsamplePass downsample_pass;
+  GTAO gtao;
+  AdvancedSSR ssr;
+  TAA taa_pass;
+  SyntheticGbuffer synth;
+
+  DrawTAAParams draw_params{};
+  glm::mat4 projection, view, prev_view;
+  bool has_camera = false;
+  std::string task_names;
+
+  explicit PostFxFrame(const vkrh_config& c)
+      : cfg{c}, graph{c.stream}, init{graph, c},
+        gbuffer{graph, c.width, c.height},
+        gtao{graph, c.width, c.height, false, true},  // main.cpp:265: (graph, W, H, USE_RAY_QUERY = 0, half_res = 1)
+        ssr{graph, c.width, c.height},
+        taa_pass{graph, c.width, c.height} {
+    if (c.tiled) gbuffer.enable_tiling(graph, c.full_width, c.full_height);
+  }
+
+  void set_camera(const vkrh_camera& cam) {
+    std::memcpy(&view, cam.view, 64);
+    std::memcpy(&prev_view, cam.prev_view, 64);
+    std::memcpy(&projection, cam.projection, 64);
+    // main.cpp:334-339
+    draw_params.prev_mvp = projection * prev_view;
+    draw_params.mvp = projection * view;
+    draw_params.prev_camera = prev_view;
+    draw_params.camera = view;
+    draw_params.fovy_aspect_znear_zfar = glm::vec4{cam.fovy, cam.aspect, cam.znear, cam.zfar};
+    draw_params.jitter = glm::vec4{0.f, 0.f, 0.f, 0.f};
+    has_camera = true;
+  }
+
+  void run(uint32_t mask) {
+    if (!has_camera && (mask & ~uint32_t(VKRH_STAGE_LUT))) throw std::runtime_error{"vkrh_run: camera not set"};
+    const glm::vec4 fazz = draw_params.fovy_aspect_znear_zfar;
+    if (mask & VKRH_STAGE_LUT) ssr.preintegrate_pdf(graph);
+    if (mask & VKRH_STAGE_PREV_DEPTH) {
+      // what the previous frame left behind: its depth in `prev_depth`, including the Hi-Z mips
+      synth.draw_depth(graph, gbuffer.prev_depth, prev_view, draw_params.prev_mvp, fazz);
+      downsample_pass.run(graph, gbuffer.normal, gbuffer.velocity_vectors, gbuffer.prev_depth, gbuffer.downsampled_normals,
+                          gbuffer.downsampled_velocity_vectors);
+    }
+    if (mask & VKRH_STAGE_GBUFFER) synth.draw_taa(graph, gbuffer, draw_params);
+    if (mask & VKRH_STAGE_DOWNSAMPLE)  // main.cpp:347
+      downsample_pass.run(graph, gbuffer.normal, gbuffer.velocity_vectors, gbuffer.depth, gbuffer.downsampled_normals,
+                          gbuffer.downsampled_velocity_vectors);
+    if ((mask & VKRH_STAGE_HIZ_TAIL) && gbuffer.tiled) {
+      // the launcher gathered whole-frame mips 0..k of frame_hiz; finish the chain locally
+      downsample_pass.run_downsample_depth(graph, gbuffer.frame_hiz, hiz_gathered_mips - 1);
+    }
+    // main.cpp:368-373
+    const glm::mat4 normal_mat = glm::transpose(glm::inverse(view));
+    const GTAOParams gtao_params{normal_mat, fazz.x, fazz.y, fazz.z, fazz.w};
+    const AdvancedSSRParams assr_params{normal_mat, fazz.x, fazz.y, fazz.z, fazz.w};
+    if (mask & VKRH_STAGE_SSR) ssr.run(graph, assr_params, draw_params, gbuffer, gtao.raw);  // main.cpp:375
+    if (mask & VKRH_STAGE_GTAO) {                                                           // main.cpp:384-388
+      gtao.add_main_pass(graph, gtao_params, gbuffer.depth, gbuffer.normal, gbuffer.material, ssr.get_preintegrated_pdf());
+      gtao.add_filter_pass(graph, gtao_params, gbuffer.depth);
+      gtao.add_accumulate_pass(graph, draw_params, gbuffer);
+    }
+    // main.cpp:390-391: the colour input of TAA is the deferred-shading output; until that pass
+    // exists on this path TAA resolves the albedo attachment.
+    if (mask & VKRH_STAGE_TAA) taa_pass.run(graph, gbuffer, gbuffer.albedo, draw_params);
+    graph.submit();
+    task_names.clear();
+    for (const auto& n : graph.last_submitted_tasks()) { task_names += n; task_names += '\n'; }
+  }
+
+  void end_frame(bool swap_depth) {  // main.cpp:416-420
+    if (swap_depth) graph.remap(gbuffer.depth, gbuffer.prev_depth);
+    taa_pass.remap_targets(graph);
+    ssr.remap_images(graph);
+    gtao.remap(graph);
+  }
+
+  uint32_t hiz_gathered_mips = 4;  // tiled: view mips 0..3 of frame_hiz (image mips 1..4) arrive by all-gather
+
+  rendergraph::ImageResourceId lookup(const std::string& name) {
+    static const std::map<std::string, int> ids = {
+        {"depth", 0}, {"prev_depth", 1}, {"normal", 2}, {"albedo", 3}, {"material", 4}, {"velocity", 5}, {"dn", 6}, {"dv", 7},
+        {"raw", 8}, {"filtered", 9}, {"acc_ao", 10}, {"acc_hist", 11}, {"rays", 12}, {"reflections", 13}, {"blurred", 14},
+        {"blurred_hist", 15}, {"pdf", 16}, {"taa_hist", 17}, {"taa_target", 18}, {"frame_hiz", 19}, {"frame_normals", 20},
+        {"frame_albedo", 21}};
+    auto it = ids.find(name);
+    if (it == ids.end()) throw std::runtime_error{"vkrh_image: unknown image '" + name + "'"};
+    switch (it->second) {
+      case 0: return gbuffer.depth; case 1: return gbuffer.prev_depth; case 2: return gbuffer.normal; case 3: return gbuffer.albedo;
+      case 4: return gbuffer.material; case 5: return gbuffer.velocity_vectors; case 6: return gbuffer.downsampled_normals;
+      case 7: return gbuffer.downsampled_velocity_vectors; case 8: return gtao.raw; case 9: return gtao.filtered;
+      case 10: return gtao.accumulated_ao; case 11: return gtao.accumulated_history; case 12: return ssr.get_rays();
+      case 13: return ssr.get_ouput(); case 14: return ssr.get_blurred(); case 15: return ssr.get_blurred_history();
+      case 16: return ssr.get_preintegrated_pdf(); case 17: return taa_pass.get_history(); case 18: return taa_pass.get_output();
+      case 19: return gbuffer.frame_hiz; case 20: return gbuffer.frame_normals; default: return gbuffer.frame_albedo;
+    }
+  }
+};
+
+template <typename F> int guarded(F&& f) {
+  try { f(); return 0; }
+  catch (const std::exception& e) { g_error = e.what(); return 1; }
+  catch (...) { g_error = "unknown exception"; return 2; }
+}
+
+}  // namespace
+
+extern "C" {
+
+void vkrh_set_allocator(vkrh_alloc_fn alloc, vkrh_free_fn free_fn, void* user) {
+  gpu::set_device_allocator((gpu::AllocFn)alloc, (gpu::FreeFn)free_fn, user);
+}
+
+void* vkrh_create(const vkrh_config* cfg) {
+  PostFxFrame* f = nullptr;
+  int rc = guarded([&] {
+    if (!cfg) throw std::runtime_error{"vkrh_create: NULL config"};
+    if ((cfg->width | cfg->height | (uint32_t)cfg->origin_x | (uint32_t)cfg->origin_y) & 1u)
+      throw std::runtime_error{"vkrh_create: window origin and extent must be even"};
+    f = new PostFxFrame(*cfg);
+  });
+  return rc == 0 ? f : nullptr;
+}
+void vkrh_destroy(void* frame) { delete (PostFxFrame*)frame; }
+const char* vkrh_last_error(void) { return g_error.c_str(); }
+
+int vkrh_set_camera(void* frame, const vkrh_camera* cam) {
+  return guarded([&] { if (!frame || !cam) throw std::runtime_error{"NULL argument"}; ((PostFxFrame*)frame)->set_camera(*cam); });
+}
+int vkrh_pin_randoms(void* frame, float jitter, uint32_t gtao_frame_count, uint32_t ssr_counter) {
+  return guarded([&] {
+    auto* f = (PostFxFrame*)frame;
+    f->gtao.pin_angle_jitter(jitter);
+    f->gtao.set_frame_count(gtao_frame_count);
+    f->ssr.set_counter(ssr_counter);
+  });
+}
+int vkrh_set_gtao_mode(void* frame, uint32_t use_mis, uint32_t two_directions) {
+  return guarded([&] { auto* f = (PostFxFrame*)frame; f->gtao.set_mis(use_mis != 0); f->gtao.set_two_directions(two_directions != 0); });
+}
+int vkrh_run(void* frame, uint32_t stage_mask) { return guarded([&] { ((PostFxFrame*)frame)->run(stage_mask); }); }
+int vkrh_end_frame(void* frame, uint32_t swap_depth) { return guarded([&] { ((PostFxFrame*)frame)->end_frame(swap_depth != 0); }); }
+int vkrh_image(void* frame, const char* name, uint32_t base_mip, uint32_t mip_count, vkr_img* out) {
+  return guarded([&] {
+    auto* f = (PostFxFrame*)frame;
+    if (!f || !name || !out) throw std::runtime_error{"NULL argument"};
+    auto& img = f->graph.get_image(f->lookup(name));
+    if (mip_count == 0) mip_count = img->get_mip_levels() - base_mip;
+    *out = img->describe(base_mip, mip_count);
+  });
+}
+int vkrh_enable_task_timing(void* frame, uint32_t on) { return guarded([&] { ((PostFxFrame*)frame)->graph.enable_task_timing(on != 0); }); }
+const char* vkrh_collect_task_times(void* frame) {
+  auto* f = (PostFxFrame*)frame;
+  f->task_names.clear();
+  int rc = guarded([&] {
+    for (auto& t : f->graph.collect_task_times())
+      f->task_names += t.name + " " + std::to_string(t.total_ms) + " " + std::to_string(t.launches) + "\n";
+  });
+  return rc == 0 ? f->task_names.c_str() : nullptr;
+}
+const char* vkrh_last_tasks(void* frame) { return ((PostFxFrame*)frame)->task_names.c_str(); }
+
+}  // extern "C"

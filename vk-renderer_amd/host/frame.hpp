@@ -1,0 +1,70 @@
+// frame.hpp — headless frame driver: the per-frame pass order of the reference's main loop
+// (src/main.cpp:261-274 construction, :345-391 passes, :416-420 history remaps) around the
+// rendergraph mirror, plus a flat C interface (vkrh_*) so Python launchers (bench.py, tests,
+// the multi-GPU driver) can run it one stage at a time and interleave RCCL exchanges.
+#ifndef VKR_HOST_FRAME_HPP_INCLUDED
+#define VKR_HOST_FRAME_HPP_INCLUDED
+#include <stdint.h>
+#include "../../include/vkr_postfx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vkrh_config {
+  uint32_t full_width, full_height;  /* whole frame                                        */
+  int32_t  origin_x, origin_y;       /* window of the frame held by this process           */
+  uint32_t width, height;            /* window extent (== full on one GPU)                 */
+  uint32_t tiled;                    /* 1: SSR reads the gathered whole-frame images       */
+  void*    stream;                   /* HIP stream all passes are recorded on              */
+} vkrh_config;
+
+/* views / projection as 16 floats, column-major (glm layout) */
+typedef struct vkrh_camera {
+  float view[16], prev_view[16], projection[16];
+  float fovy, aspect, znear, zfar;
+} vkrh_camera;
+
+enum {
+  VKRH_STAGE_LUT        = 1u << 0,  /* ssr.preintegrate_pdf (main.cpp:269)                              */
+  VKRH_STAGE_GBUFFER    = 1u << 1,  /* synthetic G-buffer for the current camera (replaces main.cpp:345) */
+  VKRH_STAGE_PREV_DEPTH = 1u << 2,  /* prev_depth mip 0 from the previous camera + its Hi-Z mips        */
+  VKRH_STAGE_DOWNSAMPLE = 1u << 3,  /* downsample_pass.run (main.cpp:347)                               */
+  VKRH_STAGE_HIZ_TAIL   = 1u << 4,  /* tiled only: coarse mips of the gathered whole-frame pyramid       */
+  VKRH_STAGE_SSR        = 1u << 5,  /* ssr.run: trace, filter, blur (main.cpp:375)                       */
+  VKRH_STAGE_GTAO       = 1u << 6,  /* gtao main, filter, accumulate (main.cpp:384-388)                  */
+  VKRH_STAGE_TAA        = 1u << 7,  /* taa_pass.run (main.cpp:391)                                       */
+  VKRH_STAGE_CHAIN      = (1u << 3) | (1u << 5) | (1u << 6) | (1u << 7)
+};
+
+typedef void* (*vkrh_alloc_fn)(uint64_t bytes, void* user);
+typedef void (*vkrh_free_fn)(void* ptr, void* user);
+
+/* replace the device allocator used for every graph image (call before vkrh_create) */
+void vkrh_set_allocator(vkrh_alloc_fn alloc, vkrh_free_fn free_fn, void* user);
+
+void* vkrh_create(const vkrh_config* cfg);
+void  vkrh_destroy(void* frame);
+const char* vkrh_last_error(void);
+
+int vkrh_set_camera(void* frame, const vkrh_camera* cam);
+/* pin the host-side randoms of the reference (gtao.cpp:109-111 rand(), advanced_ssr.cpp:168-171 counter) */
+int vkrh_pin_randoms(void* frame, float gtao_angle_jitter, uint32_t gtao_frame_count, uint32_t ssr_counter);
+int vkrh_set_gtao_mode(void* frame, uint32_t use_mis, uint32_t two_directions);
+/* record the stages in `mask` (canonical order) and submit them on the stream */
+int vkrh_run(void* frame, uint32_t stage_mask);
+/* end-of-frame remaps (main.cpp:416-420); swap_depth = 0 keeps a static G-buffer */
+int vkrh_end_frame(void* frame, uint32_t swap_depth);
+/* current descriptor of a named image ("depth", "taa_target", ...) */
+int vkrh_image(void* frame, const char* name, uint32_t base_mip, uint32_t mip_count, vkr_img* out);
+/* per-task device timing with HIP events on the frame's stream */
+int vkrh_enable_task_timing(void* frame, uint32_t on);
+/* synchronises and returns "name total_ms launches\n" lines accumulated since the last call */
+const char* vkrh_collect_task_times(void* frame);
+/* names of the tasks executed by the last vkrh_run, '\n'-separated */
+const char* vkrh_last_tasks(void* frame);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

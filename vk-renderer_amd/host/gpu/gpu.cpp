@@ -1,0 +1,336 @@
+// gpu/gpu.cpp — implementation of the HIP-backed gpu:: layer and the program table that maps
+// the reference's program names (src/shaders/config.json) onto C-ABI entry points.
+#include "gpu.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <map>
+#include <mutex>
+
+namespace gpu {
+
+// ---- allocation --------------------------------------------------------------------------------
+namespace {
+void* default_alloc(size_t bytes, void*) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) throw std::runtime_error{std::string{"hipMalloc failed: "} + hipGetErrorString(e)};
+  return p;
+}
+void default_free(void* p, void*) { (void)hipFree(p); }
+AllocFn g_alloc = default_alloc;
+FreeFn g_free = default_free;
+void* g_alloc_user = nullptr;
+}  // namespace
+
+void set_device_allocator(AllocFn alloc, FreeFn free_fn, void* user) {
+  g_alloc = alloc ? alloc : default_alloc;
+  g_free = free_fn ? free_fn : default_free;
+  g_alloc_user = user;
+}
+void* device_alloc(size_t bytes) {
+  void* p = g_alloc(bytes, g_alloc_user);
+  if (!p) throw std::runtime_error{"device allocation failed"};
+  return p;
+}
+void device_free(void* ptr) { if (ptr) g_free(ptr, g_alloc_user); }
+
+void check_status(int rc, const char* what) {
+  if (rc != 0) throw std::runtime_error{std::string{what} + ": " + vkr_last_error() + " (code " + std::to_string(rc) + ")"};
+}
+
+// ---- images ----------------------------------------------------------------------------------------
+uint32_t to_vkr_format(VkFormat fmt) {
+  switch (fmt) {
+    case VK_FORMAT_D24_UNORM_S8_UINT: return VKR_FMT_D24_UNORM_S8;
+    case VK_FORMAT_R16G16_UNORM: return VKR_FMT_RG16_UNORM;
+    case VK_FORMAT_R16G16_SFLOAT: return VKR_FMT_RG16_SFLOAT;
+    case VK_FORMAT_R8G8B8A8_SRGB: return VKR_FMT_RGBA8_SRGB;
+    case VK_FORMAT_R8G8B8A8_UNORM: return VKR_FMT_RGBA8_UNORM;
+    case VK_FORMAT_R16G16B16A16_UNORM: return VKR_FMT_RGBA16_UNORM;
+    case VK_FORMAT_R16G16B16A16_SFLOAT: return VKR_FMT_RGBA16_SFLOAT;
+    case VK_FORMAT_R16_SFLOAT: return VKR_FMT_R16_SFLOAT;
+    case VK_FORMAT_R32_SFLOAT: return VKR_FMT_R32_SFLOAT;
+    case VK_FORMAT_R8_UNORM: return VKR_FMT_R8_UNORM;
+    default: throw std::runtime_error{"Unsupported image format on the post-process path"};
+  }
+}
+
+static inline uint32_t mip_dim(uint32_t v, uint32_t i) { uint32_t r = v >> i; return r ? r : 1u; }
+
+Image::Image(const ImageInfo& i, const FrameWindow& w) : info{i}, window{w} {
+  if (info.mip_levels == 0 || info.mip_levels > VKR_MAX_MIPS) throw std::runtime_error{"Image: bad mip count"};
+  if (info.width == 0 || info.height == 0) throw std::runtime_error{"Image: empty extent"};
+  const uint32_t bpp = vkr_format_bytes(to_vkr_format(info.format));
+  uint64_t off = 0;
+  const uint32_t layers = info.array_layers ? info.array_layers : 1;
+  for (uint32_t m = 0; m < info.mip_levels; m++) {
+    pitch[m] = (mip_dim(info.width, m) * bpp + 255u) & ~255u;  // rows 256-B aligned
+    offset[m] = off;
+    off += (uint64_t(pitch[m]) * mip_dim(info.height, m) * layers + 255u) & ~uint64_t(255);
+  }
+  bytes = off;
+  base = device_alloc(bytes);
+  if (window.full_width == 0) { window.full_width = info.width; window.full_height = info.height; }
+}
+Image::~Image() { device_free(base); }
+
+vkr_img Image::describe(uint32_t base_mip, uint32_t count) const {
+  if (base_mip + count > info.mip_levels || count == 0) throw std::runtime_error{"Image view outside the mip chain"};
+  vkr_img d{};
+  d.base = (uint8_t*)base + offset[base_mip];
+  d.format = to_vkr_format(info.format);
+  d.mip_count = count;
+  d.width = mip_dim(info.width, base_mip);
+  d.height = mip_dim(info.height, base_mip);
+  d.full_width = mip_dim(window.full_width, base_mip);
+  d.full_height = mip_dim(window.full_height, base_mip);
+  d.origin_x = window.origin_x >> base_mip;
+  d.origin_y = window.origin_y >> base_mip;
+  for (uint32_t m = 0; m < count; m++) {
+    d.pitch_bytes[m] = pitch[base_mip + m];
+    d.mip_offset[m] = offset[base_mip + m] - offset[base_mip];
+  }
+  return d;
+}
+
+Buffer::Buffer(VmaMemoryUsage memory, uint64_t sz, VkBufferUsageFlags) : size{sz} {
+  dev = device_alloc((sz + 255) & ~uint64_t(255));
+  if (memory != VMA_MEMORY_USAGE_GPU_ONLY) shadow.resize(sz);
+}
+Buffer::~Buffer() { device_free(dev); }
+void* Buffer::device_ptr(void* stream) {
+  if (dirty && !shadow.empty()) {
+    hipError_t e = hipMemcpyAsync(dev, shadow.data(), size, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) throw std::runtime_error{std::string{"buffer upload failed: "} + hipGetErrorString(e)};
+    e = hipStreamSynchronize((hipStream_t)stream);  // the shadow is pageable; happens once per write
+    if (e != hipSuccess) throw std::runtime_error{std::string{"buffer upload failed: "} + hipGetErrorString(e)};
+    dirty = false;
+  }
+  return dev;
+}
+BufferPtr create_buffer(VmaMemoryUsage memory, uint64_t size, VkBufferUsageFlags usage) { return std::make_shared<Buffer>(memory, size, usage); }
+
+// ---- samplers ----------------------------------------------------------------------------------------
+namespace { std::vector<std::unique_ptr<VkSamplerCreateInfo>> g_samplers; std::mutex g_sampler_lock; }
+VkSampler create_sampler(const VkSamplerCreateInfo& info) {
+  std::lock_guard<std::mutex> lock{g_sampler_lock};
+  for (auto& s : g_samplers)
+    if (std::memcmp(s.get(), &info, sizeof(info)) == 0) return (VkSampler)s.get();
+  g_samplers.emplace_back(new VkSamplerCreateInfo(info));
+  return (VkSampler)g_samplers.back().get();
+}
+const VkSamplerCreateInfo& sampler_info(VkSampler s) { return *(const VkSamplerCreateInfo*)s; }
+
+// ---- descriptor writes -----------------------------------------------------------------------------------
+static SetSlot& slot_of(VkDescriptorSet set, uint32_t binding) {
+  if (!set) throw std::runtime_error{"write_set: null descriptor set"};
+  auto* obj = (DescriptorSetObject*)set;
+  if (binding >= obj->slots.size()) throw std::runtime_error{"write_set: binding out of range"};
+  return obj->slots[binding];
+}
+static const ImageViewObject& view_of(VkImageView v) {
+  if (!v) throw std::runtime_error{"write_set: null image view"};
+  return *(const ImageViewObject*)v;
+}
+void write_binding(VkDescriptorSet set, const TextureBinding& b) {
+  auto& s = slot_of(set, b.binding);
+  s = SetSlot{};
+  s.kind = SetSlot::Texture; s.view = view_of(b.view); s.sampler = b.sampler;
+}
+void write_binding(VkDescriptorSet set, const StorageTextureBinding& b) {
+  auto& s = slot_of(set, b.binding);
+  s = SetSlot{};
+  s.kind = SetSlot::StorageTexture; s.view = view_of(b.view);
+}
+void write_binding(VkDescriptorSet set, const UBOBinding& b) {
+  auto& s = slot_of(set, b.binding);
+  s = SetSlot{};
+  s.kind = SetSlot::Ubo; s.host_data = b.host; s.host_size = b.size; s.buffer = b.buffer;
+}
+void write_binding(VkDescriptorSet set, const SSBOBinding& b) {
+  auto& s = slot_of(set, b.binding);
+  s = SetSlot{};
+  s.kind = SetSlot::Ssbo; s.buffer = b.buffer;
+}
+
+// ---- program table ----------------------------------------------------------------------------------------
+namespace {
+std::map<std::string, ProgramFn>& programs() { static std::map<std::string, ProgramFn> p; return p; }
+
+vkr_img tex(const LaunchState& st, uint32_t slot, SetSlot::Kind kind, const char* prog) {
+  const SetSlot& s = st.set ? st.set->slots[slot] : SetSlot{};
+  if (!st.set || s.kind != kind || !s.view.image)
+    throw std::runtime_error{std::string{prog} + ": binding " + std::to_string(slot) + " is not bound as expected"};
+  if (kind == SetSlot::Texture) {
+    const auto& si = sampler_info(s.sampler);
+    if (!s.sampler || si.magFilter != VK_FILTER_LINEAR || si.addressModeU != VK_SAMPLER_ADDRESS_MODE_CLAMP_TO_EDGE)
+      throw std::runtime_error{std::string{prog} + ": only gpu::DEFAULT_SAMPLER is implemented on this path"};
+  }
+  return s.view.image->describe(s.view.range.base_mip, s.view.range.mips_count);
+}
+template <typename T> const T* ubo(const LaunchState& st, uint32_t slot, const char* prog) {
+  const SetSlot& s = st.set ? st.set->slots[slot] : SetSlot{};
+  if (!st.set || s.kind != SetSlot::Ubo || !s.host_data || s.host_size < sizeof(T))
+    throw std::runtime_error{std::string{prog} + ": uniform block " + std::to_string(slot) + " is not bound"};
+  return (const T*)s.host_data;
+}
+template <typename T> const T* push(const LaunchState& st, const char* prog) {
+  if (st.push_size < sizeof(T)) throw std::runtime_error{std::string{prog} + ": push constants missing"};
+  return (const T*)st.push;
+}
+}  // namespace
+
+void create_program(const std::string& name, ProgramFn fn) { programs()[name] = std::move(fn); }
+bool has_program(const std::string& name) { return programs().count(name) != 0; }
+
+void register_hot_path_programs() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const auto T = SetSlot::Texture, S = SetSlot::StorageTexture;
+    // advanced_ssr/downsample_gbuffer.frag: set {0 depth, 1 normal, 2 velocity}; attachments {normal, velocity, depth mip+1}
+    create_program("downsample_gbuffer", [=](LaunchState& st) {
+      const char* P = "downsample_gbuffer";
+      const SetSlot& ds = st.set->slots[0];
+      if (st.attachments.size() != 3) throw std::runtime_error{"downsample_gbuffer: expects 2 colour attachments + depth"};
+      const ImageViewObject& dout = st.attachments[2];
+      if (ds.kind != T || ds.view.image != dout.image || dout.range.base_mip != ds.view.range.base_mip + 1)
+        throw std::runtime_error{"downsample_gbuffer: depth attachment must be the next mip of the sampled depth"};
+      vkr_img depth = ds.view.image->describe(ds.view.range.base_mip, 2);
+      vkr_img n = tex(st, 1, T, P), v = tex(st, 2, T, P);
+      vkr_img on = st.attachments[0].image->describe(st.attachments[0].range.base_mip, 1);
+      vkr_img ov = st.attachments[1].image->describe(st.attachments[1].range.base_mip, 1);
+      return vkr_downsample_gbuffer(&depth, &n, &v, &on, &ov, st.stream);
+    });
+    // advanced_ssr/depth_mips.frag: set {0 depth mip i-1}; attachment {depth mip i}
+    create_program("depth_mips", [=](LaunchState& st) {
+      const SetSlot& ds = st.set->slots[0];
+      if (st.attachments.size() != 1) throw std::runtime_error{"depth_mips: expects one depth attachment"};
+      const ImageViewObject& dout = st.attachments[0];
+      if (ds.kind != T || ds.view.image != dout.image || dout.range.base_mip != ds.view.range.base_mip + 1)
+        throw std::runtime_error{"depth_mips: attachment must be the next mip of the sampled depth"};
+      vkr_img depth = ds.view.image->describe(ds.view.range.base_mip, 2);
+      return vkr_depth_mips(&depth, 0, st.stream);
+    });
+    create_program("pdf_preintegrate", [=](LaunchState& st) {
+      vkr_img out = tex(st, 0, S, "pdf_preintegrate");
+      return vkr_pdf_preintegrate(&out, st.stream);
+    });
+    create_program("sssr_trace", [=](LaunchState& st) {
+      const char* P = "sssr_trace";
+      vkr_img depth = tex(st, 0, T, P), normal = tex(st, 1, T, P), material = tex(st, 2, T, P);
+      vkr_img rays = tex(st, 5, S, P), occ = tex(st, 6, S, P), pdf = tex(st, 7, T, P);
+      const SetSlot& h = st.set->slots[4];
+      if (h.kind != SetSlot::Ubo || !h.buffer) throw std::runtime_error{"sssr_trace: Halton buffer (binding 4) is not bound"};
+      return vkr_sssr_trace(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), (const float*)h.buffer->device_ptr(st.stream),
+                            &rays, &occ, &pdf, push<vkr_trace_push>(st, P), st.stream);
+    });
+    create_program("sssr_filter", [=](LaunchState& st) {
+      const char* P = "sssr_filter";
+      vkr_img rays = tex(st, 0, T, P), depth = tex(st, 1, T, P), albedo = tex(st, 2, T, P), normal = tex(st, 3, T, P);
+      vkr_img material = tex(st, 4, T, P), out = tex(st, 5, S, P);
+      return vkr_sssr_filter(&rays, &depth, &albedo, &normal, &material, &out, ubo<vkr_trace_params>(st, 6, P),
+                             push<vkr_filter_push>(st, P), st.stream);
+    });
+    create_program("sssr_blur", [=](LaunchState& st) {
+      const char* P = "sssr_blur";
+      vkr_img depth = tex(st, 0, T, P), normal = tex(st, 1, T, P), refl = tex(st, 2, T, P), material = tex(st, 3, T, P);
+      vkr_img history = tex(st, 4, T, P), velocity = tex(st, 5, T, P), hdepth = tex(st, 6, T, P), out = tex(st, 7, S, P);
+      return vkr_sssr_blur(&depth, &normal, &refl, &material, &history, &velocity, &hdepth, &out,
+                           ubo<vkr_reproject_params>(st, 8, P), push<vkr_blur_push>(st, P), st.stream);
+    });
+    create_program("gtao_compute_main", [=](LaunchState& st) {
+      const char* P = "gtao_compute_main";
+      vkr_img depth = tex(st, 0, T, P), normal = tex(st, 2, T, P), material = tex(st, 3, T, P), pdf = tex(st, 4, T, P);
+      vkr_img out = tex(st, 5, S, P);
+      return vkr_gtao_main(&depth, ubo<vkr_gtao_params>(st, 1, P), &normal, &material, &pdf, &out, push<vkr_gtao_push>(st, P), st.stream);
+    });
+    create_program("gtao_filter", [=](LaunchState& st) {
+      const char* P = "gtao_filter";
+      vkr_img depth = tex(st, 0, T, P), raw = tex(st, 1, T, P), out = tex(st, 2, S, P);
+      return vkr_gtao_filter(&depth, &raw, &out, push<vkr_gtao_filter_push>(st, P), st.stream);
+    });
+    create_program("gtao_accumulate", [=](LaunchState& st) {
+      const char* P = "gtao_accumulate";
+      vkr_img depth = tex(st, 0, T, P), pdepth = tex(st, 1, T, P), ao = tex(st, 2, T, P), out = tex(st, 3, S, P);
+      vkr_img velocity = tex(st, 4, T, P), history = tex(st, 5, T, P);
+      return vkr_gtao_accumulate(&depth, &pdepth, &ao, &out, &velocity, &history, ubo<vkr_gtao_accum_params>(st, 6, P),
+                                 push<vkr_gtao_accum_push>(st, P), st.stream);
+    });
+    create_program("taa_resolve", [=](LaunchState& st) {
+      const char* P = "taa_resolve";
+      vkr_img hist = tex(st, 0, T, P), hdepth = tex(st, 1, T, P), depth = tex(st, 2, T, P), velocity = tex(st, 3, T, P);
+      vkr_img color = tex(st, 4, T, P), out = tex(st, 5, S, P);
+      return vkr_taa_resolve(&hist, &hdepth, &depth, &velocity, &color, &out, ubo<vkr_reproject_params>(st, 6, P), st.stream);
+    });
+    // synthetic G-buffer "raster" program: attachments {albedo, normal, material, velocity, depth} or {depth}
+    create_program("synthetic_gbuffer", [=](LaunchState& st) {
+      const vkr_synth_params* p = ubo<vkr_synth_params>(st, 0, "synthetic_gbuffer");
+      auto att = [&](size_t i) { return st.attachments[i].image->describe(st.attachments[i].range.base_mip, 1); };
+      if (st.attachments.size() == 1) {
+        vkr_img d = att(0);
+        return vkr_synth_gbuffer(&d, nullptr, nullptr, nullptr, nullptr, p, st.stream);
+      }
+      if (st.attachments.size() != 5) throw std::runtime_error{"synthetic_gbuffer: expects 4 colour attachments + depth"};
+      vkr_img a = att(0), n = att(1), m = att(2), v = att(3), d = att(4);
+      return vkr_synth_gbuffer(&d, &n, &a, &m, &v, p, st.stream);
+    });
+  });
+}
+
+void BasePipeline::set_program(const std::string& name) {
+  register_hot_path_programs();
+  if (!gpu::has_program(name)) throw std::runtime_error{"Program not found"};
+  program = name;
+}
+ComputePipeline create_compute_pipeline() { return ComputePipeline{}; }
+ComputePipeline create_compute_pipeline(const char* name) { ComputePipeline p; p.set_program(name); return p; }
+GraphicsPipeline create_graphics_pipeline() { return GraphicsPipeline{}; }
+
+// ---- command context ---------------------------------------------------------------------------------------
+VkDescriptorSet CmdContext::allocate_set() {
+  sets.emplace_back(new DescriptorSetObject{});
+  return (VkDescriptorSet)sets.back().get();
+}
+void CmdContext::bind_pipeline(const ComputePipeline& p) {
+  if (!p.has_program()) throw std::runtime_error{"Pipeline without program"};
+  bound_program = p.program_name();
+}
+void CmdContext::bind_pipeline(const GraphicsPipeline& p) {
+  if (!p.has_program()) throw std::runtime_error{"Pipeline without program"};
+  bound_program = p.program_name();
+}
+void CmdContext::bind_sets(uint32_t first_set, const std::initializer_list<VkDescriptorSet>& s) {
+  if (first_set != 0 || s.size() != 1) throw std::runtime_error{"Only descriptor set 0 is used on this path"};
+  state.set = (const DescriptorSetObject*)*s.begin();
+}
+void CmdContext::push_constants_compute(uint32_t offset, uint32_t size, const void* constants) {
+  if (push_data.size() < offset + size) push_data.resize(offset + size);
+  std::memcpy(push_data.data() + offset, constants, size);
+}
+void CmdContext::set_framebuffer(uint32_t width, uint32_t height, const std::initializer_list<ImageViewObject>& attachments) {
+  state.fb_width = width; state.fb_height = height;
+  state.attachments.assign(attachments.begin(), attachments.end());
+}
+void CmdContext::launch() {
+  if (!bound_program) throw std::runtime_error{"No pipeline bound"};
+  auto it = programs().find(*bound_program);
+  if (it == programs().end()) throw std::runtime_error{"Program not found"};
+  state.push = push_data.data();
+  state.push_size = (uint32_t)push_data.size();
+  state.stream = stream;
+  int rc = it->second(state);
+  push_data.clear();
+  state.set = nullptr;
+  check_status(rc, bound_program->c_str());
+}
+void CmdContext::dispatch(uint32_t x, uint32_t y, uint32_t z) {
+  state.groups[0] = x; state.groups[1] = y; state.groups[2] = z;
+  launch();
+}
+void CmdContext::draw(uint32_t vertex_count, uint32_t, uint32_t, uint32_t) {
+  if (vertex_count != 3) throw std::runtime_error{"Only the full-screen triangle draw is implemented on this path"};
+  launch();
+}
+
+}  // namespace gpu

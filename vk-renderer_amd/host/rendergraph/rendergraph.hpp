@@ -1,0 +1,190 @@
+// rendergraph/rendergraph.hpp — the reference's task-graph API (src/rendergraph/rendergraph.hpp:17-158,
+// resources.hpp:49-114) over one in-order HIP stream.
+//
+// What is kept: ids are 32-bit indices into a table the graph owns; `add_task` runs `create_cb`
+// immediately (it declares resource use through the builder) and stores `run_cb`; `submit()` runs
+// the stored callbacks in submission order, never reordered (rendergraph.cpp:291-305); `remap`
+// swaps two table entries so ids stay valid (resources.cpp:89-91); misuse throws
+// std::runtime_error.  What is dropped: barriers / events / layouts — a single HIP stream
+// already orders every task after its predecessors.  Usage declarations are still checked: one
+// task may not read and write the same subresource ("Incompatible image usage in task",
+// resources.cpp:350-352).
+#ifndef VKR_HOST_RENDERGRAPH_HPP_INCLUDED
+#define VKR_HOST_RENDERGRAPH_HPP_INCLUDED
+
+#include <cinttypes>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../gpu/gpu.hpp"
+
+namespace rendergraph {
+
+struct GraphResources;
+
+struct ImageResourceId {
+  ImageResourceId() {}
+  uint32_t get_index() const { return index; }
+  bool operator==(const ImageResourceId& id) const { return index == id.index; }
+ private:
+  uint32_t index = ~0u;
+  friend struct GraphResources;
+};
+struct BufferResourceId {
+  BufferResourceId() {}
+  uint32_t get_index() const { return index; }
+  bool operator==(const BufferResourceId& id) const { return index == id.index; }
+ private:
+  uint32_t index = ~0u;
+  friend struct GraphResources;
+};
+struct ImageViewId {
+  ImageViewId(ImageResourceId id, gpu::ImageViewRange view) : res_id{id}, range{view} {}
+  ImageViewId() {}
+  ImageResourceId get_id() const { return res_id; }
+  const gpu::ImageViewRange& get_range() const { return range; }
+  operator ImageResourceId() const { return res_id; }
+ private:
+  ImageResourceId res_id;
+  gpu::ImageViewRange range;
+};
+
+enum class Usage : uint8_t { None, Sampled, Storage, ColorAttachment, DepthAttachment, TransferRead, TransferWrite };
+
+struct GraphResources {
+  ImageResourceId create_image(const gpu::ImageInfo& info, const gpu::FrameWindow& window);
+  BufferResourceId create_buffer(VmaMemoryUsage mem, uint64_t size, VkBufferUsageFlags usage);
+  void remap(ImageResourceId src, ImageResourceId dst);
+  gpu::ImagePtr& get_image(ImageResourceId id);
+  const gpu::ImagePtr& get_image(ImageResourceId id) const;
+  gpu::BufferPtr& get_buffer(BufferResourceId id);
+  // usage tracking of the task being recorded
+  void declare(ImageResourceId id, uint32_t base_mip, uint32_t mips, Usage usage, uint32_t task_index);
+  size_t image_count() const { return images.size(); }
+ private:
+  struct Entry {
+    gpu::ImagePtr image;
+    std::vector<std::pair<uint32_t, Usage>> last;  // per mip: (task index, usage)
+  };
+  std::vector<Entry> images;
+  std::vector<gpu::BufferPtr> buffers;
+};
+
+struct RenderGraph;
+
+struct RenderGraphBuilder {  // rendergraph.hpp:17-55
+  RenderGraphBuilder(GraphResources& res, uint32_t task) : resources{res}, task_index{task} {}
+  ImageViewId use_color_attachment(ImageResourceId id, uint32_t mip, uint32_t layer);
+  ImageViewId use_depth_attachment(ImageResourceId id, uint32_t mip, uint32_t layer);
+  ImageViewId use_storage_image(ImageResourceId id, VkShaderStageFlags stages, uint32_t mip, uint32_t layer);
+  ImageViewId use_storage_image_array(ImageResourceId id, VkShaderStageFlags stages);
+  ImageViewId sample_image(ImageResourceId id, VkShaderStageFlags stages, VkImageAspectFlags aspect, uint32_t base_mip,
+                           uint32_t mip_count, uint32_t base_layer, uint32_t layer_count);
+  ImageViewId sample_image(ImageResourceId id, VkShaderStageFlags stages, VkImageAspectFlags aspect = 0);
+  void use_uniform_buffer(BufferResourceId, VkShaderStageFlags) {}
+  void use_storage_buffer(BufferResourceId, VkShaderStageFlags, bool = true) {}
+  void use_indirect_buffer(BufferResourceId) {}
+  void transfer_read(ImageResourceId id, uint32_t base_mip, uint32_t mip_count, uint32_t base_layer, uint32_t layer_count);
+  void transfer_write(ImageResourceId id, uint32_t base_mip, uint32_t mip_count, uint32_t base_layer, uint32_t layer_count);
+  gpu::ImageInfo get_image_info(ImageResourceId id);
+  uint32_t get_frames_count() const { return 1; }
+ private:
+  GraphResources& resources;
+  uint32_t task_index;
+};
+
+struct RenderResources {  // rendergraph.hpp:57-83
+  RenderResources(GraphResources& res, gpu::CmdContext& c) : resources{res}, cmd{c} {}
+  gpu::BufferPtr& get_buffer(BufferResourceId id) { return resources.get_buffer(id); }
+  gpu::ImagePtr& get_image(ImageResourceId id) { return resources.get_image(id); }
+  VkImageView get_view(const ImageViewId& ref);
+  gpu::ImageViewObject get_image_range(const ImageViewId& ref) { return *(const gpu::ImageViewObject*)get_view(ref); }
+  VkDescriptorSet allocate_set(VkDescriptorSetLayout) { return cmd.allocate_set(); }
+  VkDescriptorSet allocate_set(const gpu::GraphicsPipeline&, uint32_t) { return cmd.allocate_set(); }
+  VkDescriptorSet allocate_set(const gpu::ComputePipeline&, uint32_t) { return cmd.allocate_set(); }
+  uint32_t get_frames_count() const { return 1; }
+  uint32_t get_frame_index() const { return 0; }
+  void reset() { views.clear(); }
+ private:
+  GraphResources& resources;
+  gpu::CmdContext& cmd;
+  std::vector<std::unique_ptr<gpu::ImageViewObject>> views;
+};
+
+struct BaseTask {
+  BaseTask(const std::string& task_name) : name{task_name} {}
+  virtual void write_commands(RenderResources&, gpu::CmdContext&) = 0;
+  virtual ~BaseTask() {}
+  const std::string& get_name() const { return name; }
+  std::string name;
+};
+template <typename TaskData> using TaskRunCB = std::function<void(TaskData&, RenderResources&, gpu::CmdContext&)>;
+template <typename TaskData> using TaskCreateCB = std::function<void(TaskData&, RenderGraphBuilder&)>;
+template <typename TaskData> struct Task : BaseTask {
+  Task(const std::string& name) : BaseTask{name} {}
+  TaskData data;
+  TaskRunCB<TaskData> callback;
+  void write_commands(RenderResources& resources, gpu::CmdContext& cmd) override { callback(data, resources, cmd); }
+};
+
+struct RenderGraph {  // rendergraph.hpp:112-158
+  // `stream`: the HIP stream every task is recorded on (nullptr = the default stream)
+  explicit RenderGraph(void* stream = nullptr);
+  ~RenderGraph();
+
+  template <typename TaskData>
+  void add_task(const std::string& name, TaskCreateCB<TaskData> create_cb, TaskRunCB<TaskData> run_cb) {
+    RenderGraphBuilder builder{resources, (uint32_t)tasks.size() + task_base};
+    std::unique_ptr<Task<TaskData>> ptr{new Task<TaskData>{name}};
+    create_cb(ptr->data, builder);
+    ptr->callback = run_cb;
+    tasks.push_back(std::move(ptr));
+  }
+
+  void submit();
+
+  ImageResourceId create_image(VkImageType type, const gpu::ImageInfo& info, VkImageTiling tiling, VkImageUsageFlags usage);
+  BufferResourceId create_buffer(VmaMemoryUsage mem, uint64_t size, VkBufferUsageFlags usage) { return resources.create_buffer(mem, size, usage); }
+  gpu::ImageInfo get_descriptor(ImageResourceId id) const { return resources.get_image(id)->get_info(); }
+  void remap(ImageResourceId src, ImageResourceId dst) { resources.remap(src, dst); }
+
+  uint32_t get_frames_count() const { return 1; }
+  uint32_t get_frame_index() const { return 0; }
+
+  // ---- additions for headless / tiled use (not in the reference) ----------------------------------
+  void set_stream(void* stream) { cmd.set_stream(stream); }
+  void* get_stream() const { return cmd.get_stream(); }
+  // Multi-GPU: this process holds the window (origin, win) of a (full) frame.  Images created at
+  // win >> k inherit origin >> k / full >> k; any other extent (LUTs ...) is a standalone image.
+  void set_frame_window(uint32_t full_w, uint32_t full_h, int32_t origin_x, int32_t origin_y, uint32_t win_w, uint32_t win_h);
+  // standalone image that always covers the whole frame at full >> k (gathered Hi-Z pyramid, ...)
+  ImageResourceId create_frame_image(const gpu::ImageInfo& info);
+  gpu::ImagePtr& get_image(ImageResourceId id) { return resources.get_image(id); }
+  const std::vector<std::string>& last_submitted_tasks() const { return submitted_names; }
+  // Per-task device timing: HIP events recorded around every task on the graph's stream (the
+  // counterpart of the reference's per-task debug labels, rendergraph.cpp:289-304).  Events are
+  // only recorded, never waited on, inside submit(); collect_task_times() synchronises.
+  void enable_task_timing(bool on);
+  struct TaskTime { std::string name; double total_ms = 0; uint32_t launches = 0; };
+  std::vector<TaskTime> collect_task_times();
+
+ private:
+  GraphResources resources;
+  gpu::CmdContext cmd;
+  std::vector<std::unique_ptr<BaseTask>> tasks;
+  std::vector<std::string> submitted_names;
+  uint32_t task_base = 1;
+  bool timing = false;
+  struct TimedTask { std::string name; void* start; void* stop; };
+  std::vector<TimedTask> timed;
+  std::vector<void*> event_pool;
+  void* get_event();
+  bool has_window = false;
+  uint32_t full_w = 0, full_h = 0, win_w = 0, win_h = 0;
+  int32_t org_x = 0, org_y = 0;
+};
+
+}  // namespace rendergraph
+#endif
