@@ -287,38 +287,72 @@ struct BlurArgs {
   uint32_t accumulate, disable_blur;
 };
 
-__global__ __launch_bounds__(256) void k_sssr_blur(BlurArgs a) {
-  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+// Tile geometry of the blur: a block resolves BLUR_BX x BLUR_BY pixels and stages the pixels within
+// the largest possible radius (r <= 11: sigma <= 4, blur.comp:45,53) in LDS.  Every staged pixel
+// is decoded once per block — depth (D24 -> float), normal (bilinear of 4 full-res texels,
+// octahedral decode, normalise; blur.comp:63) and reflection colour — instead of once per tap:
+// the reference shader repeats that work up to 529 times per pixel.
+#define BLUR_BX 32
+#define BLUR_BY 16
+#define BLUR_R 11
+#define BLUR_TW (BLUR_BX + 2 * BLUR_R)
+#define BLUR_TH (BLUR_BY + 2 * BLUR_R)
+
+__global__ __launch_bounds__(BLUR_BX * BLUR_BY) void k_sssr_blur(BlurArgs a) {
+  __shared__ float s_depth[BLUR_TH * BLUR_TW];
+  __shared__ float s_nx[BLUR_TH * BLUR_TW], s_ny[BLUR_TH * BLUR_TW], s_nz[BLUR_TH * BLUR_TW];
+  __shared__ float s_r[BLUR_TH * BLUR_TW], s_g[BLUR_TH * BLUR_TW], s_b[BLUR_TH * BLUR_TW];
+
+  const int tid = threadIdx.y * BLUR_BX + threadIdx.x;
+  const int bx0 = a.out.ox + blockIdx.x * BLUR_BX - BLUR_R;  // frame coordinates of the tile origin
+  const int by0 = a.out.oy + blockIdx.y * BLUR_BY - BLUR_R;
+  const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
+  for (int t = tid; t < BLUR_TW * BLUR_TH; t += BLUR_BX * BLUR_BY) {
+    const int tx = t % BLUR_TW, ty = t / BLUR_TW;
+    const int px = bx0 + tx, py = by0 + ty;
+    const f2 uv = mk2((float)px / tex_size.x, (float)py / tex_size.y);
+    s_depth[t] = fetch<FmtD24>(a.depth1, px, py);
+    const f3 n = decode_normal(sample<FmtRG16U>(a.normal, uv));
+    s_nx[t] = n.x; s_ny[t] = n.y; s_nz[t] = n.z;
+    const f3 c = fetch<FmtRGBA8>(a.refl, px, py);
+    s_r[t] = c.x; s_g[t] = c.y; s_b[t] = c.z;
+  }
+  __syncthreads();
+
+  const int lx = blockIdx.x * BLUR_BX + threadIdx.x;
+  const int ly = blockIdx.y * BLUR_BY + threadIdx.y;
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
-  const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
   const f2 screen_uv = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
   float roughness = sample<FmtSRGB8>(a.material, screen_uv).y;
   roughness = mixf(0.0f, a.max_roughness, roughness);
-  const float center_depth = fetch<FmtD24>(a.depth1, gx, gy);
+  const int tc = (threadIdx.y + BLUR_R) * BLUR_TW + (threadIdx.x + BLUR_R);
+  const float center_depth = s_depth[tc];
   const f3 center_normal = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
   float sigma = mixf(0.4f, 4.0f, roughness);
   if (a.disable_blur != 0) sigma = 0.35f;
   float weight_sum = 0.0f;
   f3 color = mk3(0, 0, 0);
-  const int r = f2i(floorf(3.0f * sigma - 0.01f));
+  const int r = min(f2i(floorf(3.0f * sigma - 0.01f)), BLUR_R);
   const float g = 1.0f / (((2.0f * VKR_PI) * sigma) * sigma);
   const float e = (2.0f * sigma) * sigma;
+  // smooth weights: reciprocal-multiply and the hardware exp2 are within ~1e-6 of the reference
+  // formula, far inside the 1e-3 / one-UNORM8-step tolerance; summation order is the shader's
+  const float neg_inv_e_log2 = -1.4426950408889634f / e;
+  const float k_bilateral = 1000.0f / center_depth;
 #pragma unroll 1
   for (int i = -r; i <= r; i++) {
+    const int col = tc + i;
 #pragma unroll 1
     for (int j = -r; j <= r; j++) {
-      const int px = gx + i, py = gy + j;
-      const f2 uv = mk2((float)px / tex_size.x, (float)py / tex_size.y);
-      const float pixel_depth = fetch<FmtD24>(a.depth1, px, py);
-      const f3 pixel_normal = decode_normal(sample<FmtRG16U>(a.normal, uv));
-      const float bilateral_weight = vmax(1.0f - (1000.0f * fabsf(center_depth - pixel_depth)) / center_depth, 0.0f);
-      const float normal_weight = vmax(dot(center_normal, pixel_normal), 0.0f);
-      float w = g * expf((float)(-(i * i + j * j)) / e);
+      const int t = col + j * BLUR_TW;
+      const float pixel_depth = s_depth[t];
+      const float bilateral_weight = vmax(1.0f - fabsf(center_depth - pixel_depth) * k_bilateral, 0.0f);
+      const float normal_weight = vmax((center_normal.x * s_nx[t] + center_normal.y * s_ny[t]) + center_normal.z * s_nz[t], 0.0f);
+      float w = g * __builtin_amdgcn_exp2f((float)(i * i + j * j) * neg_inv_e_log2);
       w *= bilateral_weight;
       w *= normal_weight;
-      color = color + fetch<FmtRGBA8>(a.refl, px, py) * w;
+      color = color + mk3(s_r[t], s_g[t], s_b[t]) * w;
       weight_sum += w;
     }
   }
@@ -432,7 +466,11 @@ extern "C" int vkr_sssr_blur(const vkr_img* depth, const vkr_img* normal, const 
   a.max_roughness = push->max_roughness;
   a.accumulate = push->accumulate;
   a.disable_blur = push->disable_blur;
-  dim3 block(64, 4);
+  if (a.max_roughness > 1.0f || a.max_roughness < 0.0f) {  // sigma <= 4 bounds the staged radius (blur.comp:45)
+    set_error("sssr_blur: max_roughness must be in [0,1] (reference slider range, advanced_ssr.cpp:558)");
+    return VKR_ERR_EXTENT;
+  }
+  dim3 block(BLUR_BX, BLUR_BY);
   hipLaunchKernelGGL(k_sssr_blur, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_blur");
 }
