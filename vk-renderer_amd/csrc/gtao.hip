@@ -41,6 +41,9 @@ VKR_DEV float find_horizon(const Tex& depth, const Proj& pr, f2 start, f3 camera
 // repeats every 4x4 pixels (main.comp:276-278), so its 16 (cos,sin) pairs are kernel
 // arguments evaluated once on the host instead of per pixel.
 __global__ __launch_bounds__(256) void k_gtao_main(GtaoArgs a) {
+  __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
+  srgb_lut_stage(s_lut, threadIdx.y * blockDim.x + threadIdx.x, 256);
+  __syncthreads();
   const int lx = blockIdx.x * blockDim.x + threadIdx.x;
   const int ly = blockIdx.y * blockDim.y + threadIdx.y;
   if (lx >= a.out.w || ly >= a.out.h) return;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void k_gtao_main(GtaoArgs a) {
       occ_x = (2.0f * sum) / (float)dirs;  // main.comp:216
     } else {
       // main.comp:250-273
-      const float roughness = sample<FmtSRGB8>(a.material, screen_uv).y;
+      const float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
       const float pdf_ggx = sampleGGXdirPDF(a.pdf, w0, camera_normal, L, roughness * roughness);
       const uint2 prev = *dst;  // imageLoad(gtao_out): (occlusion, pdf) written by the SSR trace
       const float ao_x = half_bits_to_float(prev.x & 0xFFFFu), ao_y = half_bits_to_float(prev.x >> 16);

@@ -68,28 +68,34 @@ VKR_DEV f3 sampleGGXVNDF(f3 Ve, float alpha_x, float alpha_y, float U1, float U2
   return normalize(mk3(alpha_x * Nh.x, alpha_y * Nh.y, vmax(0.0f, Nh.z)));
 }
 
-// texelFetch(depth_tex, ivec2(p), mip) on the pyramid: beyond the last mip or out of the
-// (floored) mip extent -> 0
-VKR_DEV float pyramid_fetch(const Pyramid& pyr, int gx, int gy, int mip) {
-  if (mip < 0 || mip >= pyr.count) return 0.0f;
-  return fetch<FmtD24>(pyr.mip[mip], gx, gy);
-}
-
-// One thread per ray; a wave covers an 8x8 pixel tile (block 8x8x4 tiles) so that the
-// rays of a wave start in neighbouring texels and share cache lines while they stay coherent.
+// One thread per ray; a wave covers an 8x8 pixel tile (block = 4 such tiles) so that the rays of
+// a wave start in neighbouring texels and share cache lines while they stay coherent.
+// The Hi-Z pyramid is indexed by a per-lane mip level, so its per-mip descriptors are staged in
+// LDS once per block (one ds_read_b128 per step) instead of being re-read from the kernel
+// argument segment with dependent global loads on every step of the march.
 __global__ __launch_bounds__(256) void k_sssr_trace(TraceArgs a) {
+  __shared__ uint4 s_mip[16];  // {base lo, base hi, pitch, w | h << 16}; the pyramid covers the whole frame
+  __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
+  srgb_lut_stage(s_lut, threadIdx.x, 256);
+  if (threadIdx.x < 16) {
+    const Tex& m = a.depth.mip[threadIdx.x < (unsigned)a.depth.count ? threadIdx.x : 0];
+    const uint64_t base = (uint64_t)m.p;
+    s_mip[threadIdx.x] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)m.pitch, (uint32_t)m.w | ((uint32_t)m.h << 16));
+  }
+  __syncthreads();
   // 256 threads = 4 waves; wave w owns the 8x8 tile (blockIdx.x*4 + w, blockIdx.y)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lx = (blockIdx.x * 4 + wave) * 8 + (lane & 7);
   const int ly = blockIdx.y * 8 + (lane >> 3);
   if (lx >= a.out_ray.w || ly >= a.out_ray.h) return;
+  const int mip_count = a.depth.count;
   const int gx = a.out_ray.ox + lx, gy = a.out_ray.oy + ly;
   const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
   const f2 screen_uv = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
   const Proj pr = a.pr;
 
   // trace.comp:49-58
-  float roughness = sample<FmtSRGB8>(a.material, screen_uv).y;
+  float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
   const float mg = mixf(0.0f, a.max_roughness, roughness);
   roughness = mg * mg;
   const Tex& depth0 = a.depth.mip[0];
@@ -151,7 +157,16 @@ __global__ __launch_bounds__(256) void k_sssr_trace(TraceArgs a) {
 #pragma unroll 1
   while (i < 80 && current_mip >= 0) {
     const f2 mip_pos = res * xy(position);
-    const float surface_z = pyramid_fetch(a.depth, f2i(mip_pos.x), f2i(mip_pos.y), current_mip);
+    // texelFetch(depth_tex, ivec2(p), mip): beyond the last mip or outside the mip extent -> 0
+    float surface_z = 0.0f;
+    if ((unsigned)current_mip < (unsigned)mip_count) {
+      const uint4 m = s_mip[current_mip];
+      const int tx = f2i(mip_pos.x), ty = f2i(mip_pos.y);
+      if (tx >= 0 && ty >= 0 && tx < (int)(m.w & 0xFFFFu) && ty < (int)(m.w >> 16)) {
+        const uint8_t* row = (const uint8_t*)(((uint64_t)m.y << 32) | m.x) + (size_t)ty * m.z;
+        surface_z = d24_to_float(((const uint32_t*)row)[tx]);
+      }
+    }
     // advance_ray (screen_trace.glsl:17-45)
     f2 xy_plane = mk2(floorf(mip_pos.x), floorf(mip_pos.y)) + floor_offset;
     xy_plane = xy_plane * res_inv + uv_offset;
@@ -231,15 +246,18 @@ struct FilterArgs {
 };
 
 __global__ __launch_bounds__(256) void k_sssr_filter(FilterArgs a) {
+  __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
+  srgb_lut_stage(s_lut, threadIdx.y * blockDim.x + threadIdx.x, 256);
+  __syncthreads();
   const int lx = blockIdx.x * blockDim.x + threadIdx.x;
   const int ly = blockIdx.y * blockDim.y + threadIdx.y;
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
   const f2 screen_uv = mk2((float)gx / tex_size.x, (float)gy / tex_size.y);  // no +0.5 (filter.comp:39)
-  const f3 material = sample<FmtSRGB8>(a.material, screen_uv);
-  const float metallic = material.z, roughness = material.y;
-  const f3 albedo = sample<FmtSRGB8>(a.albedo, screen_uv);
+  const float metallic = sample_srgb_channel(a.material, screen_uv, 2, s_lut);
+  const float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
+  const f3 albedo = sample_srgb_rgb(a.albedo, screen_uv, s_lut);
   const f3 F0 = F0_approximation(albedo, metallic);
   f3 color_sum = mk3(0, 0, 0), weight_sum = mk3(0, 0, 0);
   const float center_depth = fetch<FmtD24>(a.depth1, gx, gy);
@@ -254,7 +272,7 @@ __global__ __launch_bounds__(256) void k_sssr_filter(FilterArgs a) {
     const f3 pnw = decode_normal(sample<FmtRG16U>(a.normal, pixel_uv));
     const f3 Nn = xyz(mul(a.normal_mat, mk4(pnw.x, pnw.y, pnw.z, 0.0f)));
     const f3 hit_vec = reconstruct_view_vec(mk2(trace_result.x, trace_result.y), trace_result.z, a.pr);
-    const f3 radiance = (trace_result.w != 1.0f) ? sample<FmtSRGB8>(a.albedo, mk2(trace_result.x, trace_result.y)) : mk3(0, 0, 0);
+    const f3 radiance = (trace_result.w != 1.0f) ? sample_srgb_rgb(a.albedo, mk2(trace_result.x, trace_result.y), s_lut) : mk3(0, 0, 0);
     const f3 V = -normalize(view_vec);
     const f3 L = normalize(hit_vec - view_vec);
     // ray_weight (filter.comp:97-108), literal swapped argument order of brdfG1
@@ -302,6 +320,8 @@ __global__ __launch_bounds__(BLUR_BX * BLUR_BY) void k_sssr_blur(BlurArgs a) {
   __shared__ float s_depth[BLUR_TH * BLUR_TW];
   __shared__ float s_nx[BLUR_TH * BLUR_TW], s_ny[BLUR_TH * BLUR_TW], s_nz[BLUR_TH * BLUR_TW];
   __shared__ float s_r[BLUR_TH * BLUR_TW], s_g[BLUR_TH * BLUR_TW], s_b[BLUR_TH * BLUR_TW];
+  __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
+  srgb_lut_stage(s_lut, threadIdx.y * BLUR_BX + threadIdx.x, BLUR_BX * BLUR_BY);
 
   const int tid = threadIdx.y * BLUR_BX + threadIdx.x;
   const int bx0 = a.out.ox + blockIdx.x * BLUR_BX - BLUR_R;  // frame coordinates of the tile origin
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(BLUR_BX * BLUR_BY) void k_sssr_blur(BlurArgs a) {
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   const f2 screen_uv = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
-  float roughness = sample<FmtSRGB8>(a.material, screen_uv).y;
+  float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
   roughness = mixf(0.0f, a.max_roughness, roughness);
   const int tc = (threadIdx.y + BLUR_R) * BLUR_TW + (threadIdx.x + BLUR_R);
   const float center_depth = s_depth[tc];
@@ -415,6 +435,13 @@ extern "C" int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const
   VKR_TRY(make_tex(out_ray, 0, VKR_FMT_RGBA16_UNORM, "sssr_trace.out_ray", &a.out_ray));
   VKR_TRY(make_tex(out_occlusion, 0, VKR_FMT_RGBA16_SFLOAT, "sssr_trace.out_occlusion", &a.out_occ));
   if (!same_window(a.out_ray, a.out_occ)) { set_error("sssr_trace: ray / occlusion outputs differ in extent"); return VKR_ERR_EXTENT; }
+  for (int i = 0; i < a.depth.count; i++) {
+    const Tex& m = a.depth.mip[i];
+    if (m.ox != 0 || m.oy != 0 || m.w != m.fw || m.h != m.fh || m.w > 65535 || m.h > 65535) {
+      set_error("sssr_trace: the Hi-Z pyramid must cover the whole frame (rays have unbounded reach)");
+      return VKR_ERR_EXTENT;
+    }
+  }
   a.halton = (const float4*)halton_vec4;
   load_mat(a.normal_mat, params->normal_mat);
   load_proj(a.pr, params->fovy, params->aspect, params->znear, params->zfar);

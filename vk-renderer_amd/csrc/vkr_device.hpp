@@ -94,9 +94,13 @@ VKR_DEV uint32_t float_to_srgb8(float x) {
   }
   return (uint32_t)lo;
 }
-VKR_DEV float d24_to_float(uint32_t t) { return (float)(t & 0xFFFFFFu) / 16777215.0f; }
-VKR_DEV float unorm16_to_float(uint32_t v) { return (float)v / 65535.0f; }
-VKR_DEV float unorm8_to_float(uint32_t v) { return (float)v / 255.0f; }
+// UNORM -> float is defined as the correctly rounded quotient k / (2^b - 1).  The product
+// (double)k * (1.0 / (2^b - 1)) rounded to float equals that quotient for every code of every
+// width used here (exhaustively checked in tests/test_codecs.py) and costs 3 instructions
+// instead of an IEEE division sequence.
+VKR_DEV float d24_to_float(uint32_t t) { return (float)((double)(t & 0xFFFFFFu) * (1.0 / 16777215.0)); }
+VKR_DEV float unorm16_to_float(uint32_t v) { return (float)((double)v * (1.0 / 65535.0)); }
+VKR_DEV float unorm8_to_float(uint32_t v) { return (float)((double)v * (1.0 / 255.0)); }
 VKR_DEV uint32_t float_to_unorm16(float f) { return (uint32_t)rintf(vclamp(f, 0.0f, 1.0f) * 65535.0f); }
 VKR_DEV uint32_t float_to_unorm8(float f) { return (uint32_t)rintf(vclamp(f, 0.0f, 1.0f) * 255.0f); }
 VKR_DEV float half_bits_to_float(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)h)); }
@@ -174,6 +178,46 @@ template <class F> VKR_DEV typename F::T sample(const Tex& t, f2 uv, int offx = 
   typename F::T t00 = fetch_clamped<F>(t, x0, y0), t10 = fetch_clamped<F>(t, x0 + 1, y0);
   typename F::T t01 = fetch_clamped<F>(t, x0, y0 + 1), t11 = fetch_clamped<F>(t, x0 + 1, y0 + 1);
   return F::lerp(F::lerp(t00, t10, fx), F::lerp(t01, t11, fx), fy);
+}
+
+// ---- sRGB images ------------------------------------------------------------------------------------
+// The EOTF table lives in global memory (srgb_tables.inc); kernels that sample _SRGB images copy
+// it into LDS once per block (srgb_lut_stage + __syncthreads) so a texel decode is three LDS
+// reads instead of three dependent global loads.
+#define VKR_SRGB_LUT_SIZE 256
+VKR_DEV void srgb_lut_stage(float* lds_lut, int tid, int nthreads) {
+  for (int i = tid; i < VKR_SRGB_LUT_SIZE; i += nthreads) lds_lut[i] = __uint_as_float(k_srgb_decode_bits[i]);
+}
+VKR_DEV uint32_t load_u32_clamped(const Tex& t, int gx, int gy) {
+  gx = iclamp(gx, 0, t.fw - 1);
+  gy = iclamp(gy, 0, t.fh - 1);
+  int lx = iclamp(gx - t.ox, 0, t.w - 1), ly = iclamp(gy - t.oy, 0, t.h - 1);
+  return *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);
+}
+struct BilinearTaps { uint32_t t00, t10, t01, t11; float fx, fy; };
+// the four raw texels + weights of texture(tex, uv) for any 4-byte format
+VKR_DEV BilinearTaps bilinear_taps_u32(const Tex& t, f2 uv) {
+  BilinearTaps b;
+  float x = uv.x * (float)t.fw - 0.5f, y = uv.y * (float)t.fh - 0.5f;
+  float x0f = floorf(x), y0f = floorf(y);
+  b.fx = x - x0f; b.fy = y - y0f;
+  int x0 = f2i(x0f), y0 = f2i(y0f);
+  b.t00 = load_u32_clamped(t, x0, y0); b.t10 = load_u32_clamped(t, x0 + 1, y0);
+  b.t01 = load_u32_clamped(t, x0, y0 + 1); b.t11 = load_u32_clamped(t, x0 + 1, y0 + 1);
+  return b;
+}
+// one channel (0 = r, 1 = g, 2 = b) of texture() on an RGBA8_SRGB image
+VKR_DEV float sample_srgb_channel(const Tex& t, f2 uv, int channel, const float* lut) {
+  const BilinearTaps b = bilinear_taps_u32(t, uv);
+  const int sh = channel * 8;
+  const float a00 = lut[(b.t00 >> sh) & 0xFFu], a10 = lut[(b.t10 >> sh) & 0xFFu];
+  const float a01 = lut[(b.t01 >> sh) & 0xFFu], a11 = lut[(b.t11 >> sh) & 0xFFu];
+  return mixf(mixf(a00, a10, b.fx), mixf(a01, a11, b.fx), b.fy);
+}
+VKR_DEV f3 srgb_rgb(uint32_t v, const float* lut) { return mk3(lut[v & 0xFFu], lut[(v >> 8) & 0xFFu], lut[(v >> 16) & 0xFFu]); }
+VKR_DEV f3 sample_srgb_rgb(const Tex& t, f2 uv, const float* lut) {
+  const BilinearTaps b = bilinear_taps_u32(t, uv);
+  return mix3(mix3(srgb_rgb(b.t00, lut), srgb_rgb(b.t10, lut), b.fx), mix3(srgb_rgb(b.t01, lut), srgb_rgb(b.t11, lut), b.fx), b.fy);
 }
 
 template <class T> VKR_DEV T* texel_ptr(const Tex& t, int lx, int ly) { return (T*)(const_cast<uint8_t*>(t.p) + (size_t)ly * t.pitch) + lx; }
