@@ -36,7 +36,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # (every input surface read once, every output written once, at storage-format size).
 BYTES_PER_PX = {
     "DownsampleGbuffer": 15.0,
-    "DownsampleDepth": 1.667,  # all (L-2) launches together
+    "DownsampleDepth": 1.667,  # the whole chain mips 2..L-1 (one task, two launches)
     "SSSR_trace": 10.333,
     "SSSR_filter": 16.0,
     "SSSR_blur": 14.0,

@@ -19,14 +19,39 @@ struct GtaoArgs {
   uint32_t use_mis, two_directions, reflections_only;
 };
 
+// Depth tile staged in LDS for the horizon search.  A block resolves GT_BX x GT_BY pixels; every
+// sample of find_horizon lies within min(100/|P|, 16) pixels of its pixel (main.comp:229) and the
+// bilinear footprint adds one more, so an apron of GT_R = 17 texels covers all 16 taps.  The tile
+// holds decoded depth for frame coordinates *after* clamp-to-edge, so a tap is four LDS reads.
+#define GT_BX 64
+#define GT_BY 16
+#define GT_R 17
+#define GT_TW (GT_BX + 2 * GT_R)
+#define GT_TH (GT_BY + 2 * GT_R)
+
+struct DepthTile {
+  const float* d;
+  int x0, y0;  // frame coordinates of tile texel (0,0)
+  float fw, fh;
+};
+// texture(depth, uv): same arithmetic as sample<FmtD24>, texels served from the tile
+VKR_DEV float tile_sample(const DepthTile& t, f2 uv) {
+  float x = uv.x * t.fw - 0.5f, y = uv.y * t.fh - 0.5f;
+  float x0f = floorf(x), y0f = floorf(y);
+  float fx = x - x0f, fy = y - y0f;
+  int tx = iclamp(f2i(x0f) - t.x0, 0, GT_TW - 2), ty = iclamp(f2i(y0f) - t.y0, 0, GT_TH - 2);
+  const float* p = t.d + ty * GT_TW + tx;
+  return mixf(mixf(p[0], p[1], fx), mixf(p[GT_TW], p[GT_TW + 1], fx), fy);
+}
+
 // main.comp:84-108
-VKR_DEV float find_horizon(const Tex& depth, const Proj& pr, f2 start, f3 camera_start, f2 dir, f3 v) {
+VKR_DEV float find_horizon(const DepthTile& depth, const Proj& pr, f2 start, f3 camera_start, f2 dir, f3 v) {
   float h_cos = -1.0f;
   float previous_z = camera_start.z;
 #pragma unroll 1
   for (int i = 1; i <= 16; i++) {
     f2 tc = start + ((float)i / 16.0f) * dir;
-    float sample_depth = sample<FmtD24>(depth, tc);
+    float sample_depth = tile_sample(depth, tc);
     f3 sample_pos = reconstruct_view_vec(tc, sample_depth, pr);
     if (sample_pos.z > previous_z + 0.1f) break;  // MAX_THIKNESS, main.comp:82
     previous_z = sample_pos.z;
@@ -37,15 +62,24 @@ VKR_DEV float find_horizon(const Tex& depth, const Proj& pr, f2 start, f3 camera
   return h_cos;
 }
 
-// One thread per half-res pixel; blocks of 64x4 pixels.  The slice-direction pattern
-// repeats every 4x4 pixels (main.comp:276-278), so its 16 (cos,sin) pairs are kernel
-// arguments evaluated once on the host instead of per pixel.
-__global__ __launch_bounds__(256) void k_gtao_main(GtaoArgs a) {
+// One thread per half-res pixel.  The slice-direction pattern repeats every 4x4 pixels
+// (main.comp:276-278), so its 16 (cos,sin) pairs are kernel arguments evaluated once on the host
+// instead of per pixel.
+__global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
-  srgb_lut_stage(s_lut, threadIdx.y * blockDim.x + threadIdx.x, 256);
+  __shared__ float s_depth[GT_TW * GT_TH];
+  const int tid = threadIdx.y * GT_BX + threadIdx.x;
+  srgb_lut_stage(s_lut, tid, GT_BX * GT_BY);
+  DepthTile tile;
+  tile.d = s_depth;
+  tile.x0 = a.out.ox + blockIdx.x * GT_BX - GT_R;
+  tile.y0 = a.out.oy + blockIdx.y * GT_BY - GT_R;
+  tile.fw = (float)a.depth.fw; tile.fh = (float)a.depth.fh;
+  for (int t = tid; t < GT_TW * GT_TH; t += GT_BX * GT_BY)
+    s_depth[t] = fetch_clamped<FmtD24>(a.depth, tile.x0 + t % GT_TW, tile.y0 + t / GT_TW);
   __syncthreads();
-  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+  const int lx = blockIdx.x * GT_BX + threadIdx.x;
+  const int ly = blockIdx.y * GT_BY + threadIdx.y;
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   if (gx >= a.tex_w || gy >= a.tex_h) return;
@@ -54,7 +88,7 @@ __global__ __launch_bounds__(256) void k_gtao_main(GtaoArgs a) {
   float occ_x = 0.0f, occ_y = pdf_uniform;
   uint2* dst = texel_ptr<uint2>(a.out, lx, ly);
 
-  const float frag_depth = sample<FmtD24>(a.depth, screen_uv);
+  const float frag_depth = tile_sample(tile, screen_uv);
   if (frag_depth >= 1.0f) {  // sky: mis -> (0,1), non-mis -> 0 (main.comp:187-189,221-223)
     occ_x = 0.0f;
     occ_y = a.use_mis ? 1.0f : pdf_uniform;
@@ -77,7 +111,7 @@ __global__ __launch_bounds__(256) void k_gtao_main(GtaoArgs a) {
       const f3 normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
       const f3 X = -normalize(cross(slice_normal, w0));
       const float n = VKR_PI / 2.0f - acosf(dot(normalize(normal_projected), X));
-      const float h_cos = find_horizon(a.depth, a.pr, screen_uv, camera_pos, sample_direction, w0);
+      const float h_cos = find_horizon(tile, a.pr, screen_uv, camera_pos, sample_direction, w0);
       float h = acosf(h_cos);
       h = vmin(n + vmin(h - n, VKR_PI / 2.0f), h);
       const float arc = vmax((-cosf(2.0f * h - n) + cosf(n)) + (2.0f * h) * sinf(n), 0.0f);
@@ -117,25 +151,38 @@ __global__ __launch_bounds__(256) void k_gtao_main(GtaoArgs a) {
   *dst = o;
 }
 
-// filter.comp:17-51: 4x4 taps at offsets -2..+1, depth-weighted mean of raw.r.
-__global__ __launch_bounds__(256) void k_gtao_filter(Tex depth, Tex raw, Tex out, int tex_w, int tex_h, float znear, float zfar) {
-  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+// filter.comp:17-51: 4x4 taps at offsets -2..+1, depth-weighted mean of raw.r.  The block stages
+// {linearised depth, raw.r} of its pixels plus the (-2..+1) apron in LDS; out-of-frame taps read 0
+// like the shader's texelFetch (linearize(0) = -znear, raw = 0).
+#define GF_BX 64
+#define GF_BY 4
+#define GF_TW (GF_BX + 3)
+#define GF_TH (GF_BY + 3)
+__global__ __launch_bounds__(GF_BX * GF_BY) void k_gtao_filter(Tex depth, Tex raw, Tex out, int tex_w, int tex_h, float znear, float zfar) {
+  __shared__ float2 s_t[GF_TW * GF_TH];
+  const int tid = threadIdx.y * GF_BX + threadIdx.x;
+  const int bx0 = out.ox + blockIdx.x * GF_BX - 2, by0 = out.oy + blockIdx.y * GF_BY - 2;
+  for (int t = tid; t < GF_TW * GF_TH; t += GF_BX * GF_BY) {
+    const int px = bx0 + t % GF_TW, py = by0 + t / GF_TW;
+    s_t[t] = make_float2(linearize_depth2(fetch<FmtD24>(depth, px, py), znear, zfar), fetch<FmtRGBA16F>(raw, px, py).x);
+  }
+  __syncthreads();
+  const int lx = blockIdx.x * GF_BX + threadIdx.x;
+  const int ly = blockIdx.y * GF_BY + threadIdx.y;
   if (lx >= out.w || ly >= out.h) return;
   const int gx = out.ox + lx, gy = out.oy + ly;
   if (gx >= tex_w || gy >= tex_h) return;
-  const float pixel_depth = fetch<FmtD24>(depth, gx, gy);
-  const float linear_depth = linearize_depth2(pixel_depth, znear, zfar);
+  const int tc = (threadIdx.y + 2) * GF_TW + (threadIdx.x + 2);
+  const float linear_depth = s_t[tc].x;
   float weight_sum = 0.0f, ao = 0.0f;
 #pragma unroll
   for (int x = 0; x < 4; x++) {
 #pragma unroll
     for (int y = 0; y < 4; y++) {
-      const int sx = gx + (x - 2), sy = gy + (y - 2);
-      const float sampled_depth = linearize_depth2(fetch<FmtD24>(depth, sx, sy), znear, zfar);
-      const float weight = vmax(0.0f, 1.0f - (5.0f * fabsf(sampled_depth - linear_depth)) / fabsf(linear_depth));
+      const float2 sm = s_t[tc + (x - 2) + (y - 2) * GF_TW];
+      const float weight = vmax(0.0f, 1.0f - (5.0f * fabsf(sm.x - linear_depth)) / fabsf(linear_depth));
       weight_sum += weight;
-      ao += weight * fetch<FmtRGBA16F>(raw, sx, sy).x;
+      ao += weight * sm.y;
     }
   }
   ao /= weight_sum;
@@ -226,7 +273,7 @@ extern "C" int vkr_gtao_main(const vkr_img* depth, const vkr_gtao_params* params
       a.slice_cs[di][k][1] = sinf(angle);
     }
   }
-  dim3 block(64, 4);
+  dim3 block(GT_BX, GT_BY);
   hipLaunchKernelGGL(k_gtao_main, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   return launch_status("gtao_main");
 }
@@ -238,7 +285,7 @@ extern "C" int vkr_gtao_filter(const vkr_img* depth, const vkr_img* raw_gtao, co
   VKR_TRY(make_tex(depth, 0, VKR_FMT_D24_UNORM_S8, "gtao_filter.depth", &d));
   VKR_TRY(make_tex(raw_gtao, 0, VKR_FMT_RGBA16_SFLOAT, "gtao_filter.raw", &raw));
   VKR_TRY(make_tex(out_filtered, 0, VKR_FMT_R16_SFLOAT, "gtao_filter.out", &out));
-  dim3 block(64, 4);
+  dim3 block(GF_BX, GF_BY);
   hipLaunchKernelGGL(k_gtao_filter, grid2d(out.w, out.h, block), block, 0, (hipStream_t)stream, d, raw, out,
                      (out.fw / 8) * 8, (out.fh / 4) * 4, push->znear, push->zfar);
   return launch_status("gtao_filter");

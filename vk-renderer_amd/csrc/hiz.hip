@@ -5,6 +5,7 @@
 // min() of quantised values re-quantises to itself, so the path is bit-exact integer work.
 // Roofline: HBM.  D1 moves 15 B per full-res pixel, D2 1.667 B.
 #include "vkr_host.hpp"
+#include <algorithm>
 
 namespace vkr {
 
@@ -48,23 +49,89 @@ __global__ __launch_bounds__(256) void k_downsample_gbuffer(Tex d0, Tex d1, Tex 
   *texel_ptr<uint32_t>(d1, x, y) = mn;
 }
 
-// mip i = 2x2 min of mip i-1 (depth_mips.frag).  One thread per destination texel.
-__global__ __launch_bounds__(256) void k_depth_mip(Tex src, Tex dst) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= dst.w || y >= dst.h) return;
-  auto ld = [&](int lx, int ly) -> uint32_t {
-    return (lx < src.w && ly < src.h) ? (*(const uint32_t*)(src.p + (size_t)ly * src.pitch + (size_t)lx * 4) & 0xFFFFFFu) : 0u;
-  };
-  uint32_t a, b, c, d;
-  if (2 * x + 1 < src.w && 2 * y + 1 < src.h) {
-    uint2 r0 = *(const uint2*)(src.p + (size_t)(2 * y) * src.pitch + (size_t)(2 * x) * 4);
-    uint2 r1 = *(const uint2*)(src.p + (size_t)(2 * y + 1) * src.pitch + (size_t)(2 * x) * 4);
-    a = r0.x & 0xFFFFFFu; b = r0.y & 0xFFFFFFu; c = r1.x & 0xFFFFFFu; d = r1.y & 0xFFFFFFu;
-  } else {
-    a = ld(2 * x, 2 * y); b = ld(2 * x + 1, 2 * y); c = ld(2 * x, 2 * y + 1); d = ld(2 * x + 1, 2 * y + 1);
+// depth_mips.frag: mip i = 2x2 min of mip i-1.  The reference records one full-screen draw per mip
+// (downsample_pass.cpp:107-129: L-2 dependent passes, 10 at 4K).  Here one workgroup reduces a
+// 32x32 block of the source mip through LDS and writes up to FUSED_LEVELS consecutive mips, so
+// the whole chain is two launches.  A destination texel (X,Y) of level k exists iff X < W_k and
+// Y < H_k (W_k = max(1, W >> k)); a non-existent texel is only ever read when its parent extent
+// is 1, where the reference's out-of-bounds texelFetch returns 0 — so non-existent texels are
+// carried as 0 through LDS and never stored.
+#define FUSED_LEVELS 5
+struct MipChainArgs {
+  Tex src;
+  Tex dst[FUSED_LEVELS];
+  int levels;
+};
+
+VKR_DEV uint32_t min4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return min(min(a, b), min(c, d)); }
+
+__global__ __launch_bounds__(256) void k_depth_mips_fused(MipChainArgs a) {
+  __shared__ uint32_t s_l1[16][16], s_l2[8][8], s_l3[4][4], s_l4[2][2];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  {  // level 1: one thread per texel, 2x2 quad of the source as two 8-byte row loads
+    const int x = blockIdx.x * 16 + tx, y = blockIdx.y * 16 + ty;
+    const Tex& src = a.src;
+    uint32_t v = 0u;
+    if (x < a.dst[0].w && y < a.dst[0].h) {
+      uint32_t q0, q1, q2, q3;
+      if (2 * x + 1 < src.w && 2 * y + 1 < src.h) {
+        uint2 r0 = *(const uint2*)(src.p + (size_t)(2 * y) * src.pitch + (size_t)(2 * x) * 4);
+        uint2 r1 = *(const uint2*)(src.p + (size_t)(2 * y + 1) * src.pitch + (size_t)(2 * x) * 4);
+        q0 = r0.x & 0xFFFFFFu; q1 = r0.y & 0xFFFFFFu; q2 = r1.x & 0xFFFFFFu; q3 = r1.y & 0xFFFFFFu;
+      } else {  // parent extent 1: texelFetch out of bounds -> 0
+        auto ld = [&](int lx, int ly) -> uint32_t {
+          return (lx < src.w && ly < src.h) ? (*(const uint32_t*)(src.p + (size_t)ly * src.pitch + (size_t)lx * 4) & 0xFFFFFFu) : 0u;
+        };
+        q0 = ld(2 * x, 2 * y); q1 = ld(2 * x + 1, 2 * y); q2 = ld(2 * x, 2 * y + 1); q3 = ld(2 * x + 1, 2 * y + 1);
+      }
+      v = min4(q0, q1, q2, q3);
+      *texel_ptr<uint32_t>(a.dst[0], x, y) = v;
+    }
+    s_l1[ty][tx] = v;
   }
-  *texel_ptr<uint32_t>(dst, x, y) = min(min(a, b), min(c, d));
+  if (a.levels < 2) return;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lx = threadIdx.x & 7, ly = threadIdx.x >> 3;
+    const int x = blockIdx.x * 8 + lx, y = blockIdx.y * 8 + ly;
+    uint32_t v = 0u;
+    if (x < a.dst[1].w && y < a.dst[1].h) {
+      v = min4(s_l1[2 * ly][2 * lx], s_l1[2 * ly][2 * lx + 1], s_l1[2 * ly + 1][2 * lx], s_l1[2 * ly + 1][2 * lx + 1]);
+      *texel_ptr<uint32_t>(a.dst[1], x, y) = v;
+    }
+    s_l2[ly][lx] = v;
+  }
+  if (a.levels < 3) return;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int lx = threadIdx.x & 3, ly = threadIdx.x >> 2;
+    const int x = blockIdx.x * 4 + lx, y = blockIdx.y * 4 + ly;
+    uint32_t v = 0u;
+    if (x < a.dst[2].w && y < a.dst[2].h) {
+      v = min4(s_l2[2 * ly][2 * lx], s_l2[2 * ly][2 * lx + 1], s_l2[2 * ly + 1][2 * lx], s_l2[2 * ly + 1][2 * lx + 1]);
+      *texel_ptr<uint32_t>(a.dst[2], x, y) = v;
+    }
+    s_l3[ly][lx] = v;
+  }
+  if (a.levels < 4) return;
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int lx = threadIdx.x & 1, ly = threadIdx.x >> 1;
+    const int x = blockIdx.x * 2 + lx, y = blockIdx.y * 2 + ly;
+    uint32_t v = 0u;
+    if (x < a.dst[3].w && y < a.dst[3].h) {
+      v = min4(s_l3[2 * ly][2 * lx], s_l3[2 * ly][2 * lx + 1], s_l3[2 * ly + 1][2 * lx], s_l3[2 * ly + 1][2 * lx + 1]);
+      *texel_ptr<uint32_t>(a.dst[3], x, y) = v;
+    }
+    s_l4[ly][lx] = v;
+  }
+  if (a.levels < 5) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int x = blockIdx.x, y = blockIdx.y;
+    if (x < a.dst[4].w && y < a.dst[4].h)
+      *texel_ptr<uint32_t>(a.dst[4], x, y) = min4(s_l4[0][0], s_l4[0][1], s_l4[1][0], s_l4[1][1]);
+  }
 }
 
 }  // namespace vkr
@@ -103,13 +170,17 @@ extern "C" int vkr_downsample_gbuffer(const vkr_img* depth, const vkr_img* norma
 
 extern "C" int vkr_depth_mips(const vkr_img* depth, uint32_t src_mip, void* stream) {
   if (!depth) { set_error("depth_mips: NULL image"); return VKR_ERR_NULL; }
-  for (uint32_t i = src_mip + 1; i < depth->mip_count; i++) {
-    Tex src, dst;
-    VKR_TRY(make_tex(depth, (int)i - 1, VKR_FMT_D24_UNORM_S8, "depth_mips.src", &src));
-    VKR_TRY(make_tex(depth, (int)i, VKR_FMT_D24_UNORM_S8, "depth_mips.dst", &dst));
-    if (src.pitch % 8 != 0 || (uintptr_t)src.p % 8 != 0) { set_error("depth_mips: rows must be 8-byte aligned"); return VKR_ERR_LAYOUT; }
-    dim3 block(64, 4);
-    hipLaunchKernelGGL(k_depth_mip, grid2d(dst.w, dst.h, block), block, 0, (hipStream_t)stream, src, dst);
+  if (depth->mip_count > VKR_MAX_MIPS) { set_error("depth_mips: bad mip count"); return VKR_ERR_MIPS; }
+  for (uint32_t s = src_mip; s + 1 < depth->mip_count; s += FUSED_LEVELS) {
+    MipChainArgs a;
+    VKR_TRY(make_tex(depth, (int)s, VKR_FMT_D24_UNORM_S8, "depth_mips.src", &a.src));
+    if (a.src.pitch % 8 != 0 || (uintptr_t)a.src.p % 8 != 0) { set_error("depth_mips: rows must be 8-byte aligned"); return VKR_ERR_LAYOUT; }
+    a.levels = (int)std::min<uint32_t>(FUSED_LEVELS, depth->mip_count - 1 - s);
+    for (int k = 0; k < FUSED_LEVELS; k++)
+      VKR_TRY(make_tex(depth, (int)s + 1 + (k < a.levels ? k : a.levels - 1), VKR_FMT_D24_UNORM_S8, "depth_mips.dst", &a.dst[k]));
+    // one workgroup per 32x32 source block; level-1 extent decides the grid
+    dim3 grid((a.dst[0].w + 15) / 16, (a.dst[0].h + 15) / 16);
+    hipLaunchKernelGGL(k_depth_mips_fused, grid, dim3(256), 0, (hipStream_t)stream, a);
     VKR_TRY(launch_status("depth_mips"));
   }
   return VKR_OK;

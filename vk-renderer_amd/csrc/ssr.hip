@@ -163,8 +163,10 @@ __global__ __launch_bounds__(256) void k_sssr_trace(TraceArgs a) {
       const uint4 m = s_mip[current_mip];
       const int tx = f2i(mip_pos.x), ty = f2i(mip_pos.y);
       if (tx >= 0 && ty >= 0 && tx < (int)(m.w & 0xFFFFu) && ty < (int)(m.w >> 16)) {
-        const uint8_t* row = (const uint8_t*)(((uint64_t)m.y << 32) | m.x) + (size_t)ty * m.z;
-        surface_z = d24_to_float(((const uint32_t*)row)[tx]);
+        // the table holds plain integers: tell the compiler this is a global (not flat) address
+        typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
+        const uint64_t addr = (((uint64_t)m.y << 32) | m.x) + (uint64_t)ty * m.z + (uint64_t)tx * 4u;
+        surface_z = d24_to_float(*(gptr_t)addr);
       }
     }
     // advance_ray (screen_trace.glsl:17-45)
@@ -245,26 +247,28 @@ struct FilterArgs {
   uint32_t render_flags;
 };
 
-__global__ __launch_bounds__(256) void k_sssr_filter(FilterArgs a) {
+// Everything process_pixel() derives from the *tap* pixel alone (its ray, depth, normal, hit colour:
+// filter.comp:112-134 and the Fresnel power term / N.L / N.V of ray_weight :97-103) is computed once
+// per pixel into an LDS tile with a one-pixel apron; the five cross taps of every centre then only
+// combine those with the centre's F0 / roughness / depth.  Same operations in the same order as the
+// shader, each evaluated once instead of five times.
+#define FILT_BX 32
+#define FILT_BY 8
+#define FILT_TW (FILT_BX + 2)
+#define FILT_TH (FILT_BY + 2)
+
+__global__ __launch_bounds__(FILT_BX * FILT_BY) void k_sssr_filter(FilterArgs a) {
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
-  srgb_lut_stage(s_lut, threadIdx.y * blockDim.x + threadIdx.x, 256);
+  __shared__ float4 s_geo[FILT_TW * FILT_TH];  // {fresnel power term, NdotL, NdotV, depth}
+  __shared__ float4 s_rad[FILT_TW * FILT_TH];  // radiance rgb
+  const int tid = threadIdx.y * FILT_BX + threadIdx.x;
+  srgb_lut_stage(s_lut, tid, FILT_BX * FILT_BY);
   __syncthreads();
-  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
-  if (lx >= a.out.w || ly >= a.out.h) return;
-  const int gx = a.out.ox + lx, gy = a.out.oy + ly;
+
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
-  const f2 screen_uv = mk2((float)gx / tex_size.x, (float)gy / tex_size.y);  // no +0.5 (filter.comp:39)
-  const float metallic = sample_srgb_channel(a.material, screen_uv, 2, s_lut);
-  const float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
-  const f3 albedo = sample_srgb_rgb(a.albedo, screen_uv, s_lut);
-  const f3 F0 = F0_approximation(albedo, metallic);
-  f3 color_sum = mk3(0, 0, 0), weight_sum = mk3(0, 0, 0);
-  const float center_depth = fetch<FmtD24>(a.depth1, gx, gy);
-  const int taps = (a.render_flags & VKR_NORMALIZE_REFLECTIONS) ? 5 : 1;
-  const int offs[5][2] = {{0, 0}, {-1, 0}, {0, 1}, {1, 0}, {0, -1}};
-  for (int k = 0; k < taps; k++) {
-    const int px = gx + offs[k][0], py = gy + offs[k][1];
+  const int bx0 = a.out.ox + blockIdx.x * FILT_BX - 1, by0 = a.out.oy + blockIdx.y * FILT_BY - 1;
+  for (int t = tid; t < FILT_TW * FILT_TH; t += FILT_BX * FILT_BY) {
+    const int px = bx0 + t % FILT_TW, py = by0 + t / FILT_TW;
     const f4 trace_result = fetch<FmtRGBA16U>(a.rays, px, py);
     const f2 pixel_uv = mk2((float)px / tex_size.x, (float)py / tex_size.y);
     const float pixel_depth = fetch<FmtD24>(a.depth1, px, py);
@@ -275,20 +279,46 @@ __global__ __launch_bounds__(256) void k_sssr_filter(FilterArgs a) {
     const f3 radiance = (trace_result.w != 1.0f) ? sample_srgb_rgb(a.albedo, mk2(trace_result.x, trace_result.y), s_lut) : mk3(0, 0, 0);
     const f3 V = -normalize(view_vec);
     const f3 L = normalize(hit_vec - view_vec);
-    // ray_weight (filter.comp:97-108), literal swapped argument order of brdfG1
     const f3 H = normalize(V + L);
-    const f3 F = fresnelSchlick(vmax(dot(H, V), 0.0f), F0);
-    const float alpha2 = roughness * roughness;
-    const float NdotL = vmax(dot(Nn, L), 0.0f), NdotV = vmax(dot(Nn, V), 0.0f);
-    const float G2 = brdfG2(NdotL, NdotV, alpha2);
-    const float G1 = brdfG1(NdotV, alpha2);
-    f3 weight = (F * G2) / G1;
-    float bilateral_weight = 1.0f;
-    if (a.render_flags & VKR_BILATERAL_FILTER)
-      bilateral_weight = vmax(1.0f - (1000.0f * fabsf(center_depth - pixel_depth)) / center_depth, 0.0f);
-    weight = weight * bilateral_weight;
-    color_sum = color_sum + weight * radiance;
-    weight_sum = weight_sum + weight;
+    const float p5 = powf(vclamp(1.0f - vmax(dot(H, V), 0.0f), 0.0f, 1.0f), 5.0f);  // fresnelSchlick's power term
+    s_geo[t] = make_float4(p5, vmax(dot(Nn, L), 0.0f), vmax(dot(Nn, V), 0.0f), pixel_depth);
+    s_rad[t] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+  }
+  __syncthreads();
+
+  const int lx = blockIdx.x * FILT_BX + threadIdx.x;
+  const int ly = blockIdx.y * FILT_BY + threadIdx.y;
+  if (lx >= a.out.w || ly >= a.out.h) return;
+  const int gx = a.out.ox + lx, gy = a.out.oy + ly;
+  const f2 screen_uv = mk2((float)gx / tex_size.x, (float)gy / tex_size.y);  // no +0.5 (filter.comp:39)
+  const float metallic = sample_srgb_channel(a.material, screen_uv, 2, s_lut);
+  const float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
+  const f3 albedo = sample_srgb_rgb(a.albedo, screen_uv, s_lut);
+  const f3 F0 = F0_approximation(albedo, metallic);
+  const f3 one_minus_F0 = mk3(1.0f, 1.0f, 1.0f) - F0;
+  const float alpha2 = roughness * roughness;
+  f3 color_sum = mk3(0, 0, 0), weight_sum = mk3(0, 0, 0);
+  const int tc = (threadIdx.y + 1) * FILT_TW + (threadIdx.x + 1);
+  const float center_depth = s_geo[tc].w;
+  const int taps = (a.render_flags & VKR_NORMALIZE_REFLECTIONS) ? 5 : 1;
+  const int offs[5] = {0, -1, FILT_TW, 1, -FILT_TW};  // (0,0) (-1,0) (0,1) (1,0) (0,-1): filter.comp:62-68
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    if (k < taps) {
+      const float4 geo = s_geo[tc + offs[k]];
+      const float4 rad = s_rad[tc + offs[k]];
+      // ray_weight (filter.comp:97-108), literal swapped argument order of brdfG1
+      const f3 F = F0 + one_minus_F0 * geo.x;
+      const float G2 = brdfG2(geo.y, geo.z, alpha2);
+      const float G1 = brdfG1(geo.z, alpha2);
+      f3 weight = (F * G2) / G1;
+      float bilateral_weight = 1.0f;
+      if (a.render_flags & VKR_BILATERAL_FILTER)
+        bilateral_weight = vmax(1.0f - (1000.0f * fabsf(center_depth - geo.w)) / center_depth, 0.0f);
+      weight = weight * bilateral_weight;
+      color_sum = color_sum + weight * mk3(rad.x, rad.y, rad.z);
+      weight_sum = weight_sum + weight;
+    }
   }
   if (vmax(weight_sum.x, vmax(weight_sum.y, weight_sum.z)) < 0.001f) weight_sum = mk3(1, 1, 1);
   color_sum = color_sum / weight_sum;
@@ -317,9 +347,10 @@ struct BlurArgs {
 #define BLUR_TH (BLUR_BY + 2 * BLUR_R)
 
 __global__ __launch_bounds__(BLUR_BX * BLUR_BY) void k_sssr_blur(BlurArgs a) {
-  __shared__ float s_depth[BLUR_TH * BLUR_TW];
-  __shared__ float s_nx[BLUR_TH * BLUR_TW], s_ny[BLUR_TH * BLUR_TW], s_nz[BLUR_TH * BLUR_TW];
-  __shared__ float s_r[BLUR_TH * BLUR_TW], s_g[BLUR_TH * BLUR_TW], s_b[BLUR_TH * BLUR_TW];
+  // staged tile, one float4 {normal.xyz, depth} + one packed RGBA8 reflection texel per pixel:
+  // a tap is one ds_read_b128 + one ds_read_b32 (the kernel is LDS-issue bound)
+  __shared__ float4 s_nd[BLUR_TH * BLUR_TW];
+  __shared__ uint32_t s_refl[BLUR_TH * BLUR_TW];
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   srgb_lut_stage(s_lut, threadIdx.y * BLUR_BX + threadIdx.x, BLUR_BX * BLUR_BY);
 
@@ -331,11 +362,11 @@ __global__ __launch_bounds__(BLUR_BX * BLUR_BY) void k_sssr_blur(BlurArgs a) {
     const int tx = t % BLUR_TW, ty = t / BLUR_TW;
     const int px = bx0 + tx, py = by0 + ty;
     const f2 uv = mk2((float)px / tex_size.x, (float)py / tex_size.y);
-    s_depth[t] = fetch<FmtD24>(a.depth1, px, py);
     const f3 n = decode_normal(sample<FmtRG16U>(a.normal, uv));
-    s_nx[t] = n.x; s_ny[t] = n.y; s_nz[t] = n.z;
-    const f3 c = fetch<FmtRGBA8>(a.refl, px, py);
-    s_r[t] = c.x; s_g[t] = c.y; s_b[t] = c.z;
+    s_nd[t] = make_float4(n.x, n.y, n.z, fetch<FmtD24>(a.depth1, px, py));
+    // texelFetch out of the frame -> 0
+    const bool inside = px >= 0 && py >= 0 && px < a.refl.fw && py < a.refl.fh;
+    s_refl[t] = inside ? *texel_ptr<const uint32_t>(a.refl, iclamp(px - a.refl.ox, 0, a.refl.w - 1), iclamp(py - a.refl.oy, 0, a.refl.h - 1)) : 0u;
   }
   __syncthreads();
 
@@ -347,35 +378,80 @@ __global__ __launch_bounds__(BLUR_BX * BLUR_BY) void k_sssr_blur(BlurArgs a) {
   float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
   roughness = mixf(0.0f, a.max_roughness, roughness);
   const int tc = (threadIdx.y + BLUR_R) * BLUR_TW + (threadIdx.x + BLUR_R);
-  const float center_depth = s_depth[tc];
+  const float center_depth = s_nd[tc].w;
   const f3 center_normal = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
   float sigma = mixf(0.4f, 4.0f, roughness);
   if (a.disable_blur != 0) sigma = 0.35f;
-  float weight_sum = 0.0f;
-  f3 color = mk3(0, 0, 0);
   const int r = min(f2i(floorf(3.0f * sigma - 0.01f)), BLUR_R);
   const float g = 1.0f / (((2.0f * VKR_PI) * sigma) * sigma);
   const float e = (2.0f * sigma) * sigma;
-  // smooth weights: reciprocal-multiply and the hardware exp2 are within ~1e-6 of the reference
-  // formula, far inside the 1e-3 / one-UNORM8-step tolerance; summation order is the shader's
-  const float neg_inv_e_log2 = -1.4426950408889634f / e;
+  // The tap weights are smooth functions, so this loop is free to differ from the shader's
+  // evaluation order by rounding noise (~1e-6, against a 1e-3 / one-UNORM8-step tolerance):
+  //  * exp(-(i^2+j^2)/e) = E[|i|] * E[|j|] with E[k+1] = E[k] * q_k, q_{k+1} = q_k * exp(-2/e):
+  //    two hardware exp2 per pixel instead of one per tap;
+  //  * the four taps (+-i, +-j) share one Gaussian weight and are processed as two packed pairs
+  //    (v_pk_fma_f32 / v_pk_mul_f32: two taps per instruction);
+  //  * colour is accumulated in UNORM8 code units and scaled by 1/255 once.
+  typedef float v2f __attribute__((ext_vector_type(2)));
   const float k_bilateral = 1000.0f / center_depth;
+  const float q0 = __builtin_amdgcn_exp2f(-1.4426950408889634f / e);  // exp(-1/e)
+  const float kq = q0 * q0;                                           // exp(-2/e)
+  v2f acc_r = {0.0f, 0.0f}, acc_g = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f}, acc_w = {0.0f, 0.0f};
+  const v2f cnx = {center_normal.x, center_normal.x}, cny = {center_normal.y, center_normal.y}, cnz = {center_normal.z, center_normal.z};
+  const v2f cd2 = {center_depth, center_depth}, kb2 = {k_bilateral, k_bilateral}, one2 = {1.0f, 1.0f};
+  // two taps ta, tb sharing the Gaussian weight wg
+  auto tap_pair = [&](int ta, int tb, float wg) {
+    const float4 na = s_nd[ta], nb = s_nd[tb];
+    const uint32_t ca = s_refl[ta], cb = s_refl[tb];
+    const v2f dz = cd2 - (v2f){na.w, nb.w};
+    v2f bil = __builtin_elementwise_fma(-__builtin_elementwise_abs(dz), kb2, one2);
+    v2f nw = __builtin_elementwise_fma(cnz, (v2f){na.z, nb.z}, __builtin_elementwise_fma(cny, (v2f){na.y, nb.y}, cnx * (v2f){na.x, nb.x}));
+    bil = __builtin_elementwise_max(bil, (v2f){0.0f, 0.0f});
+    nw = __builtin_elementwise_max(nw, (v2f){0.0f, 0.0f});
+    const v2f w = (v2f){wg, wg} * bil * nw;
+    acc_r = __builtin_elementwise_fma(w, (v2f){(float)(ca & 0xFFu), (float)(cb & 0xFFu)}, acc_r);
+    acc_g = __builtin_elementwise_fma(w, (v2f){(float)((ca >> 8) & 0xFFu), (float)((cb >> 8) & 0xFFu)}, acc_g);
+    acc_b = __builtin_elementwise_fma(w, (v2f){(float)((ca >> 16) & 0xFFu), (float)((cb >> 16) & 0xFFu)}, acc_b);
+    acc_w += w;
+  };
+  {  // centre tap: bilateral weight 1, normal weight |n|^2-ish (dot of the two decodes)
+    const float4 nc = s_nd[tc];
+    const uint32_t cc = s_refl[tc];
+    const float nw = vmax((center_normal.x * nc.x + center_normal.y * nc.y) + center_normal.z * nc.z, 0.0f);
+    const float w = g * nw;  // |cd - cd| = 0 -> bilateral 1
+    acc_r.x = w * (float)(cc & 0xFFu); acc_g.x = w * (float)((cc >> 8) & 0xFFu); acc_b.x = w * (float)((cc >> 16) & 0xFFu);
+    acc_w.x = w;
+  }
+  {  // the two axes: (+-k, 0) and (0, +-k)
+    float ek = 1.0f, q = q0;
 #pragma unroll 1
-  for (int i = -r; i <= r; i++) {
-    const int col = tc + i;
-#pragma unroll 1
-    for (int j = -r; j <= r; j++) {
-      const int t = col + j * BLUR_TW;
-      const float pixel_depth = s_depth[t];
-      const float bilateral_weight = vmax(1.0f - fabsf(center_depth - pixel_depth) * k_bilateral, 0.0f);
-      const float normal_weight = vmax((center_normal.x * s_nx[t] + center_normal.y * s_ny[t]) + center_normal.z * s_nz[t], 0.0f);
-      float w = g * __builtin_amdgcn_exp2f((float)(i * i + j * j) * neg_inv_e_log2);
-      w *= bilateral_weight;
-      w *= normal_weight;
-      color = color + mk3(s_r[t], s_g[t], s_b[t]) * w;
-      weight_sum += w;
+    for (int k = 1; k <= r; k++) {
+      ek *= q; q *= kq;  // ek = exp(-k^2/e)
+      const float wg = g * ek;
+      tap_pair(tc - k, tc + k, wg);
+      tap_pair(tc - k * BLUR_TW, tc + k * BLUR_TW, wg);
     }
   }
+  {  // the four quadrants: (+-i, +-j), i, j >= 1
+    float ei = 1.0f, qi = q0;
+#pragma unroll 1
+    for (int i = 1; i <= r; i++) {
+      ei *= qi; qi *= kq;
+      const float gi = g * ei;
+      float ej = 1.0f, qj = q0;
+#pragma unroll 1
+      for (int j = 1; j <= r; j++) {
+        ej *= qj; qj *= kq;
+        const float wg = gi * ej;
+        const int up = tc - j * BLUR_TW, dn = tc + j * BLUR_TW;
+        tap_pair(up - i, up + i, wg);
+        tap_pair(dn - i, dn + i, wg);
+      }
+    }
+  }
+  float weight_sum = acc_w.x + acc_w.y;
+  f3 color = mk3(acc_r.x + acc_r.y, acc_g.x + acc_g.y, acc_b.x + acc_b.y);
+  color = color * (1.0f / 255.0f);
   color = color / vmax(weight_sum, 0.001f);
 
   bool reprojected = false;
@@ -467,7 +543,7 @@ extern "C" int vkr_sssr_filter(const vkr_img* rays, const vkr_img* depth, const 
   load_mat(a.normal_mat, params->normal_mat);
   load_proj(a.pr, params->fovy, params->aspect, params->znear, params->zfar);
   a.render_flags = push->render_flags;
-  dim3 block(64, 4);
+  dim3 block(FILT_BX, FILT_BY);
   hipLaunchKernelGGL(k_sssr_filter, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_filter");
 }

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <stdexcept>
+#include <vector>
 
 DownsamplePass::DownsamplePass() : sampler {gpu::create_sampler(gpu::DEFAULT_SAMPLER)} {
   gpu::Registers always_write {};
@@ -74,32 +75,41 @@ void DownsamplePass::run_downsample_gbuff(rendergraph::RenderGraph &graph, rende
     });
 }
 
+// downsample_pass.cpp:94-131 records one "DownsampleDepth" draw per mip (L-2 dependent passes).
+// MI355X-first: the same chain is one task whose attachments are all remaining mips; the bound
+// program reduces five levels per workgroup through LDS.  Each mip is still the 2x2 min of its
+// parent with extent max(1, W >> i) (:118-120).
 void DownsamplePass::run_downsample_depth(rendergraph::RenderGraph &graph, rendergraph::ImageResourceId depth, uint32_t src_mip) {
   const auto desc = graph.get_descriptor(depth);
+  if (src_mip + 1 >= desc.mip_levels) return;
   downsample_depth.set_rendersubpass({true, {desc.format}});
 
-  struct Input { rendergraph::ImageViewId depth_tex, depth_rt; };
+  struct Input {
+    rendergraph::ImageViewId depth_tex;
+    std::vector<rendergraph::ImageViewId> depth_rt;
+  };
 
-  for (uint32_t mip = src_mip + 1; mip < desc.mip_levels; mip++) {
-    graph.add_task<Input>("DownsampleDepth",
-      [&](Input &in, rendergraph::RenderGraphBuilder &builder) {
-        in.depth_rt = builder.use_depth_attachment(depth, mip, 0);
-        in.depth_tex = builder.sample_image(depth, VK_SHADER_STAGE_FRAGMENT_BIT, VK_IMAGE_ASPECT_DEPTH_BIT, mip - 1, 1, 0, 1);
-      },
-      [=](Input &in, rendergraph::RenderResources &resources, gpu::CmdContext &cmd) {
-        auto set = resources.allocate_set(downsample_depth, 0);
-        gpu::write_set(set, gpu::TextureBinding {0, resources.get_view(in.depth_tex), sampler});
+  graph.add_task<Input>("DownsampleDepth",
+    [&](Input &in, rendergraph::RenderGraphBuilder &builder) {
+      in.depth_tex = builder.sample_image(depth, VK_SHADER_STAGE_FRAGMENT_BIT, VK_IMAGE_ASPECT_DEPTH_BIT, src_mip, 1, 0, 1);
+      for (uint32_t mip = src_mip + 1; mip < desc.mip_levels; mip++)
+        in.depth_rt.push_back(builder.use_depth_attachment(depth, mip, 0));
+    },
+    [=](Input &in, rendergraph::RenderResources &resources, gpu::CmdContext &cmd) {
+      auto set = resources.allocate_set(downsample_depth, 0);
+      gpu::write_set(set, gpu::TextureBinding {0, resources.get_view(in.depth_tex), sampler});
 
-        const uint32_t w = std::max(desc.width >> mip, 1u), h = std::max(desc.height >> mip, 1u);
-        cmd.set_framebuffer(w, h, {resources.get_image_range(in.depth_rt)});
-        cmd.bind_pipeline(downsample_depth);
-        cmd.bind_descriptors_graphics(0, {set});
-        cmd.bind_viewport(0.f, 0.f, float(w), float(h), 0.f, 1.f);
-        cmd.bind_scissors(0, 0, w, h);
-        cmd.draw(3, 1, 0, 0);
-        cmd.end_renderpass();
-      });
-  }
+      std::vector<gpu::ImageViewObject> targets;
+      for (const auto &rt : in.depth_rt) targets.push_back(resources.get_image_range(rt));
+      const uint32_t w = std::max(desc.width >> (src_mip + 1), 1u), h = std::max(desc.height >> (src_mip + 1), 1u);
+      cmd.set_framebuffer(w, h, targets);
+      cmd.bind_pipeline(downsample_depth);
+      cmd.bind_descriptors_graphics(0, {set});
+      cmd.bind_viewport(0.f, 0.f, float(w), float(h), 0.f, 1.f);
+      cmd.bind_scissors(0, 0, w, h);
+      cmd.draw(3, 1, 0, 0);
+      cmd.end_renderpass();
+    });
 }
 
 void DownsamplePass::run(rendergraph::RenderGraph &graph, rendergraph::ImageResourceId src_normals, rendergraph::ImageResourceId src_velocity,

@@ -202,14 +202,19 @@ void register_hot_path_programs() {
       vkr_img ov = st.attachments[1].image->describe(st.attachments[1].range.base_mip, 1);
       return vkr_downsample_gbuffer(&depth, &n, &v, &on, &ov, st.stream);
     });
-    // advanced_ssr/depth_mips.frag: set {0 depth mip i-1}; attachment {depth mip i}
+    // advanced_ssr/depth_mips.frag: set {0 depth mip i-1}; attachments {depth mip i, i+1, ...}.
+    // The reference draws once per mip; bound with several consecutive mips the fused kernel
+    // builds the whole run in one go (each mip still the 2x2 min of its parent).
     create_program("depth_mips", [=](LaunchState& st) {
       const SetSlot& ds = st.set->slots[0];
-      if (st.attachments.size() != 1) throw std::runtime_error{"depth_mips: expects one depth attachment"};
-      const ImageViewObject& dout = st.attachments[0];
-      if (ds.kind != T || ds.view.image != dout.image || dout.range.base_mip != ds.view.range.base_mip + 1)
-        throw std::runtime_error{"depth_mips: attachment must be the next mip of the sampled depth"};
-      vkr_img depth = ds.view.image->describe(ds.view.range.base_mip, 2);
+      if (st.attachments.empty()) throw std::runtime_error{"depth_mips: expects at least one depth attachment"};
+      if (ds.kind != T) throw std::runtime_error{"depth_mips: binding 0 is not bound as expected"};
+      for (size_t i = 0; i < st.attachments.size(); i++) {
+        const ImageViewObject& dout = st.attachments[i];
+        if (ds.view.image != dout.image || dout.range.base_mip != ds.view.range.base_mip + 1 + i)
+          throw std::runtime_error{"depth_mips: attachments must be the consecutive mips after the sampled depth"};
+      }
+      vkr_img depth = ds.view.image->describe(ds.view.range.base_mip, 1 + (uint32_t)st.attachments.size());
       return vkr_depth_mips(&depth, 0, st.stream);
     });
     create_program("pdf_preintegrate", [=](LaunchState& st) {
@@ -311,6 +316,10 @@ void CmdContext::push_constants_compute(uint32_t offset, uint32_t size, const vo
 void CmdContext::set_framebuffer(uint32_t width, uint32_t height, const std::initializer_list<ImageViewObject>& attachments) {
   state.fb_width = width; state.fb_height = height;
   state.attachments.assign(attachments.begin(), attachments.end());
+}
+void CmdContext::set_framebuffer(uint32_t width, uint32_t height, const std::vector<ImageViewObject>& attachments) {
+  state.fb_width = width; state.fb_height = height;
+  state.attachments = attachments;
 }
 void CmdContext::launch() {
   if (!bound_program) throw std::runtime_error{"No pipeline bound"};

@@ -226,6 +226,7 @@ struct CmdContext {
   void push_constants_compute(uint32_t offset, uint32_t size, const void* constants);
   void push_constants_graphics(VkShaderStageFlags, uint32_t offset, uint32_t size, const void* constants) { push_constants_compute(offset, size, constants); }
   void set_framebuffer(uint32_t width, uint32_t height, const std::initializer_list<ImageViewObject>& attachments);
+  void set_framebuffer(uint32_t width, uint32_t height, const std::vector<ImageViewObject>& attachments);
   void bind_viewport(float, float, float, float, float, float) {}
   void bind_scissors(int32_t, int32_t, uint32_t, uint32_t) {}
   void end_renderpass() { state.attachments.clear(); }
