@@ -58,3 +58,6 @@ int vkr_ref_hierarchical_raymarch(const vkr_img* depth, const float* origin3, co
 }
 
 }  // extern "C"
+
+// gtao_direction (main.comp:276-278) for the known-answer table of SURVEY.md 8(c)(4)
+extern "C" float vkr_ref_gtao_direction(int x, int y) { return (1.0f / 16.0f) * (float)((((x + y) & 3) << 2) + (x & 3)); }

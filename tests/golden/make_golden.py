@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/chain_256x144.npz from the CPU oracle (the reference ships no golden
+vectors and cannot run here, SURVEY.md 8(c), so these are self-generated pins: they freeze the
+oracle's behaviour, they do not prove it equals the reference's).
+
+Content: for the frozen frame setup (camera.FrameSetup defaults, SEED 0x5EED0001) at 256x144,
+two frames of the chain with history ping-pong; per image a SHA-256 of the raw storage bytes of
+every mip and a 24x16 crop of raw storage values around the image centre.
+
+Run from the repository root:  python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import vk_renderer_amd  # noqa: E402,F401
+from vk_renderer_amd.chain import PostFxChain  # noqa: E402
+
+W, H = 256, 144
+IMAGES = ("depth", "prev_depth", "normal", "albedo", "material", "velocity", "dn", "dv", "rays", "raw", "reflections", "filtered",
+          "blurred_hist", "acc_hist", "taa_hist")
+
+
+def run_chain(backend="oracle", device=None):
+    c = PostFxChain(W, H, backend=backend, device=device)
+    c.synth()
+    c.build_prev_hiz()
+    c.init_histories()
+    c.preintegrate_pdf()
+    for _ in range(2):
+        c.frame()
+        c.swap_histories()
+    c.sync()
+    return c
+
+
+def digest(img):
+    host = img.to_host()
+    out = []
+    for m in range(img.mips):
+        raw = np.ascontiguousarray(img.raw(m, host))
+        if img.format == 1:  # D24: stencil bits are not part of the contract
+            raw = raw & 0xFFFFFF
+        out.append(hashlib.sha256(raw.tobytes()).hexdigest())
+    return out
+
+
+def crop(img):
+    raw = img.raw(0)
+    cy, cx = raw.shape[0] // 2, raw.shape[1] // 2
+    return np.ascontiguousarray(raw[cy - 8:cy + 8, cx - 12:cx + 12])
+
+
+def main():
+    c = run_chain()
+    data = {}
+    for name in IMAGES:
+        img = getattr(c, name)
+        data[name + "__sha256"] = np.array(digest(img))
+        data[name + "__crop"] = crop(img)
+    data["pdf__spot"] = c.pdf.decode()[[100, 512, 900], :, 0][:, [100, 512, 900]]
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "chain_256x144.npz")
+    np.savez_compressed(out, **data)
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()

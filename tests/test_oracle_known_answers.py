@@ -1,0 +1,298 @@
+"""Known-answer tests that pin the oracle.  The reference ships no tests,
+goldens or runnable CPU path, so these analytic identities are what stands between the restatement
+and a silent transcription error."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from vk_renderer_amd import abi
+from vk_renderer_amd.camera import FOVY, ZFAR, ZNEAR, FrameSetup
+from vk_renderer_amd.chain import PostFxChain
+from vk_renderer_amd.images import ImageBuf
+
+F3 = C.c_float * 3
+F2 = C.c_float * 2
+
+
+def _typed(l):
+    l.vkr_ref_linearize_depth2.restype = C.c_float
+    l.vkr_ref_linearize_depth2.argtypes = [C.c_float] * 3
+    l.vkr_ref_encode_depth.restype = C.c_float
+    l.vkr_ref_encode_depth.argtypes = [C.c_float] * 3
+    l.vkr_ref_gtao_direction.restype = C.c_float
+    l.vkr_ref_gtao_direction.argtypes = [C.c_int, C.c_int]
+    l.vkr_ref_reconstruct_view_vec.argtypes = [F2, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, F3]
+    l.vkr_ref_project_view_vec.argtypes = [F3, C.c_float, C.c_float, C.c_float, C.c_float, F3]
+    l.vkr_ref_encode_normal.argtypes = [F3, F2]
+    l.vkr_ref_decode_normal.argtypes = [F2, F3]
+    return l
+
+
+@pytest.fixture(scope="module")
+def lib(oracle_lib):
+    return _typed(oracle_lib)
+
+
+# (1) depth / projection round trips ---------------------------------------------------------------
+def test_depth_roundtrip(lib):
+    for z in (-0.05, -0.06, -0.5, -1.0, -3.7, -12.0, -79.9, -80.0):
+        d = lib.vkr_ref_encode_depth(z, ZNEAR, ZFAR)
+        assert 0.0 <= d <= 1.0 + 1e-6
+        back = lib.vkr_ref_linearize_depth2(d, ZNEAR, ZFAR)
+        assert back == pytest.approx(z, rel=2e-3 if z < -40 else 2e-4)  # fp32 cancellation grows towards zfar
+    assert lib.vkr_ref_linearize_depth2(0.0, ZNEAR, ZFAR) == pytest.approx(-ZNEAR)
+    assert lib.vkr_ref_linearize_depth2(1.0, ZNEAR, ZFAR) == pytest.approx(-ZFAR, rel=2e-4)  # fp32: d*(f-n) - f cancels
+
+
+def test_project_reconstruct_roundtrip(lib):
+    aspect = 16.0 / 9.0
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        u, v = rng.uniform(0.02, 0.98, 2)
+        d = float(rng.uniform(0.2, 0.999))
+        out = F3()
+        lib.vkr_ref_reconstruct_view_vec(F2(u, v), d, FOVY, aspect, ZNEAR, ZFAR, out)
+        assert out[2] < 0  # view-space z is negative (gbuffer_encode.glsl:53-56)
+        back = F3()
+        lib.vkr_ref_project_view_vec(F3(*out), FOVY, aspect, ZNEAR, ZFAR, back)
+        assert back[0] == pytest.approx(u, abs=2e-6) and back[1] == pytest.approx(v, abs=2e-6)
+        assert back[2] == pytest.approx(d, abs=2e-6)
+
+
+# (2) octahedral normals -----------------------------------------------------------------------------
+def test_normal_roundtrip_including_negative_z(lib):
+    rng = np.random.default_rng(3)
+    vecs = rng.normal(size=(500, 3))
+    vecs /= np.linalg.norm(vecs, axis=1, keepdims=True)
+    vecs = np.vstack([vecs, [[0, 0, 1], [0, 0, -1], [1, 0, 0], [0, -1, 0], [0.6, 0, -0.8]]])
+    for n in vecs:
+        e = F2()
+        lib.vkr_ref_encode_normal(F3(*[float(v) for v in n]), e)
+        assert 0.0 <= e[0] <= 1.0 and 0.0 <= e[1] <= 1.0
+        d = F3()
+        lib.vkr_ref_decode_normal(e, d)
+        assert np.allclose([d[0], d[1], d[2]], n, atol=3e-6)
+
+
+# (3) Halton(2,3) --------------------------------------------------------------------------------------
+def test_halton_first_elements(lib):
+    buf = (C.c_float * (4 * 128))()
+    lib.vkr_ref_halton23(buf, 128)
+    h = np.frombuffer(buf, dtype=np.float32).reshape(128, 4)
+    want = [(1 / 2, 1 / 3), (1 / 4, 2 / 3), (3 / 4, 1 / 9), (1 / 8, 4 / 9)]
+    for i, (a, b) in enumerate(want):
+        assert h[i, 0] == pytest.approx(a, rel=1e-6) and h[i, 1] == pytest.approx(b, rel=1e-6)
+    assert np.all(h[:, 2:] == 0) and np.all((h[:, :2] > 0) & (h[:, :2] < 1))
+    # the Python chain and the C++ host build the same table
+    c = PostFxChain(64, 32, backend="oracle")
+    assert np.array_equal(c.halton_host, h)
+
+
+# (4) slice direction pattern ---------------------------------------------------------------------------
+def test_gtao_direction_table(lib):
+    table = [[0, 5, 10, 15], [4, 9, 14, 3], [8, 13, 2, 7], [12, 1, 6, 11]]  # [y][x] * 16 (main.comp:276-278)
+    for y in range(8):
+        for x in range(8):
+            assert lib.vkr_ref_gtao_direction(x, y) == table[y % 4][x % 4] / 16.0
+
+
+# helpers --------------------------------------------------------------------------------------------------
+def _plane_chain(w=64, h=32, z_view=-4.0, use_mis=0, static_camera=False):
+    """G-buffer of a fronto-parallel plane at view depth z_view, normal facing the camera."""
+    kw = dict(prev_delta=(0.0, 0.0, 0.0), prev_yaw_delta=0.0) if static_camera else {}
+    setup = FrameSetup(w, h, use_mis=use_mis, **kw)
+    c = PostFxChain(w, h, backend="oracle", setup=setup)
+    _typed(abi.oracle())
+    d = float(abi.oracle().vkr_ref_encode_depth(z_view, ZNEAR, ZFAR))
+    d24 = np.uint32(round(d * 16777215.0))
+    c.depth.set_raw(np.full((h, w, 1), d24, dtype=np.uint32))
+    c.prev_depth.set_raw(np.full((h, w, 1), d24, dtype=np.uint32))
+    # world normal such that the view-space normal is (0,0,1): n_world = view^-1 rotation * (0,0,1)
+    n_world = setup.inv_view[:3, :3] @ np.array([0.0, 0.0, 1.0])
+    e = F2()
+    abi.oracle().vkr_ref_encode_normal(F3(*[float(v) for v in n_world]), e)
+    n16 = np.array([round(e[0] * 65535), round(e[1] * 65535)], dtype=np.uint16)
+    c.normal.set_raw(np.broadcast_to(n16, (h, w, 2)).copy())
+    mat = np.zeros((h, w, 4), dtype=np.uint8)
+    mat[..., 1] = 188  # sRGB code of roughness ~0.5
+    c.material.set_raw(mat)
+    alb = np.full((h, w, 4), 128, dtype=np.uint8)
+    c.albedo.set_raw(alb)
+    c.velocity.set_raw(np.zeros((h, w, 2), dtype=np.float16))
+    return c
+
+
+# (5) flat plane: no occluders ------------------------------------------------------------------------------
+def test_gtao_flat_plane_is_unoccluded():
+    """Fronto-parallel plane: every horizon sample lies in the plane, so nothing occludes.  One slice
+    direction per pixel (4x4 rotation pattern, main.comp:276-278) integrates only its own half-slice, whose
+    value swings around 1 with the tilt between view ray and plane normal; the mean over a 4x4 pattern
+    block is the full cosine-weighted visibility = 1, and at the screen centre (view ray = normal) every
+    single direction gives 1: h = pi/2, n = 0 -> 2 * 0.25 * (-cos(pi) + cos(0)) = 1."""
+    c = _plane_chain(256, 128)
+    c.downsample()
+    c.gtao_main()
+    ao = c.raw.decode()[..., 0]
+    inner = ao[8:-8, 16:-16]
+    h, w = inner.shape
+    blocks = inner.reshape(h // 4, 4, w // 4, 4).mean(axis=(1, 3))
+    assert blocks.min() > 0.93 and blocks.max() < 1.03, (blocks.min(), blocks.max())
+    cy, cx = ao.shape[0] // 2, ao.shape[1] // 2
+    assert np.all(np.abs(ao[cy - 2:cy + 2, cx - 2:cx + 2] - 1.0) < 0.06)
+    assert np.allclose(c.raw.decode()[..., 1], 1.0 / (2.0 * math.pi), rtol=1e-3)  # occlusion.y untouched in non-MIS mode
+
+
+def test_gtao_sky_pixels():
+    for mis, want in ((0, (0.0, 1.0 / (2.0 * math.pi))), (1, (0.0, 1.0))):
+        c = _plane_chain(use_mis=mis)
+        c.depth.set_raw(np.full((32, 64, 1), 0xFFFFFF, dtype=np.uint32))
+        c.downsample()
+        c.preintegrate_pdf() if mis else None
+        c.gtao_main()
+        out = c.raw.decode()
+        assert np.allclose(out[..., 0], want[0]) and np.allclose(out[..., 1], want[1], rtol=1e-3)
+
+
+# (6) Hi-Z ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("size", [(64, 32), (66, 38), (100, 36), (2, 2), (130, 2)])
+def test_hiz_every_mip_is_min_of_parents(size):
+    w, h = size
+    rng = np.random.default_rng(w * 1000 + h)
+    from vk_renderer_amd.images import depth_mip_count
+
+    L = depth_mip_count(w, h)
+    depth = ImageBuf(abi.FMT_D24_UNORM_S8, w, h, L)
+    depth.set_raw(rng.integers(0, 1 << 24, size=(h, w, 1), dtype=np.uint32))
+    n = ImageBuf(abi.FMT_RG16_UNORM, w, h)
+    n.set_raw(rng.integers(0, 1 << 16, size=(h, w, 2), dtype=np.uint16))
+    v = ImageBuf(abi.FMT_RG16_SFLOAT, w, h)
+    v.set_raw(rng.integers(0, 0x7BFF, size=(h, w, 2), dtype=np.uint16).view(np.float16))
+    dn = ImageBuf(abi.FMT_RG16_UNORM, max(1, w // 2), max(1, h // 2))
+    dv = ImageBuf(abi.FMT_RG16_SFLOAT, max(1, w // 2), max(1, h // 2))
+    lib = abi.oracle()
+    assert lib.vkr_ref_downsample_gbuffer(C.byref(depth.desc()), C.byref(n.desc()), C.byref(v.desc()), C.byref(dn.desc()), C.byref(dv.desc())) == 0
+    assert lib.vkr_ref_depth_mips(C.byref(depth.desc()), 1) == 0
+    for m in range(1, L):
+        p, q = depth.raw(m - 1)[..., 0] & 0xFFFFFF, depth.raw(m)[..., 0]
+        ph, pw = p.shape
+        for y in range(q.shape[0]):
+            for x in range(q.shape[1]):
+                vals = [int(p[yy, xx]) if (yy < ph and xx < pw) else 0 for yy in (2 * y, 2 * y + 1) for xx in (2 * x, 2 * x + 1)]
+                assert int(q[y, x]) == min(vals), (m, x, y)  # odd extents drop the last row/column; OOB fetch = 0
+    # downsampled normal / velocity come from the texel holding the minimum (first match d1, d2, d3 else d0)
+    d0 = depth.raw(0)[..., 0] & 0xFFFFFF
+    for y in range(dn.height):
+        for x in range(dn.width):
+            quad = [(0, 0), (1, 0), (0, 1), (1, 1)]
+            vals = [int(d0[2 * y + oy, 2 * x + ox]) for ox, oy in quad]
+            mn = min(vals)
+            pick = next((k for k in (1, 2, 3) if vals[k] == mn), 0)
+            ox, oy = quad[pick]
+            assert np.array_equal(dn.raw(0)[y, x], n.raw(0)[2 * y + oy, 2 * x + ox])
+            assert np.array_equal(dv.raw(0)[y, x].view(np.uint16), v.raw(0)[2 * y + oy, 2 * x + ox].view(np.uint16))
+
+
+def test_hiz_rejects_single_mip_and_mismatched_outputs():
+    lib = abi.oracle()
+    depth = ImageBuf(abi.FMT_D24_UNORM_S8, 16, 16, 1)
+    n, v = ImageBuf(abi.FMT_RG16_UNORM, 16, 16), ImageBuf(abi.FMT_RG16_SFLOAT, 16, 16)
+    dn, dv = ImageBuf(abi.FMT_RG16_UNORM, 8, 8), ImageBuf(abi.FMT_RG16_SFLOAT, 8, 8)
+    assert lib.vkr_ref_downsample_gbuffer(C.byref(depth.desc()), C.byref(n.desc()), C.byref(v.desc()), C.byref(dn.desc()), C.byref(dv.desc())) != 0
+    depth = ImageBuf(abi.FMT_D24_UNORM_S8, 16, 16, 3)
+    bad = ImageBuf(abi.FMT_RG16_UNORM, 4, 8)
+    assert lib.vkr_ref_downsample_gbuffer(C.byref(depth.desc()), C.byref(n.desc()), C.byref(v.desc()), C.byref(bad.desc()), C.byref(dv.desc())) != 0
+
+
+# (7) PDF LUT vs quadrature -----------------------------------------------------------------------------------------
+def test_pdf_lut_matches_quadrature():
+    from scipy import integrate
+
+    c = PostFxChain(64, 32, backend="oracle")
+    c.preintegrate_pdf()
+    lut = c.pdf.decode()[..., 0]
+
+    def G2(t, a, b):
+        L = (b - a) * t + (b + a)
+        return (1 - t) * L / (1 + t * t - 0.5 * L * L) ** 2 if L > 0 else 0.0
+
+    for (x, y) in [(512, 512), (100, 300), (900, 200), (512, 100), (300, 700)]:
+        a, b = 2 * (x + 0.5) / 1024 - 1, (y + 0.5) / 1024
+        val, _ = integrate.quad(G2, -1, 1, args=(a, b), limit=400, points=[-(b + a) / (b - a)] if abs(b - a) > 1e-9 and -1 < -(b + a) / (b - a) < 1 else None)
+        assert lut[y, x] == pytest.approx(val, rel=5e-3), (x, y)
+
+
+# (8) TAA ---------------------------------------------------------------------------------------------------------------
+def test_taa_static_scene_blends_one_tenth():
+    c = _plane_chain(use_mis=1, static_camera=True)
+    hist = np.zeros((32, 64, 4), dtype=np.float16)
+    hist[..., :3] = 0.25
+    c.taa_hist.set_raw(hist)
+    c.taa()
+    out = c.taa_target.decode()
+    cur = c.albedo.decode()[0, 0, 0]
+    assert np.allclose(out[..., :3], 0.9 * 0.25 + 0.1 * cur, rtol=2e-3)
+    assert np.all(out[..., 3] == 0)
+
+
+def test_taa_history_outside_screen_returns_current():
+    c = _plane_chain(use_mis=1)
+    c.velocity.set_raw(np.full((32, 64, 2), 2.0, dtype=np.float16))  # prev_uv = uv + 2 -> outside [0,1]
+    hist = np.zeros((32, 64, 4), dtype=np.float16)
+    hist[..., :3] = 0.9
+    c.taa_hist.set_raw(hist)
+    c.taa()
+    out = c.taa_target.decode()
+    cur = c.albedo.decode()[..., :3]
+    assert np.allclose(out[..., :3], cur.astype(np.float16).astype(np.float32), atol=1e-3)
+
+
+# (9) accumulate ---------------------------------------------------------------------------------------------------------
+def test_accumulate_clear_history_and_saturation():
+    c = _plane_chain(use_mis=1, static_camera=True)
+    c.downsample()
+    c.build_prev_hiz()
+    c.filtered.set_raw(np.full((16, 32, 1), 0.5, dtype=np.float16))
+    hist = np.zeros((16, 32, 2), dtype=np.float16)
+    hist[..., 0], hist[..., 1] = 0.25, 1.0  # 255 samples accumulated
+    c.acc_hist.set_raw(hist)
+    c.gtao_accumulate(clear_history=1)
+    out = c.acc_ao.decode()
+    assert np.allclose(out[..., 0], 0.5) and np.allclose(out[..., 1], 1.0 / 255.0, rtol=1e-3)
+    c.gtao_accumulate(clear_history=0)
+    out = c.acc_ao.decode()
+    # n = 255 * 1.0 * valid(=1) -> ao = (0.25*255 + 0.5)/256, n+1 = 256 > 255 -> stored count 100/255
+    assert np.allclose(out[..., 0], (0.25 * 255 + 0.5) / 256, rtol=2e-3)
+    assert np.allclose(out[..., 1], 100.0 / 255.0, rtol=1e-3)
+
+
+# (10) blur -----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rough_code", [0, 90, 188, 255])
+def test_blur_constant_input_is_identity(rough_code):
+    c = _plane_chain(use_mis=1)
+    mat = np.zeros((32, 64, 4), dtype=np.uint8)
+    mat[..., 1] = rough_code
+    c.material.set_raw(mat)
+    c.downsample()
+    c.build_prev_hiz()
+    refl = np.zeros((16, 32, 4), dtype=np.uint8)
+    refl[..., 0], refl[..., 1], refl[..., 2] = 200, 100, 50
+    c.reflections.set_raw(refl)
+    c.ssr_blur(accumulate=0)
+    out = c.blurred.raw(0)
+    r = int(math.floor(3 * (0.4 + 3.6 * c.material.decode()[0, 0, 1]) - 0.01))
+    inner = out[r:-r or None, r:-r or None] if 2 * r < 16 else out[0:0]
+    assert np.all(np.abs(inner[..., :3].astype(int) - np.array([200, 100, 50])) <= 1)
+
+
+# (11) filter ---------------------------------------------------------------------------------------------------------------
+def test_filter_all_rays_invalid_gives_zero():
+    c = _plane_chain(use_mis=1)
+    c.downsample()
+    rays = np.zeros((16, 32, 4), dtype=np.uint16)
+    rays[..., 0], rays[..., 1], rays[..., 2], rays[..., 3] = 30000, 30000, 60000, 65535  # w == 1.0 -> invalid
+    c.rays.set_raw(rays)
+    c.ssr_filter()
+    out = c.reflections.raw(0)
+    assert np.all(out[1:-1, 1:-1, :3] == 0)  # interior: every tap is an invalid ray (edge taps fetch out of bounds = valid garbage)

@@ -2,7 +2,9 @@
 // only error channel, gpu/common.cpp:6-12) are turned into status codes at this C boundary.
 #include "frame.hpp"
 
+#include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -190,6 +192,80 @@ const char* vkrh_collect_task_times(void* frame) {
       f->task_names += t.name + " " + std::to_string(t.total_ms) + " " + std::to_string(t.launches) + "\n";
   });
   return rc == 0 ? f->task_names.c_str() : nullptr;
+}
+int vkrh_selftest_errors(char* buf, uint32_t buf_size) {
+  std::string out;
+  auto expect = [&](const char* name, std::function<void()> f) {
+    try { f(); out += std::string{name} + ": no error\n"; }
+    catch (const std::exception& e) { out += std::string{name} + ": " + e.what() + "\n"; }
+  };
+  expect("unknown_program", [] { gpu::create_compute_pipeline("no_such_program"); });
+  expect("known_program", [] { gpu::create_compute_pipeline("gtao_compute_main"); });
+  expect("single_mip_depth", [] {
+    rendergraph::RenderGraph g;
+    const auto u = VK_IMAGE_USAGE_SAMPLED_BIT;
+    auto d = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_D24_UNORM_S8_UINT, VK_IMAGE_ASPECT_DEPTH_BIT, 16, 16}, VK_IMAGE_TILING_OPTIMAL, u);
+    auto n = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16G16_UNORM, VK_IMAGE_ASPECT_COLOR_BIT, 16, 16}, VK_IMAGE_TILING_OPTIMAL, u);
+    auto v = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16G16_SFLOAT, VK_IMAGE_ASPECT_COLOR_BIT, 16, 16}, VK_IMAGE_TILING_OPTIMAL, u);
+    auto on = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16G16_UNORM, VK_IMAGE_ASPECT_COLOR_BIT, 8, 8}, VK_IMAGE_TILING_OPTIMAL, u);
+    auto ov = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16G16_SFLOAT, VK_IMAGE_ASPECT_COLOR_BIT, 8, 8}, VK_IMAGE_TILING_OPTIMAL, u);
+    DownsamplePass pass;
+    pass.run(g, n, v, d, on, ov);
+  });
+  expect("mismatched_outputs", [] {
+    rendergraph::RenderGraph g;
+    const auto u = VK_IMAGE_USAGE_SAMPLED_BIT;
+    auto d = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_D24_UNORM_S8_UINT, VK_IMAGE_ASPECT_DEPTH_BIT, 16, 16, 1, 5, 1}, VK_IMAGE_TILING_OPTIMAL, u);
+    auto n = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16G16_UNORM, VK_IMAGE_ASPECT_COLOR_BIT, 16, 16}, VK_IMAGE_TILING_OPTIMAL, u);
+    auto v = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16G16_SFLOAT, VK_IMAGE_ASPECT_COLOR_BIT, 16, 16}, VK_IMAGE_TILING_OPTIMAL, u);
+    auto on = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16G16_UNORM, VK_IMAGE_ASPECT_COLOR_BIT, 4, 8}, VK_IMAGE_TILING_OPTIMAL, u);
+    auto ov = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16G16_SFLOAT, VK_IMAGE_ASPECT_COLOR_BIT, 8, 8}, VK_IMAGE_TILING_OPTIMAL, u);
+    DownsamplePass pass;
+    pass.run(g, n, v, d, on, ov);
+  });
+  expect("incompatible_usage", [] {
+    rendergraph::RenderGraph g;
+    auto img = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16_SFLOAT, VK_IMAGE_ASPECT_COLOR_BIT, 8, 8}, VK_IMAGE_TILING_OPTIMAL, VK_IMAGE_USAGE_STORAGE_BIT);
+    struct D { rendergraph::ImageViewId a, b; };
+    g.add_task<D>("bad",
+      [&](D& d, rendergraph::RenderGraphBuilder& b) { d.a = b.sample_image(img, VK_SHADER_STAGE_COMPUTE_BIT); d.b = b.use_storage_image(img, VK_SHADER_STAGE_COMPUTE_BIT, 0, 0); },
+      [](D&, rendergraph::RenderResources&, gpu::CmdContext&) {});
+  });
+  expect("read_then_write_in_separate_tasks", [] {
+    rendergraph::RenderGraph g;
+    auto img = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16_SFLOAT, VK_IMAGE_ASPECT_COLOR_BIT, 8, 8}, VK_IMAGE_TILING_OPTIMAL, VK_IMAGE_USAGE_STORAGE_BIT);
+    struct D { rendergraph::ImageViewId a; };
+    g.add_task<D>("r", [&](D& d, rendergraph::RenderGraphBuilder& b) { d.a = b.sample_image(img, VK_SHADER_STAGE_COMPUTE_BIT); }, [](D&, rendergraph::RenderResources&, gpu::CmdContext&) {});
+    g.add_task<D>("w", [&](D& d, rendergraph::RenderGraphBuilder& b) { d.a = b.use_storage_image(img, VK_SHADER_STAGE_COMPUTE_BIT, 0, 0); }, [](D&, rendergraph::RenderResources&, gpu::CmdContext&) {});
+  });
+  expect("remap_keeps_ids_valid", [&] {
+    rendergraph::RenderGraph g;
+    auto a = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16_SFLOAT, VK_IMAGE_ASPECT_COLOR_BIT, 8, 8}, VK_IMAGE_TILING_OPTIMAL, VK_IMAGE_USAGE_STORAGE_BIT);
+    auto b = g.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R16_SFLOAT, VK_IMAGE_ASPECT_COLOR_BIT, 16, 8}, VK_IMAGE_TILING_OPTIMAL, VK_IMAGE_USAGE_STORAGE_BIT);
+    void* pa = g.get_image(a)->device_ptr();
+    void* pb = g.get_image(b)->device_ptr();
+    g.remap(a, b);
+    if (g.get_image(a)->device_ptr() != pb || g.get_image(b)->device_ptr() != pa || g.get_descriptor(a).width != 16)
+      throw std::runtime_error{"remap did not swap the table entries"};
+  });
+  expect("tasks_run_in_submission_order", [&] {
+    rendergraph::RenderGraph g;
+    std::string order;
+    struct D {};
+    for (const char* n : {"a", "b", "c"})
+      g.add_task<D>(n, [](D&, rendergraph::RenderGraphBuilder&) {}, [&order, n](D&, rendergraph::RenderResources&, gpu::CmdContext&) { order += n; });
+    if (!order.empty()) throw std::runtime_error{"run callback executed before submit"};
+    g.submit();
+    if (order != "abc") throw std::runtime_error{"tasks reordered: " + order};
+  });
+  expect("ray_query_gtao", [] { rendergraph::RenderGraph g; GTAO gtao{g, 64, 64, true}; });
+  expect("ubo_ring_overflow", [] {
+    gpu::UniformBufferPool pool;
+    struct Big { char b[6000]; };
+    pool.allocate_ubo<Big>(); pool.allocate_ubo<Big>(); pool.allocate_ubo<Big>();
+  });
+  if (buf && buf_size) { std::snprintf(buf, buf_size, "%s", out.c_str()); }
+  return 0;
 }
 const char* vkrh_last_tasks(void* frame) { return ((PostFxFrame*)frame)->task_names.c_str(); }
 

@@ -61,6 +61,9 @@ int vkrh_image(void* frame, const char* name, uint32_t base_mip, uint32_t mip_co
 int vkrh_enable_task_timing(void* frame, uint32_t on);
 /* synchronises and returns "name total_ms launches\n" lines accumulated since the last call */
 const char* vkrh_collect_task_times(void* frame);
+/* Exercises the rendergraph / pass error paths the reference signals with exceptions (no kernel is
+ * launched; images come from the installed allocator).  Writes "case: message" lines into buf. */
+int vkrh_selftest_errors(char* buf, uint32_t buf_size);
 /* names of the tasks executed by the last vkrh_run, '\n'-separated */
 const char* vkrh_last_tasks(void* frame);
 
