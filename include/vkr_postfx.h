@@ -158,6 +158,13 @@ int vkr_depth_mips(const vkr_img* depth, uint32_t src_mip, void* stream);
 /* program "pdf_preintegrate": advanced_ssr.cpp:95-114 + preintegrate.comp:45-84          */
 int vkr_pdf_preintegrate(const vkr_img* out_pdf, void* stream);
 
+/* Fills the HaltonBuffer UBO of sssr_trace (host memory, `count` x vec4): xy = Halton(2,3) of index
+ * i+1 exactly as advanced_ssr.cpp:8-34 builds it; zw — unused (0) in the reference — carry
+ * (float)cos((double)phi), (float)sin((double)phi) with phi = (2*PI)*y, the two transcendentals
+ * sampleGGXVNDF (brdf.glsl:146-148) needs per ray: 128 values evaluated once on the host instead
+ * of per pixel on the device.  vkr_sssr_trace requires a buffer filled by this function.          */
+void vkr_halton23_fill(float* host_vec4, uint32_t count);
+
 /* program "sssr_trace": advanced_ssr.cpp:147-214 + trace.comp (bindings 0..7)            */
 int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
                    const vkr_trace_params* params, const float* halton_vec4 /*device, 128 x vec4*/,

@@ -24,7 +24,7 @@ def test_header_declares_expected_entries():
 def test_library_exports_every_declared_symbol():
     if not os.path.exists(abi.PRODUCT_LIB):
         pytest.skip("HIP library not built yet (run __graft_entry__.build())")
-    lib = C.CDLL(abi.PRODUCT_LIB)
+    lib = abi._load(abi.PRODUCT_LIB, "HIP extension")
     for sym in _declared_symbols():
         assert hasattr(lib, sym), f"{sym} declared in include/vkr_postfx.h but not exported"
 

@@ -141,7 +141,11 @@ class ExtensionMissing(RuntimeError):
     pass
 
 
-def _load(path, what):
+def _load(path, what, needs_hip=True):
+    if needs_hip:
+        # torch ships its own libamdhip64.so.7; load it first so the extension binds to the same HIP
+        # runtime torch uses for memory and streams (two runtimes in one process do not share devices)
+        import torch  # noqa: F401
     if not os.path.exists(path):
         raise ExtensionMissing(
             f"{what} not built: {path} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` first."
@@ -164,6 +168,8 @@ def product():
             fn.restype = C.c_int
         lib.vkr_stream_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.vkr_stream_read.restype = C.c_int
+        lib.vkr_halton23_fill.argtypes = [C.c_void_p, C.c_uint32]
+        lib.vkr_halton23_fill.restype = None
         lib.vkr_version.restype = C.c_char_p
         lib.vkr_last_error.restype = C.c_char_p
         lib.vkr_format_bytes.argtypes = [C.c_uint32]
@@ -177,7 +183,7 @@ def oracle():
     __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this."""
     global _oracle
     if _oracle is None:
-        lib = _load(ORACLE_LIB, "oracle libvkr_oracle.so")
+        lib = _load(ORACLE_LIB, "oracle libvkr_oracle.so", needs_hip=False)
         for name, args in ENTRY_ARGS.items():
             fn = getattr(lib, "vkr_ref_" + name)
             fn.argtypes = args

@@ -110,6 +110,11 @@ class PostFxChain:
         self.halton_host = h
         if self.device is None:
             return h
+        # the HIP trace kernel wants cos/sin(2*PI*y) in zw (vkr_halton23_fill, include/vkr_postfx.h)
+        filled = np.zeros((abi.HALTON_SEQ_SIZE, 4), dtype=np.float32)
+        self.lib.vkr_halton23_fill(filled.ctypes.data_as(C.c_void_p), abi.HALTON_SEQ_SIZE)
+        assert np.array_equal(filled[:, :2], h[:, :2])
+        h = filled
         import torch
 
         return torch.from_numpy(h).to(self.device)

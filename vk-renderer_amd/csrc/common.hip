@@ -25,3 +25,26 @@ extern "C" uint32_t vkr_format_bytes(uint32_t format) {
     default: return 0;
   }
 }
+
+// advanced_ssr.cpp:8-34 (float-floor division quirk kept) + host-evaluated cos/sin of 2*PI*y in zw
+extern "C" void vkr_halton23_fill(float* out, uint32_t count) {
+  auto halton_elem = [](uint32_t index, uint32_t base) {
+    float f = 1.0f, r = 0.0f;
+    uint32_t current = index;
+    do {
+      f = f / (float)base;
+      r = r + f * (float)(current % base);
+      current = (uint32_t)floorf((float)current / (float)base);
+    } while (current > 0);
+    return r;
+  };
+  const float PI = 3.1415926535897932384626433832795f;
+  for (uint32_t i = 0; i < count; i++) {
+    const float x = halton_elem(i + 1, 2), y = halton_elem(i + 1, 3);
+    const float phi = (2.0f * PI) * y;
+    out[4 * i + 0] = x;
+    out[4 * i + 1] = y;
+    out[4 * i + 2] = (float)cos((double)phi);
+    out[4 * i + 3] = (float)sin((double)phi);
+  }
+}

@@ -56,8 +56,9 @@ VKR_DEV float find_horizon(const DepthTile& depth, const Proj& pr, f2 start, f3 
     if (sample_pos.z > previous_z + 0.1f) break;  // MAX_THIKNESS, main.comp:82
     previous_z = sample_pos.z;
     f3 sample_offset = sample_pos - camera_start;
-    float sample_cos = dot(v, normalize(sample_offset));
-    if (sample_cos > h_cos) h_cos = sample_cos;
+    // max()-reduced cosine: the hardware rsq is accurate enough (the break test above stays exact)
+    float sample_cos = dot(v, sample_offset) * fast_rsq(dot(sample_offset, sample_offset));
+    h_cos = vmax(h_cos, sample_cos);
   }
   return h_cos;
 }

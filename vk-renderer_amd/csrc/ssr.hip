@@ -43,6 +43,7 @@ struct TraceArgs {
   Proj pr;
   uint32_t frame_random;
   float max_roughness;
+  float horizon_d2;    // host-computed: smallest float x with sqrtf(x) >= 0.3f (trace.comp:257)
 };
 
 // trace.comp:143-154
@@ -52,150 +53,242 @@ VKR_DEV f3 get_tangent(f3 n) {
   return normalize(t);
 }
 
-// brdf.glsl:135-155; cos/sin(phi) in double, rounded once (they steer the march)
-VKR_DEV f3 sampleGGXVNDF(f3 Ve, float alpha_x, float alpha_y, float U1, float U2) {
+// brdf.glsl:135-155; cos/sin(phi), phi = 2*PI*U2, come with the Halton entry (vkr_halton23_fill:
+// evaluated in double on the host and rounded once — they steer the march)
+VKR_DEV f3 sampleGGXVNDF(f3 Ve, float alpha_x, float alpha_y, float U1, float cos_phi, float sin_phi) {
   f3 Vh = normalize(mk3(alpha_x * Ve.x, alpha_y * Ve.y, Ve.z));
   float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
   f3 T1 = lensq > 0.0f ? mk3(-Vh.y, Vh.x, 0.0f) * (1.0f / sqrtf(lensq)) : mk3(1, 0, 0);
   f3 T2 = cross(Vh, T1);
   float r = sqrtf(U1);
-  float phi = (2.0f * VKR_PI) * U2;
-  float t1 = r * (float)cos((double)phi);
-  float t2 = r * (float)sin((double)phi);
+  float t1 = r * cos_phi;
+  float t2 = r * sin_phi;
   float s = 0.5f * (1.0f + Vh.z);
   t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
   f3 Nh = (t1 * T1 + t2 * T2) + sqrtf(vmax(0.0f, (1.0f - t1 * t1) - t2 * t2)) * Vh;
   return normalize(mk3(alpha_x * Nh.x, alpha_y * Nh.y, vmax(0.0f, Nh.z)));
 }
 
-// One thread per ray; a wave covers an 8x8 pixel tile (block = 4 such tiles) so that the rays of
-// a wave start in neighbouring texels and share cache lines while they stay coherent.
-// The Hi-Z pyramid is indexed by a per-lane mip level, so its per-mip descriptors are staged in
-// LDS once per block (one ds_read_b128 per step) instead of being re-read from the kernel
-// argument segment with dependent global loads on every step of the march.
-__global__ __launch_bounds__(256) void k_sssr_trace(TraceArgs a) {
-  __shared__ uint4 s_mip[16];  // {base lo, base hi, pitch, w | h << 16}; the pyramid covers the whole frame
-  __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
-  srgb_lut_stage(s_lut, threadIdx.x, 256);
-  if (threadIdx.x < 16) {
-    const Tex& m = a.depth.mip[threadIdx.x < (unsigned)a.depth.count ? threadIdx.x : 0];
-    const uint64_t base = (uint64_t)m.p;
-    s_mip[threadIdx.x] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)m.pitch, (uint32_t)m.w | ((uint32_t)m.h << 16));
+// ---- the Hi-Z march -----------------------------------------------------------------------------
+// State of one ray between steps of hierarchical_raymarch_find_hor (trace.comp:206-268).  `position`
+// is always origin + current_t * direction and the mip resolution is screen_size * 2^-mip (exact
+// power-of-two scalings), so (current_t, mip, i, h) is the whole mutable state.
+struct RayConst {
+  f3 origin, direction, inv_direction;
+  f3 normal, view_vec;  // pixel_normal (w0 of the horizon test) and camera_start
+};
+struct RayState { float t, h; int mip, i; };
+struct MarchEnv {
+  const uint4* mip_table;  // LDS: {base lo, base hi, pitch, w | h << 16} per pyramid level
+  int mip_count;
+  f2 screen_size, screen_size_inv;
+  f2 uv_offset_abs;
+  Proj pr;
+  float horizon_d2;  // smallest d2 with sqrtf(d2) >= 0.3f: |v| < 0.3 <=> dot(v,v) < horizon_d2
+};
+
+// One step of the march; returns false when the ray is finished (trace.comp:241).
+VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st) {
+  const float scale = __builtin_ldexpf(1.0f, -st.mip), scale_inv = __builtin_ldexpf(1.0f, st.mip);
+  const f2 res = mk2(env.screen_size.x * scale, env.screen_size.y * scale);
+  const f2 res_inv = mk2(env.screen_size_inv.x * scale_inv, env.screen_size_inv.y * scale_inv);
+  const f3 position = rc.origin + st.t * rc.direction;
+  const f2 mip_pos = res * xy(position);
+  // texelFetch(depth_tex, ivec2(p), mip): beyond the last mip or outside the mip extent -> 0
+  float surface_z = 0.0f;
+  if ((unsigned)st.mip < (unsigned)env.mip_count) {
+    const uint4 m = env.mip_table[st.mip];
+    const int tx = f2i(mip_pos.x), ty = f2i(mip_pos.y);
+    if (tx >= 0 && ty >= 0 && tx < (int)(m.w & 0xFFFFu) && ty < (int)(m.w >> 16)) {
+      typedef const __attribute__((address_space(1))) uint32_t* gptr_t;  // a global, not flat, address
+      const uint64_t addr = (((uint64_t)m.y << 32) | m.x) + (uint64_t)ty * m.z + (uint64_t)tx * 4u;
+      surface_z = d24_to_float(*(gptr_t)addr);
+    }
   }
+  // advance_ray (screen_trace.glsl:17-45)
+  const f2 uv_offset = mk2(rc.direction.x < 0.0f ? -env.uv_offset_abs.x : env.uv_offset_abs.x,
+                           rc.direction.y < 0.0f ? -env.uv_offset_abs.y : env.uv_offset_abs.y);
+  const f2 floor_offset = mk2(rc.direction.x < 0.0f ? 0.0f : 1.0f, rc.direction.y < 0.0f ? 0.0f : 1.0f);
+  f2 xy_plane = mk2(floorf(mip_pos.x), floorf(mip_pos.y)) + floor_offset;
+  xy_plane = xy_plane * res_inv + uv_offset;
+  f3 t = (mk3(xy_plane.x, xy_plane.y, surface_z) - rc.origin) * rc.inv_direction;
+  t.z = rc.direction.z > 0.0f ? t.z : 3.402823466e+38f;
+  const float t_min = vmin(vmin(t.x, t.y), t.z);
+  const bool above_surface = surface_z > position.z;
+  const bool skipped_tile = (t_min != t.z) && above_surface;
+  st.t = above_surface ? t_min : st.t;
+  // trace.comp:245-250: the first 15 steps stay on the finest mip
+  if (st.i >= 15) st.mip += skipped_tile ? 1 : -1;
+  ++st.i;
+  // trace.comp:253-262: horizon tracking around the new position
+  if (st.mip <= 1) {
+    const f3 np = rc.origin + st.t * rc.direction;
+    const f3 v = reconstruct_view_vec(xy(np), surface_z, env.pr) - rc.view_vec;
+    const float d2 = dot(v, v);
+    if (d2 < env.horizon_d2) {  // length(v) < 0.3, decided exactly on the squared length
+      // h only feeds acos() of the (smooth) occlusion term: the hardware rsq is accurate enough
+      const float h2 = dot(rc.normal, v) * __builtin_amdgcn_rsqf(d2);
+      st.h = vmax(st.h, h2);
+    }
+  }
+  return st.i < 80 && st.mip >= 0;
+}
+
+// One thread per ray in the prologue / epilogue; the march in between runs in rounds of
+// TRACE_ROUND steps with the block's unfinished rays compacted in LDS between rounds, because
+// rays of one 8x8 tile finish anywhere between 16 and 80 steps (mean 30, per-wave maximum mean 59
+// at 4K: half the lanes idle without compaction).  Every ray executes exactly the shader's step
+// sequence; only which lane executes it changes.
+#define TRACE_THREADS 256
+#define TRACE_ROUND 16
+__global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
+  __shared__ uint4 s_mip[16];
+  __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
+  __shared__ float s_rc[17][TRACE_THREADS];     // RayConst (15) + t + h of unfinished rays
+  __shared__ int s_mi[TRACE_THREADS];           // mip | i << 8
+  __shared__ uint16_t s_list[2][TRACE_THREADS];
+  __shared__ int s_count[2];
+  const int tid = threadIdx.x;
+  srgb_lut_stage(s_lut, tid, TRACE_THREADS);
+  if (tid < 16) {
+    const Tex& m = a.depth.mip[tid < a.depth.count ? tid : 0];
+    const uint64_t base = (uint64_t)m.p;
+    s_mip[tid] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)m.pitch, (uint32_t)m.w | ((uint32_t)m.h << 16));
+  }
+  if (tid < 2) s_count[tid] = 0;
   __syncthreads();
   // 256 threads = 4 waves; wave w owns the 8x8 tile (blockIdx.x*4 + w, blockIdx.y)
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = tid >> 6, lane = tid & 63;
   const int lx = (blockIdx.x * 4 + wave) * 8 + (lane & 7);
   const int ly = blockIdx.y * 8 + (lane >> 3);
-  if (lx >= a.out_ray.w || ly >= a.out_ray.h) return;
-  const int mip_count = a.depth.count;
+  const bool active = lx < a.out_ray.w && ly < a.out_ray.h;
   const int gx = a.out_ray.ox + lx, gy = a.out_ray.oy + ly;
   const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
   const f2 screen_uv = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
   const Proj pr = a.pr;
-
-  // trace.comp:49-58
-  float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
-  const float mg = mixf(0.0f, a.max_roughness, roughness);
-  roughness = mg * mg;
   const Tex& depth0 = a.depth.mip[0];
-  const float pixel_depth = sample<FmtD24>(depth0, screen_uv);
-  const f3 pixel_normal_world = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
-  const f3 pixel_normal = normalize(xyz(mul(a.normal_mat, mk4(pixel_normal_world.x, pixel_normal_world.y, pixel_normal_world.z, 0.0f))));
-  const f3 view_vec = reconstruct_view_vec(screen_uv, pixel_depth, pr);
 
-  // trace.comp:61-63,156-158: rand() -> Halton index; sin evaluated in double
-  const float rdot = dot(screen_uv, mk2(12.9898f, 78.233f));
-  const float rnd01 = fractf((float)sin((double)rdot) * 43758.5453f);
-  const uint32_t base_index = f2u(rnd01 * (float)VKR_HALTON_SEQ_SIZE);
-  const uint32_t index = (base_index + a.frame_random) & (VKR_HALTON_SEQ_SIZE - 1);
-  const float4 hv = a.halton[index];
+  MarchEnv env;
+  env.mip_table = s_mip;
+  env.mip_count = a.depth.count;
+  env.screen_size = mk2((float)depth0.fw, (float)depth0.fh);
+  env.screen_size_inv = mk2(1.0f / env.screen_size.x, 1.0f / env.screen_size.y);
+  env.uv_offset_abs = mk2(0.005f / env.screen_size.x, 0.005f / env.screen_size.y);  // most_detailed_mip = 0
+  env.pr = pr;
+  env.horizon_d2 = a.horizon_d2;
 
-  // trace.comp:65-77
-  f3 tangent = get_tangent(pixel_normal);
-  const f3 bitangent = normalize(cross(pixel_normal, tangent));
-  tangent = normalize(cross(bitangent, pixel_normal));
-  f3 view_dir = -normalize(view_vec);
-  view_dir = mk3(dot(view_dir, tangent), dot(view_dir, bitangent), dot(view_dir, pixel_normal));
-  const f3 brdf_norm = sampleGGXVNDF(view_dir, roughness, roughness, hv.x, hv.y);
-  const f3 N = (brdf_norm.x * tangent + brdf_norm.y * bitangent) + brdf_norm.z * pixel_normal;
-  const f3 R = reflect(view_vec, N);
+  RayConst rc;
+  RayState st;
+  f3 R = mk3(0, 0, 0), ray_start = mk3(0, 0, 0);
+  float roughness = 0.0f, pixel_depth = 1.0f;
+  bool running = false;
+  if (active) {
+    // trace.comp:49-58
+    roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
+    const float mg = mixf(0.0f, a.max_roughness, roughness);
+    roughness = mg * mg;
+    pixel_depth = sample<FmtD24>(depth0, screen_uv);
+    const f3 pixel_normal_world = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
+    rc.normal = normalize(xyz(mul(a.normal_mat, mk4(pixel_normal_world.x, pixel_normal_world.y, pixel_normal_world.z, 0.0f))));
+    rc.view_vec = reconstruct_view_vec(screen_uv, pixel_depth, pr);
 
-  // trace.comp:79-84
-  f3 ray_start = project_view_vec(view_vec + 0.001f * pixel_normal, pr);
-  ray_start.z -= 0.0001f;
-  f3 ray_dir = project_view_vec(view_vec + R, pr);
-  ray_dir = ray_dir - ray_start;
-  ray_dir = ray_dir * ((1.0f - ray_start.z) / ray_dir.z);
+    // trace.comp:61-63,156-158: rand() -> Halton index; sin evaluated in double
+    const float rdot = dot(screen_uv, mk2(12.9898f, 78.233f));
+    const float rnd01 = fractf((float)sin((double)rdot) * 43758.5453f);
+    const uint32_t base_index = f2u(rnd01 * (float)VKR_HALTON_SEQ_SIZE);
+    const uint32_t index = (base_index + a.frame_random) & (VKR_HALTON_SEQ_SIZE - 1);
+    const float4 hv = a.halton[index];
 
-  // ---- hierarchical_raymarch_find_hor (trace.comp:206-268, screen_trace.glsl:8-49) ----
-  const f3 origin = ray_start, direction = ray_dir;
-  const f3 inv_direction = mk3(direction.x != 0.0f ? 1.0f / direction.x : 3.402823466e+38f,
-                               direction.y != 0.0f ? 1.0f / direction.y : 3.402823466e+38f,
-                               direction.z != 0.0f ? 1.0f / direction.z : 3.402823466e+38f);
-  const f2 screen_size = mk2((float)depth0.fw, (float)depth0.fh);
-  f2 res = screen_size;  // most_detailed_mip = 0: screen_size * 0.5^0
-  f2 res_inv = mk2(1.0f / res.x, 1.0f / res.y);
-  f2 uv_offset = mk2(0.005f / screen_size.x, 0.005f / screen_size.y);
-  uv_offset.x = direction.x < 0.0f ? -uv_offset.x : uv_offset.x;
-  uv_offset.y = direction.y < 0.0f ? -uv_offset.y : uv_offset.y;
-  const f2 floor_offset = mk2(direction.x < 0.0f ? 0.0f : 1.0f, direction.y < 0.0f ? 0.0f : 1.0f);
+    // trace.comp:65-77
+    f3 tangent = get_tangent(rc.normal);
+    const f3 bitangent = normalize(cross(rc.normal, tangent));
+    tangent = normalize(cross(bitangent, rc.normal));
+    f3 view_dir = -normalize(rc.view_vec);
+    view_dir = mk3(dot(view_dir, tangent), dot(view_dir, bitangent), dot(view_dir, rc.normal));
+    const f3 brdf_norm = sampleGGXVNDF(view_dir, roughness, roughness, hv.x, hv.z, hv.w);
+    const f3 N = (brdf_norm.x * tangent + brdf_norm.y * bitangent) + brdf_norm.z * rc.normal;
+    R = reflect(rc.view_vec, N);
 
-  float current_t;
-  f3 position;
-  {  // initial_advance_ray
-    f2 cur_pos = res * xy(origin);
-    f2 xy_plane = mk2(floorf(cur_pos.x), floorf(cur_pos.y)) + floor_offset;
-    xy_plane = xy_plane * res_inv + uv_offset;
-    f2 t = (xy_plane - xy(origin)) * xy(inv_direction);
-    current_t = vmin(t.x, t.y);
-    position = origin + current_t * direction;
-  }
-  float h = 0.0f;
-  int current_mip = 0;
-  int i = 0;
+    // trace.comp:79-84
+    ray_start = project_view_vec(rc.view_vec + 0.001f * rc.normal, pr);
+    ray_start.z -= 0.0001f;
+    f3 ray_dir = project_view_vec(rc.view_vec + R, pr);
+    ray_dir = ray_dir - ray_start;
+    ray_dir = ray_dir * ((1.0f - ray_start.z) / ray_dir.z);
+
+    rc.origin = ray_start;
+    rc.direction = ray_dir;
+    rc.inv_direction = mk3(ray_dir.x != 0.0f ? 1.0f / ray_dir.x : 3.402823466e+38f,
+                           ray_dir.y != 0.0f ? 1.0f / ray_dir.y : 3.402823466e+38f,
+                           ray_dir.z != 0.0f ? 1.0f / ray_dir.z : 3.402823466e+38f);
+    {  // initial_advance_ray (screen_trace.glsl:8-15)
+      const f2 uv_offset = mk2(ray_dir.x < 0.0f ? -env.uv_offset_abs.x : env.uv_offset_abs.x,
+                               ray_dir.y < 0.0f ? -env.uv_offset_abs.y : env.uv_offset_abs.y);
+      const f2 floor_offset = mk2(ray_dir.x < 0.0f ? 0.0f : 1.0f, ray_dir.y < 0.0f ? 0.0f : 1.0f);
+      const f2 cur_pos = env.screen_size * xy(rc.origin);
+      f2 xy_plane = mk2(floorf(cur_pos.x), floorf(cur_pos.y)) + floor_offset;
+      xy_plane = xy_plane * env.screen_size_inv + uv_offset;
+      const f2 t = (xy_plane - xy(rc.origin)) * xy(rc.inv_direction);
+      st.t = vmin(t.x, t.y);
+    }
+    st.h = 0.0f;  // trace.comp:239
+    st.mip = 0;
+    st.i = 0;
+    // round 0: the first 15 steps never leave mip 0, so every ray runs exactly 16 steps here
+    running = true;
 #pragma unroll 1
-  while (i < 80 && current_mip >= 0) {
-    const f2 mip_pos = res * xy(position);
-    // texelFetch(depth_tex, ivec2(p), mip): beyond the last mip or outside the mip extent -> 0
-    float surface_z = 0.0f;
-    if ((unsigned)current_mip < (unsigned)mip_count) {
-      const uint4 m = s_mip[current_mip];
-      const int tx = f2i(mip_pos.x), ty = f2i(mip_pos.y);
-      if (tx >= 0 && ty >= 0 && tx < (int)(m.w & 0xFFFFu) && ty < (int)(m.w >> 16)) {
-        // the table holds plain integers: tell the compiler this is a global (not flat) address
-        typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
-        const uint64_t addr = (((uint64_t)m.y << 32) | m.x) + (uint64_t)ty * m.z + (uint64_t)tx * 4u;
-        surface_z = d24_to_float(*(gptr_t)addr);
+    for (int k = 0; k < TRACE_ROUND && running; k++) running = march_step(env, rc, st);
+  }
+  // park the unfinished rays in LDS
+  if (running) {
+    const int slot = atomicAdd(&s_count[0], 1);
+    s_list[0][slot] = (uint16_t)tid;
+    float* p = &s_rc[0][tid];
+    p[0 * TRACE_THREADS] = rc.origin.x; p[1 * TRACE_THREADS] = rc.origin.y; p[2 * TRACE_THREADS] = rc.origin.z;
+    p[3 * TRACE_THREADS] = rc.direction.x; p[4 * TRACE_THREADS] = rc.direction.y; p[5 * TRACE_THREADS] = rc.direction.z;
+    p[6 * TRACE_THREADS] = rc.inv_direction.x; p[7 * TRACE_THREADS] = rc.inv_direction.y; p[8 * TRACE_THREADS] = rc.inv_direction.z;
+    p[9 * TRACE_THREADS] = rc.normal.x; p[10 * TRACE_THREADS] = rc.normal.y; p[11 * TRACE_THREADS] = rc.normal.z;
+    p[12 * TRACE_THREADS] = rc.view_vec.x; p[13 * TRACE_THREADS] = rc.view_vec.y; p[14 * TRACE_THREADS] = rc.view_vec.z;
+    p[15 * TRACE_THREADS] = st.t; p[16 * TRACE_THREADS] = st.h;
+    s_mi[tid] = st.mip | (st.i << 8);
+  }
+  // compacted rounds: thread k of the block advances the k-th unfinished ray by TRACE_ROUND steps
+  for (int cur = 0;; cur ^= 1) {
+    __syncthreads();
+    const int n = s_count[cur];
+    if (n == 0) break;
+    if (tid == 0) s_count[cur ^ 1] = 0;
+    __syncthreads();
+    if (tid < n) {
+      const int ray = s_list[cur][tid];
+      const float* p = &s_rc[0][ray];
+      RayConst q;
+      q.origin = mk3(p[0 * TRACE_THREADS], p[1 * TRACE_THREADS], p[2 * TRACE_THREADS]);
+      q.direction = mk3(p[3 * TRACE_THREADS], p[4 * TRACE_THREADS], p[5 * TRACE_THREADS]);
+      q.inv_direction = mk3(p[6 * TRACE_THREADS], p[7 * TRACE_THREADS], p[8 * TRACE_THREADS]);
+      q.normal = mk3(p[9 * TRACE_THREADS], p[10 * TRACE_THREADS], p[11 * TRACE_THREADS]);
+      q.view_vec = mk3(p[12 * TRACE_THREADS], p[13 * TRACE_THREADS], p[14 * TRACE_THREADS]);
+      RayState rs;
+      rs.t = p[15 * TRACE_THREADS]; rs.h = p[16 * TRACE_THREADS];
+      const int mi = s_mi[ray];
+      rs.mip = (int)(int8_t)(mi & 0xFF); rs.i = mi >> 8;
+      bool more = true;
+#pragma unroll 1
+      for (int k = 0; k < TRACE_ROUND && more; k++) more = march_step(env, q, rs);
+      s_rc[15][ray] = rs.t; s_rc[16][ray] = rs.h;
+      s_mi[ray] = (rs.mip & 0xFF) | (rs.i << 8);
+      if (more) {
+        const int slot = atomicAdd(&s_count[cur ^ 1], 1);
+        s_list[cur ^ 1][slot] = (uint16_t)ray;
       }
     }
-    // advance_ray (screen_trace.glsl:17-45)
-    f2 xy_plane = mk2(floorf(mip_pos.x), floorf(mip_pos.y)) + floor_offset;
-    xy_plane = xy_plane * res_inv + uv_offset;
-    f3 t = (mk3(xy_plane.x, xy_plane.y, surface_z) - origin) * inv_direction;
-    t.z = direction.z > 0.0f ? t.z : 3.402823466e+38f;
-    const float t_min = vmin(vmin(t.x, t.y), t.z);
-    const bool above_surface = surface_z > position.z;
-    const bool skipped_tile = (t_min != t.z) && above_surface;
-    current_t = above_surface ? t_min : current_t;
-    position = origin + current_t * direction;
-    // trace.comp:245-250: the first 15 steps stay on the finest mip
-    const bool mip0sample = i < 15;
-    current_mip += mip0sample ? 0 : (skipped_tile ? 1 : -1);
-    const float rs = mip0sample ? 1.0f : (skipped_tile ? 0.5f : 2.0f);
-    const float ri = mip0sample ? 1.0f : (skipped_tile ? 2.0f : 0.5f);
-    res = res * rs;
-    res_inv = res_inv * ri;
-    ++i;
-    // trace.comp:253-262: horizon tracking
-    if (current_mip <= 1) {
-      const f3 v = reconstruct_view_vec(xy(position), surface_z, pr) - view_vec;
-      const float h2 = dot(pixel_normal, normalize(v));
-      if (length(v) < 0.3f) h = vmax(h, h2);
-    }
   }
+  if (!active) return;
+  if (running) { st.t = s_rc[15][tid]; st.h = s_rc[16][tid]; }  // this thread's ray was finished by another lane
+  const f3 out_ray = rc.origin + st.t * rc.direction;
+  const float h = st.h;
+  const f3 pixel_normal = rc.normal, view_vec = rc.view_vec;
   bool valid_hit = true;  // i <= 80 always (trace.comp:265)
-  const f3 out_ray = position;
 
   // trace.comp:94-118
   {
@@ -277,10 +370,13 @@ __global__ __launch_bounds__(FILT_BX * FILT_BY) void k_sssr_filter(FilterArgs a)
     const f3 Nn = xyz(mul(a.normal_mat, mk4(pnw.x, pnw.y, pnw.z, 0.0f)));
     const f3 hit_vec = reconstruct_view_vec(mk2(trace_result.x, trace_result.y), trace_result.z, a.pr);
     const f3 radiance = (trace_result.w != 1.0f) ? sample_srgb_rgb(a.albedo, mk2(trace_result.x, trace_result.y), s_lut) : mk3(0, 0, 0);
-    const f3 V = -normalize(view_vec);
-    const f3 L = normalize(hit_vec - view_vec);
-    const f3 H = normalize(V + L);
-    const float p5 = powf(vclamp(1.0f - vmax(dot(H, V), 0.0f), 0.0f, 1.0f), 5.0f);  // fresnelSchlick's power term
+    // weights only (never compared): hardware rsq and x^5 by multiplication
+    const f3 V = -normalize_fast(view_vec);
+    const f3 L = normalize_fast(hit_vec - view_vec);
+    const f3 H = normalize_fast(V + L);
+    const float om = vclamp(1.0f - vmax(dot(H, V), 0.0f), 0.0f, 1.0f);
+    const float om2 = om * om;
+    const float p5 = (om2 * om2) * om;  // fresnelSchlick's pow(., 5)
     s_geo[t] = make_float4(p5, vmax(dot(Nn, L), 0.0f), vmax(dot(Nn, V), 0.0f), pixel_depth);
     s_rad[t] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
   }
@@ -309,9 +405,14 @@ __global__ __launch_bounds__(FILT_BX * FILT_BY) void k_sssr_filter(FilterArgs a)
       const float4 rad = s_rad[tc + offs[k]];
       // ray_weight (filter.comp:97-108), literal swapped argument order of brdfG1
       const f3 F = F0 + one_minus_F0 * geo.x;
-      const float G2 = brdfG2(geo.y, geo.z, alpha2);
-      const float G1 = brdfG1(geo.z, alpha2);
-      f3 weight = (F * G2) / G1;
+      // brdfG2(NdotL, NdotV, alpha2) / brdfG1(NdotV, alpha2) with hardware rcp / sqrt (smooth weights)
+      const float NdotL2 = geo.y * geo.y, NdotV2 = geo.z * geo.z;
+      const float L1 = fast_sqrt(1.0f + (alpha2 * (1.0f - NdotL2)) * fast_rcp(NdotL2));
+      const float L2 = fast_sqrt(1.0f + (alpha2 * (1.0f - NdotV2)) * fast_rcp(NdotV2));
+      const float G2 = 2.0f * fast_rcp(L1 + L2);
+      const float a4 = alpha2 * alpha2;  // brdfG1's "NdotV" argument is alpha2 here (filter.comp:106)
+      const float G1 = 2.0f * fast_rcp(1.0f + fast_sqrt(1.0f + geo.z * ((1.0f - a4) * fast_rcp(a4))));
+      f3 weight = F * (G2 * fast_rcp(G1));
       float bilateral_weight = 1.0f;
       if (a.render_flags & VKR_BILATERAL_FILTER)
         bilateral_weight = vmax(1.0f - (1000.0f * fabsf(center_depth - geo.w)) / center_depth, 0.0f);
@@ -523,7 +624,13 @@ extern "C" int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const
   load_proj(a.pr, params->fovy, params->aspect, params->znear, params->zfar);
   a.frame_random = params->frame_random;
   a.max_roughness = push->max_roughness;
-  dim3 block(256, 1);
+  {  // |v| < 0.3f  <=>  dot(v,v) < horizon_d2, because correctly rounded sqrtf is monotone
+    float x = 0.3f * 0.3f;
+    while (sqrtf(x) >= 0.3f) x = nextafterf(x, 0.0f);
+    while (sqrtf(x) < 0.3f) x = nextafterf(x, 1.0f);
+    a.horizon_d2 = x;
+  }
+  dim3 block(TRACE_THREADS, 1);
   dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 7) / 8);
   hipLaunchKernelGGL(k_sssr_trace, grid, block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_trace");

@@ -62,6 +62,12 @@ VKR_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 VKR_DEV float length(f2 a) { return sqrtf(dot(a, a)); }
 VKR_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
 VKR_DEV f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+// Hardware reciprocal / rsqrt / sqrt (1 ulp): ONLY for values that never feed a comparison — weights,
+// shading terms, horizon cosines that are max()-reduced — where 1e-7 relative noise is irrelevant.
+VKR_DEV float fast_rcp(float a) { return __builtin_amdgcn_rcpf(a); }
+VKR_DEV float fast_rsq(float a) { return __builtin_amdgcn_rsqf(a); }
+VKR_DEV float fast_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+VKR_DEV f3 normalize_fast(f3 a) { return a * fast_rsq(dot(a, a)); }
 VKR_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 VKR_DEV f3 reflect(f3 I, f3 N) { return I - (2.0f * dot(N, I)) * N; }
 VKR_DEV bool is_nan(float a) { return a != a; }

@@ -39,7 +39,19 @@ AdvancedSSR::AdvancedSSR(rendergraph::RenderGraph &graph, uint32_t w, uint32_t h
   blur_pass = gpu::create_compute_pipeline("sssr_blur");
   preintegrate_pass = gpu::create_compute_pipeline("pdf_preintegrate");
 
-  const auto halton_samples = halton23_seq(HALTON_SEQ_SIZE);
+  // xy: the reference's table (advanced_ssr.cpp:22-34); zw: cos/sin of 2*PI*y evaluated on the host
+  // for the HIP trace kernel (vkr_halton23_fill, include/vkr_postfx.h) — zero in the reference
+  auto halton_samples = halton23_seq(HALTON_SEQ_SIZE);
+  {
+    std::vector<float> filled(4 * HALTON_SEQ_SIZE);
+    vkr_halton23_fill(filled.data(), HALTON_SEQ_SIZE);
+    for (uint32_t i = 0; i < HALTON_SEQ_SIZE; i++) {
+      if (filled[4 * i] != halton_samples[i].x || filled[4 * i + 1] != halton_samples[i].y)
+        throw std::runtime_error {"Halton table mismatch between host pass and C-ABI helper"};
+      halton_samples[i].z = filled[4 * i + 2];
+      halton_samples[i].w = filled[4 * i + 3];
+    }
+  }
   const uint64_t bytes = sizeof(halton_samples[0]) * HALTON_SEQ_SIZE;
   halton_buffer = gpu::create_buffer(VMA_MEMORY_USAGE_CPU_TO_GPU, bytes, VK_BUFFER_USAGE_UNIFORM_BUFFER_BIT);
   std::memcpy(halton_buffer->get_mapped_ptr(), halton_samples.data(), bytes);
