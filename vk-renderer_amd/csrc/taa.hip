@@ -30,11 +30,24 @@ __global__ __launch_bounds__(256) void k_taa_resolve(TaaArgs a) {
   const f2 prev_uv = screen_uv + velocity;
   f3 out_color = current_color;
   if (prev_uv.x >= 0.0f && prev_uv.y >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y <= 1.0f) {
-    f3 history = rgb(sample<FmtRGBA16F>(a.history, prev_uv));
-    const f3 color0 = rgb(sample<FmtRGBA16F>(a.history, prev_uv, 1, 0));
-    const f3 color1 = rgb(sample<FmtRGBA16F>(a.history, prev_uv, 0, 1));
-    const f3 color2 = rgb(sample<FmtRGBA16F>(a.history, prev_uv, -1, 0));
-    const f3 color3 = rgb(sample<FmtRGBA16F>(a.history, prev_uv, 0, -1));
+    // texture(prev_uv) and its four textureOffset neighbours (resolve.comp:41-45) share weights and
+    // overlap in texels: the 12 distinct texels of the plus-shaped footprint are loaded and decoded
+    // once; each of the five results is then the same lerp-of-lerps the sampler would compute.
+    const float hx = prev_uv.x * (float)a.history.fw - 0.5f, hy = prev_uv.y * (float)a.history.fh - 0.5f;
+    const float hx0f = floorf(hx), hy0f = floorf(hy);
+    const float fx = hx - hx0f, fy = hy - hy0f;
+    const int hx0 = f2i(hx0f), hy0 = f2i(hy0f);
+    auto tex = [&](int dx, int dy) { return rgb(fetch_clamped<FmtRGBA16F>(a.history, hx0 + dx, hy0 + dy)); };
+    const f3 t_m1_0 = tex(-1, 0), t_m1_1 = tex(-1, 1);
+    const f3 t_0_m1 = tex(0, -1), t_0_0 = tex(0, 0), t_0_1 = tex(0, 1), t_0_2 = tex(0, 2);
+    const f3 t_1_m1 = tex(1, -1), t_1_0 = tex(1, 0), t_1_1 = tex(1, 1), t_1_2 = tex(1, 2);
+    const f3 t_2_0 = tex(2, 0), t_2_1 = tex(2, 1);
+    auto bil = [&](f3 t00, f3 t10, f3 t01, f3 t11) { return mix3(mix3(t00, t10, fx), mix3(t01, t11, fx), fy); };
+    f3 history = bil(t_0_0, t_1_0, t_0_1, t_1_1);
+    const f3 color0 = bil(t_1_0, t_2_0, t_1_1, t_2_1);    // offset (+1, 0)
+    const f3 color1 = bil(t_0_1, t_1_1, t_0_2, t_1_2);    // offset ( 0,+1)
+    const f3 color2 = bil(t_m1_0, t_0_0, t_m1_1, t_0_1);  // offset (-1, 0)
+    const f3 color3 = bil(t_0_m1, t_1_m1, t_0_0, t_1_0);  // offset ( 0,-1)
     const f3 color_min = min3(color0, min3(color1, min3(color2, color3)));
     const f3 color_max = max3(color0, max3(color1, max3(color2, color3)));
     history = min3(max3(history, color_min), color_max);

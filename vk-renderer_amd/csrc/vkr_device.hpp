@@ -72,9 +72,18 @@ VKR_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x
 VKR_DEV f3 reflect(f3 I, f3 N) { return I - (2.0f * dot(N, I)) * N; }
 VKR_DEV bool is_nan(float a) { return a != a; }
 VKR_DEV float fractf(float a) { return a - floorf(a); }
-// float -> int: truncate, NaN -> 0, saturate at +-2^30 (a following +1 cannot overflow)
-VKR_DEV int f2i(float f) { return (f != f) ? 0 : (int)fminf(fmaxf(f, -1073741824.0f), 1073741824.0f); }
-VKR_DEV uint32_t f2u(float f) { return (f != f) ? 0u : (uint32_t)fminf(fmaxf(f, 0.0f), 1073741824.0f); }
+// float -> int: truncate, NaN -> 0, saturate at +-2^30 (a following +1 cannot overflow).
+// v_cvt_i32_f32 itself truncates, saturates and maps NaN to 0; the med3 narrows the saturation.
+VKR_DEV int f2i(float f) {
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+  return min(max(r, -1073741824), 1073741824);
+}
+VKR_DEV uint32_t f2u(float f) {
+  uint32_t r;
+  asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+  return min(r, 1073741824u);
+}
 
 #define VKR_PI 3.1415926535897932384626433832795f
 
@@ -169,9 +178,9 @@ template <class F> VKR_DEV typename F::T fetch(const Tex& t, int gx, int gy) {
   int lx = iclamp(gx - t.ox, 0, t.w - 1), ly = iclamp(gy - t.oy, 0, t.h - 1);
   return F::load(t, lx, ly);
 }
+// clamp-to-edge fetch of the bilinear filter.  The window lies inside the frame, so clamping to the
+// frame and then to the window held in memory is one clamp to the window.
 template <class F> VKR_DEV typename F::T fetch_clamped(const Tex& t, int gx, int gy) {
-  gx = iclamp(gx, 0, t.fw - 1);
-  gy = iclamp(gy, 0, t.fh - 1);
   int lx = iclamp(gx - t.ox, 0, t.w - 1), ly = iclamp(gy - t.oy, 0, t.h - 1);
   return F::load(t, lx, ly);
 }
@@ -195,8 +204,6 @@ VKR_DEV void srgb_lut_stage(float* lds_lut, int tid, int nthreads) {
   for (int i = tid; i < VKR_SRGB_LUT_SIZE; i += nthreads) lds_lut[i] = __uint_as_float(k_srgb_decode_bits[i]);
 }
 VKR_DEV uint32_t load_u32_clamped(const Tex& t, int gx, int gy) {
-  gx = iclamp(gx, 0, t.fw - 1);
-  gy = iclamp(gy, 0, t.fh - 1);
   int lx = iclamp(gx - t.ox, 0, t.w - 1), ly = iclamp(gy - t.oy, 0, t.h - 1);
   return *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);
 }
