@@ -212,6 +212,10 @@ int vkr_synth_gbuffer(const vkr_img* depth, const vkr_img* normal, const vkr_img
  * SURVEY.md 8(d).  Reads `bytes` from `src`, writes one float per block to `sink`.      */
 int vkr_stream_read(const void* src, uint64_t bytes, float* sink, uint32_t sink_len, void* stream);
 
+/* Test hook: counts (into 5 device uint32, zeroed by the caller) where the kernels' cheap exact
+ * arithmetic — normal-range division, UNORM decodes — disagrees with its IEEE definition.        */
+int vkr_selftest_division(uint32_t* device_counters5, float znear, float zfar, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,19 +2,40 @@
 import ctypes as C
 
 import numpy as np
+import pytest
 
 from vk_renderer_amd import abi
 
 
-def test_unorm_decode_double_mul_is_exact():
-    """vkr_device.hpp decodes UNORM as (float)((double)k * (1.0 / (2^b - 1))); the oracle defines it as the
-    correctly rounded fp32 quotient k / (2^b - 1).  They agree for every code of every width on the path."""
-    for bits in (8, 16, 24):
+def test_unorm_decode_fma_form_is_exact():
+    """vkr_device.hpp decodes UNORM as fmaf(x, C, x) with x = k * 2^-b and C = nextafter(2^-24) /
+    2^-16 + 2^-32 / float(1/255); the oracle defines it as the correctly rounded fp32 quotient
+    k / (2^b - 1).  They agree for every code of every width on the path.  (x * C and x + x*C are
+    exact in float64, so one rounding to float32 reproduces fmaf.)"""
+    consts = {24: float.fromhex("0x1.000002p-24"), 16: float.fromhex("0x1.0001p-16"), 8: float.fromhex("0x1.010102p-8")}
+    for bits, c in consts.items():
+        assert float(np.float32(c)) == c, "constant must be an exact float32"
         k = np.arange(1 << bits, dtype=np.uint32)
         d = np.float32((1 << bits) - 1)
         ref = (k.astype(np.float32) / d).astype(np.float32)
-        fast = (k.astype(np.float64) * (1.0 / float((1 << bits) - 1))).astype(np.float32)
+        x = k.astype(np.float64) * 2.0 ** -bits
+        fast = (x + x * c).astype(np.float32)
         assert np.array_equal(ref, fast), f"UNORM{bits}"
+
+
+@pytest.mark.gpu
+def test_device_division_and_decodes_are_exact():
+    """On the GPU: div_normal (the kernels' normal-range division) against IEEE '/' for linearize_depth2 over
+    all 2^24 stored depths and 2^24 hashed operand pairs, and the three UNORM decodes against their quotients."""
+    import torch
+
+    lib = abi.product()
+    lib.vkr_selftest_division.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    for znear, zfar in ((0.05, 80.0), (0.1, 1000.0), (1.0, 50.0)):
+        counters = torch.zeros(5, dtype=torch.int32, device="cuda")
+        abi.check(lib.vkr_selftest_division(counters.data_ptr(), znear, zfar, torch.cuda.current_stream().cuda_stream), lib)
+        torch.cuda.synchronize()
+        assert counters.tolist() == [0, 0, 0, 0, 0], (znear, zfar, counters.tolist())
 
 
 def test_half_roundtrip_all_codes(oracle_lib):

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
     occ_x = 0.0f;
     occ_y = a.use_mis ? 1.0f : pdf_uniform;
   } else {
+    // Exact: camera_pos, the sample radius / direction (they place the horizon samples and feed the
+    // break test) and w0 / camera_normal / L (coordinates of the ill-conditioned PDF lookup).
+    // Smooth (hardware rsq): the slice frame and its angles.
     const f3 camera_pos = reconstruct_view_vec(screen_uv, frag_depth, a.pr);
     const f3 w0 = -normalize(camera_pos);
     const f3 n_world = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
@@ -108,19 +111,21 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
       const f2 cs = mk2(a.slice_cs[di][dir_slot][0], a.slice_cs[di][dir_slot][1]);
       const f2 sample_direction = dir_radius * cs;
       const f3 sample_end_pos = reconstruct_view_vec(screen_uv + sample_direction, frag_depth, a.pr);
-      const f3 slice_normal = normalize(cross(w0, -sample_end_pos));
+      const f3 slice_normal = normalize_fast(cross(w0, -sample_end_pos));
       const f3 normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
-      const f3 X = -normalize(cross(slice_normal, w0));
-      const float n = VKR_PI / 2.0f - acosf(dot(normalize(normal_projected), X));
+      const f3 X = -normalize_fast(cross(slice_normal, w0));
+      const float np_len2 = dot(normal_projected, normal_projected);
+      const float np_len = fast_sqrt(np_len2);
+      const float n = VKR_PI / 2.0f - acosf(dot(normal_projected, X) * fast_rsq(np_len2));
       const float h_cos = find_horizon(tile, a.pr, screen_uv, camera_pos, sample_direction, w0);
       float h = acosf(h_cos);
       h = vmin(n + vmin(h - n, VKR_PI / 2.0f), h);
       const float arc = vmax((-cosf(2.0f * h - n) + cosf(n)) + (2.0f * h) * sinf(n), 0.0f);
       if (a.use_mis) {
-        occlusion = (((1.0f / VKR_PI) * length(normal_projected)) * 0.25f) * arc;
+        occlusion = (((1.0f / VKR_PI) * np_len) * 0.25f) * arc;
         L = normalize(sample_end_pos - camera_pos);
       } else {
-        sum += (length(normal_projected) * 0.25f) * arc;
+        sum += (np_len * 0.25f) * arc;
       }
     }
     if (!a.use_mis) {
@@ -138,8 +143,8 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
       } else {
         const float alpha = 1.0f / (a.weight_ratio + 1.0f);
         const float betta = 1.0f - alpha;
-        const float mis_weight1 = alpha / (alpha * ao_y + betta * pdf_uniform);
-        const float mis_weight2 = betta / (alpha * pdf_ggx + betta * pdf_uniform);
+        const float mis_weight1 = alpha * fast_rcp(alpha * ao_y + betta * pdf_uniform);
+        const float mis_weight2 = betta * fast_rcp(alpha * pdf_ggx + betta * pdf_uniform);
         const float mis_ao = ao_x * mis_weight1 + occlusion * mis_weight2;
         occ_x = is_nan(mis_ao) ? occlusion / pdf_uniform : mis_ao;
         occ_y = 1.0f;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(GF_BX * GF_BY) void k_gtao_filter(Tex depth, Tex ra
   const int bx0 = out.ox + blockIdx.x * GF_BX - 2, by0 = out.oy + blockIdx.y * GF_BY - 2;
   for (int t = tid; t < GF_TW * GF_TH; t += GF_BX * GF_BY) {
     const int px = bx0 + t % GF_TW, py = by0 + t / GF_TW;
-    s_t[t] = make_float2(linearize_depth2(fetch<FmtD24>(depth, px, py), znear, zfar), fetch<FmtRGBA16F>(raw, px, py).x);
+    s_t[t] = make_float2(linearize_depth2_unorm(fetch<FmtD24>(depth, px, py), znear, zfar), fetch<FmtRGBA16F>(raw, px, py).x);
   }
   __syncthreads();
   const int lx = blockIdx.x * GF_BX + threadIdx.x;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(256) void k_gtao_accumulate(AccumArgs a) {
     prev_ndc = prev_ndc / prev_ndc.w;
     const f2 prev_world_uv = mk2(0.5f * prev_ndc.x + 0.5f, 0.5f * prev_ndc.y + 0.5f);
     const f2 delta = mk2(fabsf(prev_world_uv.x - screen_uv.x) * tex_size.x, fabsf(prev_world_uv.y - screen_uv.y) * tex_size.y);
-    const float current_z = linearize_depth2(sample<FmtD24>(a.depth, screen_uv), a.pr.znear, a.pr.zfar);
+    const float current_z = linearize_depth2_unorm(sample<FmtD24>(a.depth, screen_uv), a.pr.znear, a.pr.zfar);
     const float prev_z = linearize_depth2(prev_ndc.z, a.pr.znear, a.pr.zfar);
     const float depth_err = fabsf(prev_z - current_z);
     const float vel_delta = vmax(fabsf(velocity.x) * tex_size.x, fabsf(velocity.y) * tex_size.y);

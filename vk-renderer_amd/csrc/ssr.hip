@@ -302,7 +302,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   }
   if (valid_hit) {
     const float hit_depth = sample<FmtD24>(depth0, xy(out_ray));
-    const float hit_z = linearize_depth2(hit_depth, pr.znear, pr.zfar);
+    const float hit_z = linearize_depth2_unorm(hit_depth, pr.znear, pr.zfar);
     const float ray_z = linearize_depth2(out_ray.z, pr.znear, pr.zfar);
     if (ray_z > hit_z + 0.3f || ray_z < hit_z - 0.1f) valid_hit = false;
   }
@@ -315,6 +315,9 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   // trace.comp:123-139: (occlusion, pdf) into gtao.raw.  h was reset to 0 inside the march,
   // so the `no_occlusion` (h == -1) case of the reference never fires.
   {
+    // Exact arithmetic: the PDF lookup is ill-conditioned near the singular texels of the LUT, so
+    // its coordinates must match the reference sequence bit for bit (a 1e-7 perturbation there
+    // moves raw.y by far more than 1e-3).
     const f3 w0 = -normalize(view_vec);
     const f3 slice_normal = normalize(cross(w0, R));
     const f3 normal_projected = pixel_normal - dot(pixel_normal, slice_normal) * slice_normal;
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(FILT_BX * FILT_BY) void k_sssr_filter(FilterArgs a)
     const f2 pixel_uv = mk2((float)px / tex_size.x, (float)py / tex_size.y);
     const float pixel_depth = fetch<FmtD24>(a.depth1, px, py);
     const f3 view_vec = reconstruct_view_vec(pixel_uv, pixel_depth, a.pr);
-    const f3 pnw = decode_normal(sample<FmtRG16U>(a.normal, pixel_uv));
+    const f3 pnw = decode_normal_fast(sample<FmtRG16U>(a.normal, pixel_uv));
     const f3 Nn = xyz(mul(a.normal_mat, mk4(pnw.x, pnw.y, pnw.z, 0.0f)));
     const f3 hit_vec = reconstruct_view_vec(mk2(trace_result.x, trace_result.y), trace_result.z, a.pr);
     const f3 radiance = (trace_result.w != 1.0f) ? sample_srgb_rgb(a.albedo, mk2(trace_result.x, trace_result.y), s_lut) : mk3(0, 0, 0);
@@ -441,29 +444,85 @@ struct BlurArgs {
 // is decoded once per block — depth (D24 -> float), normal (bilinear of 4 full-res texels,
 // octahedral decode, normalise; blur.comp:63) and reflection colour — instead of once per tap:
 // the reference shader repeats that work up to 529 times per pixel.
+//
+// The kernel is VALU-bound (rocprof: 98 % VALU-active), so the tap loop is built around packed-f32
+// instructions: a thread resolves the two vertically adjacent pixels A = (x, 2y), B = (x, 2y+1) in
+// the two lanes of v_pk_* ops; every staged tap is read once (ds_read_b128 + ds_read_b32) and
+// broadcast to both lanes.  Summation order per pixel is the shader's (i outer, j inner).
+// The tap weights are smooth functions, so they may differ from the shader's expression by
+// rounding noise (~1e-6 against a 1e-3 / one-UNORM8-step tolerance): exp(-(i^2+j^2)/e) is the
+// product of two running Gaussians advanced by recurrence (E(k+1) = E(k)*rho(k), rho(k+1) =
+// rho(k)*exp(-2/e)), the bilateral term uses a reciprocal-multiply, colour is accumulated in
+// UNORM8 code units and scaled by 1/255 once.
 #define BLUR_BX 32
 #define BLUR_BY 16
 #define BLUR_R 11
 #define BLUR_TW (BLUR_BX + 2 * BLUR_R)
 #define BLUR_TH (BLUR_BY + 2 * BLUR_R)
+#define BLUR_THREADS (BLUR_BX * BLUR_BY / 2)
 
-__global__ __launch_bounds__(BLUR_BX * BLUR_BY) void k_sssr_blur(BlurArgs a) {
-  // staged tile, one float4 {normal.xyz, depth} + one packed RGBA8 reflection texel per pixel:
-  // a tap is one ds_read_b128 + one ds_read_b32 (the kernel is LDS-issue bound)
+typedef float v2f __attribute__((ext_vector_type(2)));
+VKR_DEV v2f splat2(float a) { return (v2f){a, a}; }
+VKR_DEV v2f exp2_2(v2f x) { return (v2f){__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+
+struct BlurCentre {  // per output pixel
+  f3 normal;
+  float depth, k_bilateral, g, neg_inv_e_log2;
+  int r, tc;
+};
+
+// accumulators: xyz = sum w * colour (UNORM8 code units), w = sum w
+VKR_DEV void blur_tap(const float4* s_nd, const uint32_t* s_refl, const BlurCentre& c, int t, float wg, f4& acc) {
+  const float4 nd = s_nd[t];
+  const uint32_t col = s_refl[t];
+  const float bil = vmax(__builtin_fmaf(-fabsf(c.depth - nd.w), c.k_bilateral, 1.0f), 0.0f);
+  const float nw = vmax(__builtin_fmaf(c.normal.z, nd.z, __builtin_fmaf(c.normal.y, nd.y, c.normal.x * nd.x)), 0.0f);
+  const float w = (wg * bil) * nw;
+  acc.x = __builtin_fmaf(w, (float)(col & 0xFFu), acc.x);
+  acc.y = __builtin_fmaf(w, (float)((col >> 8) & 0xFFu), acc.y);
+  acc.z = __builtin_fmaf(w, (float)((col >> 16) & 0xFFu), acc.z);
+  acc.w += w;
+}
+
+// one pixel on its own (rows of the pair with different radii, or a missing partner row)
+VKR_DEV f4 blur_single(const float4* s_nd, const uint32_t* s_refl, const BlurCentre& c) {
+  f4 acc = mk4(0, 0, 0, 0);
+  const float kappa = __builtin_amdgcn_exp2f(2.0f * c.neg_inv_e_log2);  // exp(-2/e)
+  const int r = c.r;
+  // E(-r) and rho(-r) = exp(-(2*(-r)+1)/e)
+  const float e_start = __builtin_amdgcn_exp2f((float)(r * r) * c.neg_inv_e_log2);
+  const float rho_start = __builtin_amdgcn_exp2f((float)(1 - 2 * r) * c.neg_inv_e_log2);
+  float ei = e_start, rho_i = rho_start;
+#pragma unroll 1
+  for (int i = -r; i <= r; i++) {
+    const float gi = c.g * ei;
+    float ej = e_start, rho_j = rho_start;
+#pragma unroll 1
+    for (int j = -r; j <= r; j++) {
+      blur_tap(s_nd, s_refl, c, c.tc + i + j * BLUR_TW, gi * ej, acc);
+      ej *= rho_j; rho_j *= kappa;
+    }
+    ei *= rho_i; rho_i *= kappa;
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
+  // staged tile, one float4 {normal.xyz, depth} + one packed RGBA8 reflection texel per pixel
   __shared__ float4 s_nd[BLUR_TH * BLUR_TW];
   __shared__ uint32_t s_refl[BLUR_TH * BLUR_TW];
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
-  srgb_lut_stage(s_lut, threadIdx.y * BLUR_BX + threadIdx.x, BLUR_BX * BLUR_BY);
-
   const int tid = threadIdx.y * BLUR_BX + threadIdx.x;
+  srgb_lut_stage(s_lut, tid, BLUR_THREADS);
+
   const int bx0 = a.out.ox + blockIdx.x * BLUR_BX - BLUR_R;  // frame coordinates of the tile origin
   const int by0 = a.out.oy + blockIdx.y * BLUR_BY - BLUR_R;
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
-  for (int t = tid; t < BLUR_TW * BLUR_TH; t += BLUR_BX * BLUR_BY) {
+  for (int t = tid; t < BLUR_TW * BLUR_TH; t += BLUR_THREADS) {
     const int tx = t % BLUR_TW, ty = t / BLUR_TW;
     const int px = bx0 + tx, py = by0 + ty;
     const f2 uv = mk2((float)px / tex_size.x, (float)py / tex_size.y);
-    const f3 n = decode_normal(sample<FmtRG16U>(a.normal, uv));
+    const f3 n = decode_normal_fast(sample<FmtRG16U>(a.normal, uv));  // only enters the normal weight
     s_nd[t] = make_float4(n.x, n.y, n.z, fetch<FmtD24>(a.depth1, px, py));
     // texelFetch out of the frame -> 0
     const bool inside = px >= 0 && py >= 0 && px < a.refl.fw && py < a.refl.fh;
@@ -472,110 +531,114 @@ __global__ __launch_bounds__(BLUR_BX * BLUR_BY) void k_sssr_blur(BlurArgs a) {
   __syncthreads();
 
   const int lx = blockIdx.x * BLUR_BX + threadIdx.x;
-  const int ly = blockIdx.y * BLUR_BY + threadIdx.y;
-  if (lx >= a.out.w || ly >= a.out.h) return;
-  const int gx = a.out.ox + lx, gy = a.out.oy + ly;
-  const f2 screen_uv = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
-  float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
-  roughness = mixf(0.0f, a.max_roughness, roughness);
-  const int tc = (threadIdx.y + BLUR_R) * BLUR_TW + (threadIdx.x + BLUR_R);
-  const float center_depth = s_nd[tc].w;
-  const f3 center_normal = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
-  float sigma = mixf(0.4f, 4.0f, roughness);
-  if (a.disable_blur != 0) sigma = 0.35f;
-  const int r = min(f2i(floorf(3.0f * sigma - 0.01f)), BLUR_R);
-  const float g = 1.0f / (((2.0f * VKR_PI) * sigma) * sigma);
-  const float e = (2.0f * sigma) * sigma;
-  // The tap weights are smooth functions, so this loop is free to differ from the shader's
-  // evaluation order by rounding noise (~1e-6, against a 1e-3 / one-UNORM8-step tolerance):
-  //  * exp(-(i^2+j^2)/e) = E[|i|] * E[|j|] with E[k+1] = E[k] * q_k, q_{k+1} = q_k * exp(-2/e):
-  //    two hardware exp2 per pixel instead of one per tap;
-  //  * the four taps (+-i, +-j) share one Gaussian weight and are processed as two packed pairs
-  //    (v_pk_fma_f32 / v_pk_mul_f32: two taps per instruction);
-  //  * colour is accumulated in UNORM8 code units and scaled by 1/255 once.
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  const float k_bilateral = 1000.0f / center_depth;
-  const float q0 = __builtin_amdgcn_exp2f(-1.4426950408889634f / e);  // exp(-1/e)
-  const float kq = q0 * q0;                                           // exp(-2/e)
-  v2f acc_r = {0.0f, 0.0f}, acc_g = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f}, acc_w = {0.0f, 0.0f};
-  const v2f cnx = {center_normal.x, center_normal.x}, cny = {center_normal.y, center_normal.y}, cnz = {center_normal.z, center_normal.z};
-  const v2f cd2 = {center_depth, center_depth}, kb2 = {k_bilateral, k_bilateral}, one2 = {1.0f, 1.0f};
-  // two taps ta, tb sharing the Gaussian weight wg
-  auto tap_pair = [&](int ta, int tb, float wg) {
-    const float4 na = s_nd[ta], nb = s_nd[tb];
-    const uint32_t ca = s_refl[ta], cb = s_refl[tb];
-    const v2f dz = cd2 - (v2f){na.w, nb.w};
-    v2f bil = __builtin_elementwise_fma(-__builtin_elementwise_abs(dz), kb2, one2);
-    v2f nw = __builtin_elementwise_fma(cnz, (v2f){na.z, nb.z}, __builtin_elementwise_fma(cny, (v2f){na.y, nb.y}, cnx * (v2f){na.x, nb.x}));
-    bil = __builtin_elementwise_max(bil, (v2f){0.0f, 0.0f});
-    nw = __builtin_elementwise_max(nw, (v2f){0.0f, 0.0f});
-    const v2f w = (v2f){wg, wg} * bil * nw;
-    acc_r = __builtin_elementwise_fma(w, (v2f){(float)(ca & 0xFFu), (float)(cb & 0xFFu)}, acc_r);
-    acc_g = __builtin_elementwise_fma(w, (v2f){(float)((ca >> 8) & 0xFFu), (float)((cb >> 8) & 0xFFu)}, acc_g);
-    acc_b = __builtin_elementwise_fma(w, (v2f){(float)((ca >> 16) & 0xFFu), (float)((cb >> 16) & 0xFFu)}, acc_b);
-    acc_w += w;
-  };
-  {  // centre tap: bilateral weight 1, normal weight |n|^2-ish (dot of the two decodes)
-    const float4 nc = s_nd[tc];
-    const uint32_t cc = s_refl[tc];
-    const float nw = vmax((center_normal.x * nc.x + center_normal.y * nc.y) + center_normal.z * nc.z, 0.0f);
-    const float w = g * nw;  // |cd - cd| = 0 -> bilateral 1
-    acc_r.x = w * (float)(cc & 0xFFu); acc_g.x = w * (float)((cc >> 8) & 0xFFu); acc_b.x = w * (float)((cc >> 16) & 0xFFu);
-    acc_w.x = w;
-  }
-  {  // the two axes: (+-k, 0) and (0, +-k)
-    float ek = 1.0f, q = q0;
-#pragma unroll 1
-    for (int k = 1; k <= r; k++) {
-      ek *= q; q *= kq;  // ek = exp(-k^2/e)
-      const float wg = g * ek;
-      tap_pair(tc - k, tc + k, wg);
-      tap_pair(tc - k * BLUR_TW, tc + k * BLUR_TW, wg);
-    }
-  }
-  {  // the four quadrants: (+-i, +-j), i, j >= 1
-    float ei = 1.0f, qi = q0;
-#pragma unroll 1
-    for (int i = 1; i <= r; i++) {
-      ei *= qi; qi *= kq;
-      const float gi = g * ei;
-      float ej = 1.0f, qj = q0;
-#pragma unroll 1
-      for (int j = 1; j <= r; j++) {
-        ej *= qj; qj *= kq;
-        const float wg = gi * ej;
-        const int up = tc - j * BLUR_TW, dn = tc + j * BLUR_TW;
-        tap_pair(up - i, up + i, wg);
-        tap_pair(dn - i, dn + i, wg);
-      }
-    }
-  }
-  float weight_sum = acc_w.x + acc_w.y;
-  f3 color = mk3(acc_r.x + acc_r.y, acc_g.x + acc_g.y, acc_b.x + acc_b.y);
-  color = color * (1.0f / 255.0f);
-  color = color / vmax(weight_sum, 0.001f);
+  const int lyA = blockIdx.y * BLUR_BY + 2 * threadIdx.y;
+  if (lx >= a.out.w || lyA >= a.out.h) return;
+  const bool has_b = lyA + 1 < a.out.h;
 
-  bool reprojected = false;
-  const f2 velocity = sample<FmtRG16F>(a.velocity, screen_uv);
-  const float delta_len = length(velocity);
-  const f2 prev_uv = screen_uv + velocity;
-  if (prev_uv.x >= 0.0f && prev_uv.y >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y <= 1.0f) {
-    const f3 vc = reconstruct_view_vec(screen_uv, sample<FmtD24>(a.depth1, screen_uv), a.pr);
-    const f3 v_world_cur = xyz(mul(a.inverse_camera, mk4(vc.x, vc.y, vc.z, 1.0f)));
-    const f3 vp = reconstruct_view_vec(prev_uv, sample<FmtD24>(a.hist_depth1, prev_uv), a.pr);
-    const f3 v_world_prev = xyz(mul(a.prev_inverse_camera, mk4(vp.x, vp.y, vp.z, 1.0f)));
-    const f3 v_camera = xyz(mul(a.inverse_camera, mk4(0, 0, 0, 1)));
-    const float error = length(v_world_cur - v_world_prev);
-    const float pixel_dist = length(v_world_cur - v_camera);
-    reprojected = (delta_len < 0.0001f) || (error < vclamp((0.1f * pixel_dist) * delta_len, 0.01f, 0.1f));
+  // per-pixel set-up (blur.comp:34-55) for A and B
+  BlurCentre c[2];
+  f2 uv_c[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int gx = a.out.ox + lx, gy = a.out.oy + lyA + k;
+    uv_c[k] = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
+    float roughness = sample_srgb_channel(a.material, uv_c[k], 1, s_lut);
+    roughness = mixf(0.0f, a.max_roughness, roughness);
+    c[k].tc = (2 * threadIdx.y + k + BLUR_R) * BLUR_TW + (threadIdx.x + BLUR_R);
+    c[k].depth = s_nd[c[k].tc].w;
+    c[k].normal = decode_normal_fast(sample<FmtRG16U>(a.normal, uv_c[k]));
+    float sigma = mixf(0.4f, 4.0f, roughness);
+    if (a.disable_blur != 0) sigma = 0.35f;
+    c[k].r = min(f2i(floorf(3.0f * sigma - 0.01f)), BLUR_R);
+    c[k].g = 1.0f / (((2.0f * VKR_PI) * sigma) * sigma);
+    const float e = (2.0f * sigma) * sigma;
+    c[k].neg_inv_e_log2 = -1.4426950408889634f / e;
+    c[k].k_bilateral = 1000.0f / c[k].depth;
   }
-  if (a.accumulate == 0) reprojected = false;
-  if (reprojected) {
-    const f3 history_color = sample<FmtRGBA8>(a.history, screen_uv);  // screen_uv, not prev_uv (blur.comp:103)
-    color = mix3(history_color, color, 0.1f);
+
+  f4 accA, accB = mk4(0, 0, 0, 0);
+  if (!has_b || c[0].r != c[1].r) {
+    accA = blur_single(s_nd, s_refl, c[0]);
+    if (has_b) accB = blur_single(s_nd, s_refl, c[1]);
+  } else {
+    // paired path: lane x = pixel A, lane y = pixel B, same radius r.  A's rows are jA = -r..r,
+    // B's rows jB = jA - 1; the staged row tcA + jA*TW serves both for jA = -r+1..r.
+    const int r = c[0].r;
+    const int tcA = c[0].tc;
+    const v2f cnx = {c[0].normal.x, c[1].normal.x}, cny = {c[0].normal.y, c[1].normal.y}, cnz = {c[0].normal.z, c[1].normal.z};
+    const v2f cd = {c[0].depth, c[1].depth}, kb = {c[0].k_bilateral, c[1].k_bilateral}, g2 = {c[0].g, c[1].g};
+    const v2f nie = {c[0].neg_inv_e_log2, c[1].neg_inv_e_log2};
+    const v2f kappa = exp2_2(2.0f * nie);
+    const v2f e_edge = exp2_2((float)(r * r) * nie);             // E(+-r)
+    const v2f rho_edge = exp2_2((float)(1 - 2 * r) * nie);       // rho(-r)
+    // first paired row jA = -r+1: lane A sits at E(-r+1), lane B at E(-r)
+    const v2f ej_first = {e_edge.x * rho_edge.x, e_edge.y};
+    const v2f rhoj_first = {rho_edge.x * kappa.x, rho_edge.y};
+    v2f acc_r = {0.0f, 0.0f}, acc_g = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f}, acc_w = {0.0f, 0.0f};
+    f4 edgeA = mk4(0, 0, 0, 0), edgeB = mk4(0, 0, 0, 0);
+    v2f ei = e_edge, rho_i = rho_edge;
+    const v2f one2 = {1.0f, 1.0f}, zero2 = {0.0f, 0.0f};
+#pragma unroll 1
+    for (int i = -r; i <= r; i++) {
+      const v2f gi = g2 * ei;
+      const int col = tcA + i;
+      // unpaired ends of the column: A's row -r and B's row +r (tcB + r*TW = tcA + (r+1)*TW)
+      blur_tap(s_nd, s_refl, c[0], col - r * BLUR_TW, gi.x * e_edge.x, edgeA);
+      blur_tap(s_nd, s_refl, c[1], col + (r + 1) * BLUR_TW, gi.y * e_edge.y, edgeB);
+      v2f ej = ej_first, rho_j = rhoj_first;
+      int t = col - (r - 1) * BLUR_TW;
+#pragma unroll 2
+      for (int j = -r + 1; j <= r; j++, t += BLUR_TW) {
+        const float4 nd = s_nd[t];
+        const uint32_t colr = s_refl[t];
+        const v2f dz = cd - splat2(nd.w);
+        v2f bil = __builtin_elementwise_fma(-__builtin_elementwise_abs(dz), kb, one2);
+        v2f nw = __builtin_elementwise_fma(cnz, splat2(nd.z), __builtin_elementwise_fma(cny, splat2(nd.y), cnx * splat2(nd.x)));
+        bil = __builtin_elementwise_max(bil, zero2);
+        nw = __builtin_elementwise_max(nw, zero2);
+        const v2f w = ((gi * ej) * bil) * nw;
+        acc_r = __builtin_elementwise_fma(w, splat2((float)(colr & 0xFFu)), acc_r);
+        acc_g = __builtin_elementwise_fma(w, splat2((float)((colr >> 8) & 0xFFu)), acc_g);
+        acc_b = __builtin_elementwise_fma(w, splat2((float)((colr >> 16) & 0xFFu)), acc_b);
+        acc_w += w;
+        ej *= rho_j; rho_j *= kappa;
+      }
+      ei *= rho_i; rho_i *= kappa;
+    }
+    accA = mk4(acc_r.x + edgeA.x, acc_g.x + edgeA.y, acc_b.x + edgeA.z, acc_w.x + edgeA.w);
+    accB = mk4(acc_r.y + edgeB.x, acc_g.y + edgeB.y, acc_b.y + edgeB.z, acc_w.y + edgeB.w);
   }
-  *texel_ptr<uint32_t>(a.out, lx, ly) =
-      float_to_unorm8(color.x) | (float_to_unorm8(color.y) << 8) | (float_to_unorm8(color.z) << 16);
+
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    if (k == 1 && !has_b) break;
+    const f4 acc = k == 0 ? accA : accB;
+    f3 color = mk3(acc.x, acc.y, acc.z) * (1.0f / 255.0f);
+    color = color / vmax(acc.w, 0.001f);
+    const f2 screen_uv = uv_c[k];
+    // temporal part (blur.comp:79-105)
+    bool reprojected = false;
+    const f2 velocity = sample<FmtRG16F>(a.velocity, screen_uv);
+    const float delta_len = length(velocity);
+    const f2 prev_uv = screen_uv + velocity;
+    if (prev_uv.x >= 0.0f && prev_uv.y >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y <= 1.0f) {
+      const f3 vc = reconstruct_view_vec(screen_uv, sample<FmtD24>(a.depth1, screen_uv), a.pr);
+      const f3 v_world_cur = xyz(mul(a.inverse_camera, mk4(vc.x, vc.y, vc.z, 1.0f)));
+      const f3 vp = reconstruct_view_vec(prev_uv, sample<FmtD24>(a.hist_depth1, prev_uv), a.pr);
+      const f3 v_world_prev = xyz(mul(a.prev_inverse_camera, mk4(vp.x, vp.y, vp.z, 1.0f)));
+      const f3 v_camera = xyz(mul(a.inverse_camera, mk4(0, 0, 0, 1)));
+      const float error = length(v_world_cur - v_world_prev);
+      const float pixel_dist = length(v_world_cur - v_camera);
+      reprojected = (delta_len < 0.0001f) || (error < vclamp((0.1f * pixel_dist) * delta_len, 0.01f, 0.1f));
+    }
+    if (a.accumulate == 0) reprojected = false;
+    if (reprojected) {
+      const f3 history_color = sample<FmtRGBA8>(a.history, screen_uv);  // screen_uv, not prev_uv (blur.comp:103)
+      color = mix3(history_color, color, 0.1f);
+    }
+    *texel_ptr<uint32_t>(a.out, lx, lyA + k) =
+        float_to_unorm8(color.x) | (float_to_unorm8(color.y) << 8) | (float_to_unorm8(color.z) << 16);
+  }
 }
 
 }  // namespace vkr
@@ -680,7 +743,8 @@ extern "C" int vkr_sssr_blur(const vkr_img* depth, const vkr_img* normal, const 
     set_error("sssr_blur: max_roughness must be in [0,1] (reference slider range, advanced_ssr.cpp:558)");
     return VKR_ERR_EXTENT;
   }
-  dim3 block(BLUR_BX, BLUR_BY);
-  hipLaunchKernelGGL(k_sssr_blur, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  dim3 block(BLUR_BX, BLUR_BY / 2);  // each thread resolves two vertically adjacent pixels
+  dim3 grid((a.out.w + BLUR_BX - 1) / BLUR_BX, (a.out.h + BLUR_BY - 1) / BLUR_BY);
+  hipLaunchKernelGGL(k_sssr_blur, grid, block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_blur");
 }

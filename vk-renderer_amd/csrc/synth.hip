@@ -129,9 +129,33 @@ __global__ __launch_bounds__(256) void k_stream_read(const float4* __restrict__ 
   if (threadIdx.x == 0) sink[blockIdx.x % sink_len] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
+// Self-test (tests only): counts disagreements between the cheap exact forms and their definitions.
+//  [0] div_normal(nf, d(f-n)-f) vs IEEE '/' over all 2^24 stored depths, (n,f) = (znear, zfar)
+//  [1] div_normal(a, b) vs a / b on a hashed set of normal-range operands
+//  [2..4] d24 / unorm16 / unorm8 decode vs the correctly rounded quotient
+__global__ __launch_bounds__(256) void k_selftest_division(uint32_t* counters, float znear, float zfar) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 2^24-1
+  const float d = d24_to_float(i);
+  const float ref = (znear * zfar) / (d * (zfar - znear) - zfar);
+  if (linearize_depth2_unorm(d, znear, zfar) != ref) atomicAdd(&counters[0], 1u);
+  const float a = __uint_as_float(0x30000000u + (pcg(i) & 0x1FFFFFFFu));        // ~4.7e-10 .. 1.8e+19
+  float b = __uint_as_float(0x30000000u + (pcg(i ^ 0x9E3779B9u) & 0x1FFFFFFFu));
+  if (i & 1u) b = -b;
+  if (div_normal(a, b) != a / b) atomicAdd(&counters[1], 1u);
+  if (d != (float)i / 16777215.0f) atomicAdd(&counters[2], 1u);
+  if (i < 65536u && unorm16_to_float(i) != (float)i / 65535.0f) atomicAdd(&counters[3], 1u);
+  if (i < 256u && unorm8_to_float(i) != (float)i / 255.0f) atomicAdd(&counters[4], 1u);
+}
+
 }  // namespace vkr
 
 using namespace vkr;
+
+extern "C" int vkr_selftest_division(uint32_t* device_counters5, float znear, float zfar, void* stream) {
+  if (!device_counters5) { set_error("selftest_division: NULL counters"); return VKR_ERR_NULL; }
+  hipLaunchKernelGGL(k_selftest_division, dim3((1u << 24) / 256), dim3(256), 0, (hipStream_t)stream, device_counters5, znear, zfar);
+  return launch_status("selftest_division");
+}
 
 extern "C" int vkr_synth_gbuffer(const vkr_img* depth, const vkr_img* normal, const vkr_img* albedo,
                                  const vkr_img* material, const vkr_img* velocity, const vkr_synth_params* params,
