@@ -577,7 +577,8 @@ __global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
     v2f acc_r = {0.0f, 0.0f}, acc_g = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f}, acc_w = {0.0f, 0.0f};
     f4 edgeA = mk4(0, 0, 0, 0), edgeB = mk4(0, 0, 0, 0);
     v2f ei = e_edge, rho_i = rho_edge;
-    const v2f one2 = {1.0f, 1.0f}, zero2 = {0.0f, 0.0f};
+    const v2f zero2 = {0.0f, 0.0f}, one2 = {1.0f, 1.0f};
+    const v2f kcd = kb * cd;  // bilateral term: 1 - min(|k*cd - k*d|, 1)
 #pragma unroll 1
     for (int i = -r; i <= r; i++) {
       const v2f gi = g2 * ei;
@@ -585,23 +586,23 @@ __global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
       // unpaired ends of the column: A's row -r and B's row +r (tcB + r*TW = tcA + (r+1)*TW)
       blur_tap(s_nd, s_refl, c[0], col - r * BLUR_TW, gi.x * e_edge.x, edgeA);
       blur_tap(s_nd, s_refl, c[1], col + (r + 1) * BLUR_TW, gi.y * e_edge.y, edgeB);
-      v2f ej = ej_first, rho_j = rhoj_first;
+      v2f wj = gi * ej_first, rho_j = rhoj_first;  // running g * E(i) * E(j)
       int t = col - (r - 1) * BLUR_TW;
 #pragma unroll 2
       for (int j = -r + 1; j <= r; j++, t += BLUR_TW) {
         const float4 nd = s_nd[t];
         const uint32_t colr = s_refl[t];
-        const v2f dz = cd - splat2(nd.w);
-        v2f bil = __builtin_elementwise_fma(-__builtin_elementwise_abs(dz), kb, one2);
+        const v2f kdz = __builtin_elementwise_fma(-kb, splat2(nd.w), kcd);
+        const v2f m = __builtin_elementwise_min(__builtin_elementwise_abs(kdz), one2);
         v2f nw = __builtin_elementwise_fma(cnz, splat2(nd.z), __builtin_elementwise_fma(cny, splat2(nd.y), cnx * splat2(nd.x)));
-        bil = __builtin_elementwise_max(bil, zero2);
         nw = __builtin_elementwise_max(nw, zero2);
-        const v2f w = ((gi * ej) * bil) * nw;
+        const v2f tw = wj * nw;
+        const v2f w = __builtin_elementwise_fma(-m, tw, tw);  // wj * nw * (1 - m)
         acc_r = __builtin_elementwise_fma(w, splat2((float)(colr & 0xFFu)), acc_r);
         acc_g = __builtin_elementwise_fma(w, splat2((float)((colr >> 8) & 0xFFu)), acc_g);
         acc_b = __builtin_elementwise_fma(w, splat2((float)((colr >> 16) & 0xFFu)), acc_b);
         acc_w += w;
-        ej *= rho_j; rho_j *= kappa;
+        wj *= rho_j; rho_j *= kappa;
       }
       ei *= rho_i; rho_i *= kappa;
     }
