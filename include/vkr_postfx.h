@@ -202,6 +202,12 @@ int vkr_taa_resolve(const vkr_img* history_color, const vkr_img* history_depth,
                     const vkr_img* current_depth, const vkr_img* velocity, const vkr_img* color,
                     const vkr_img* out_color, const vkr_reproject_params* params, void* stream);
 
+/* program "ssr": ssr.cpp:10-73 + ssr/shader.frag:27-102 (bindings 0 normal, 1 depth [NEAREST,
+ * clamp-to-border U], 2 frame colour, 3 SSRParams, 4 material; colour attachment RGBA8_UNORM).
+ * depth: all mips of the full-res depth image.                                                  */
+int vkr_ssr(const vkr_img* normal, const vkr_img* depth, const vkr_img* frame, const vkr_ssr_params* params,
+            const vkr_img* material, const vkr_img* out, void* stream);
+
 /* synthetic G-buffer generator (no reference program).  Any of the
  * colour outputs may be NULL when VKR_SYNTH_DEPTH_ONLY is set.                          */
 int vkr_synth_gbuffer(const vkr_img* depth, const vkr_img* normal, const vkr_img* albedo,

@@ -132,3 +132,18 @@ def test_gtao_only_config1(oracle_lib):
         ref.gtao_main(two_directions=two)
         gpu.gtao_main(two_directions=two)
         _compare(ref, gpu, ("raw",), budget=1e-4)
+
+
+@pytest.mark.parametrize("size", [(256, 144), (640, 360)])
+def test_simple_ssr(size, oracle_lib):
+    """src/ssr.cpp + ssr/shader.frag (generic hierarchical_raymarch, nearest depth sampler)."""
+    ref, gpu = _pair(*size, oracle_lib)
+    ref.synth()
+    ref.downsample()
+    _sync_inputs(ref, gpu)
+    ref.ssr_simple()
+    gpu.ssr_simple()
+    _compare(ref, gpu, ("ssr_out",), budget=1e-4)
+    lit = int((ref.ssr_out.raw(0)[..., :3].max(axis=-1) > 0).sum())
+    print(f"[parity] ssr_out lit texels {lit}")
+    assert lit > 0.01 * size[0] * size[1], "simple SSR produced (almost) no reflections: the test scene does not exercise it"

@@ -134,6 +134,7 @@ ENTRY_ARGS = {
     "gtao_accumulate": [_IMG, _IMG, _IMG, _IMG, _IMG, _IMG, P(GtaoAccumParams), P(GtaoAccumPush)],
     "taa_resolve": [_IMG, _IMG, _IMG, _IMG, _IMG, _IMG, P(ReprojectParams)],
     "synth_gbuffer": [_IMG, _IMG, _IMG, _IMG, _IMG, P(SynthParams)],
+    "ssr": [_IMG, _IMG, _IMG, P(SsrParams), _IMG, _IMG],
 }
 
 

@@ -238,6 +238,18 @@ class PostFxChain:
         self.call("taa_resolve", C.byref(self.taa_hist.desc()), C.byref(self.prev_depth.desc()), C.byref(self.depth.desc()),
                   C.byref(self.velocity.desc()), C.byref(color.desc()), C.byref(self.taa_target.desc()), C.byref(rp))
 
+    def ssr_simple(self, color=None):
+        """src/ssr.cpp add_ssr_pass: full-res mirror SSR into an RGBA8_UNORM target (create_ssr_tex)."""
+        if not hasattr(self, "ssr_out"):
+            self.ssr_out = ImageBuf(abi.FMT_RGBA8_UNORM, self.albedo.width, self.albedo.height, device=self.device,
+                                    full=self.albedo.full, origin=self.albedo.origin)
+        p = abi.SsrParams()
+        p.normal_mat = abi.Mat4.from_np(self.setup.normal_mat)
+        p.fovy, p.aspect, p.znear, p.zfar = [float(v) for v in self.setup.fazz]
+        color = color or self.albedo
+        self.call("ssr", C.byref(self.normal.desc()), C.byref(self.depth.desc()), C.byref(color.desc()), C.byref(p),
+                  C.byref(self.material.desc()), C.byref(self.ssr_out.desc()))
+
     def frame(self):
         """One steady-state frame of the chain: D1 D2 S1 S2 S3 G1 G2 G3 T (main.cpp:347-391)."""
         self.downsample()

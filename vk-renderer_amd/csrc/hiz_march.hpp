@@ -1,0 +1,105 @@
+// hiz_march.hpp — the hierarchical-Z ray march shared by the stochastic SSR trace (trace.comp) and
+// the simple mirror SSR (ssr/shader.frag): one step of screen_trace.glsl:17-100 on a pyramid whose
+// per-level descriptors live in LDS.  Exact IEEE sequence (it decides hit / no-hit).
+#pragma once
+#include "vkr_host.hpp"
+
+namespace vkr {
+
+// State of one ray between steps of hierarchical_raymarch_find_hor (trace.comp:206-268).  `position`
+// is always origin + current_t * direction and the mip resolution is screen_size * 2^-mip (exact
+// power-of-two scalings), so (current_t, mip, i, h) is the whole mutable state.
+struct RayConst {
+  f3 origin, direction, inv_direction;
+  f3 normal, view_vec;  // pixel_normal (w0 of the horizon test) and camera_start
+};
+struct RayState { float t, h; int mip, i; };
+struct MarchEnv {
+  const uint4* mip_table;  // LDS: {base lo, base hi, pitch, w | h << 16} per pyramid level
+  int mip_count;
+  f2 screen_size, screen_size_inv;
+  f2 uv_offset_abs;
+  Proj pr;
+  float horizon_d2;  // smallest d2 with sqrtf(d2) >= 0.3f: |v| < 0.3 <=> dot(v,v) < horizon_d2
+};
+
+// One step of the march; returns false when the ray is finished.  HORIZON / PIN_STEPS = 15 / max 80 is
+// hierarchical_raymarch_find_hor (trace.comp:206-268); no horizon / PIN_STEPS = 0 is the generic
+// hierarchical_raymarch (screen_trace.glsl:51-100).
+template <bool HORIZON, int PIN_STEPS>
+VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, int max_steps) {
+  const float scale = __builtin_ldexpf(1.0f, -st.mip), scale_inv = __builtin_ldexpf(1.0f, st.mip);
+  const f2 res = mk2(env.screen_size.x * scale, env.screen_size.y * scale);
+  const f2 res_inv = mk2(env.screen_size_inv.x * scale_inv, env.screen_size_inv.y * scale_inv);
+  const f3 position = rc.origin + st.t * rc.direction;
+  const f2 mip_pos = res * xy(position);
+  // texelFetch(depth_tex, ivec2(p), mip): beyond the last mip or outside the mip extent -> 0
+  float surface_z = 0.0f;
+  if ((unsigned)st.mip < (unsigned)env.mip_count) {
+    const uint4 m = env.mip_table[st.mip];
+    const int tx = f2i(mip_pos.x), ty = f2i(mip_pos.y);
+    if (tx >= 0 && ty >= 0 && tx < (int)(m.w & 0xFFFFu) && ty < (int)(m.w >> 16)) {
+      typedef const __attribute__((address_space(1))) uint32_t* gptr_t;  // a global, not flat, address
+      const uint64_t addr = (((uint64_t)m.y << 32) | m.x) + (uint64_t)ty * m.z + (uint64_t)tx * 4u;
+      surface_z = d24_to_float(*(gptr_t)addr);
+    }
+  }
+  // advance_ray (screen_trace.glsl:17-45)
+  const f2 uv_offset = mk2(rc.direction.x < 0.0f ? -env.uv_offset_abs.x : env.uv_offset_abs.x,
+                           rc.direction.y < 0.0f ? -env.uv_offset_abs.y : env.uv_offset_abs.y);
+  const f2 floor_offset = mk2(rc.direction.x < 0.0f ? 0.0f : 1.0f, rc.direction.y < 0.0f ? 0.0f : 1.0f);
+  f2 xy_plane = mk2(floorf(mip_pos.x), floorf(mip_pos.y)) + floor_offset;
+  xy_plane = xy_plane * res_inv + uv_offset;
+  f3 t = (mk3(xy_plane.x, xy_plane.y, surface_z) - rc.origin) * rc.inv_direction;
+  t.z = rc.direction.z > 0.0f ? t.z : 3.402823466e+38f;
+  const float t_min = vmin(vmin(t.x, t.y), t.z);
+  const bool above_surface = surface_z > position.z;
+  const bool skipped_tile = (t_min != t.z) && above_surface;
+  st.t = above_surface ? t_min : st.t;
+  // trace.comp:245-250: the first 15 steps stay on the finest mip
+  if (st.i >= PIN_STEPS) st.mip += skipped_tile ? 1 : -1;
+  ++st.i;
+  // trace.comp:253-262: horizon tracking around the new position
+  if (HORIZON && st.mip <= 1) {
+    const f3 np = rc.origin + st.t * rc.direction;
+    const f3 v = reconstruct_view_vec(xy(np), surface_z, env.pr) - rc.view_vec;
+    const float d2 = dot(v, v);
+    if (d2 < env.horizon_d2) {  // length(v) < 0.3, decided exactly on the squared length
+      // h only feeds acos() of the (smooth) occlusion term: the hardware rsq is accurate enough
+      const float h2 = dot(rc.normal, v) * __builtin_amdgcn_rsqf(d2);
+      st.h = vmax(st.h, h2);
+    }
+  }
+  return st.i < max_steps && st.mip >= 0;
+}
+
+
+// the LDS descriptor of one pyramid level
+VKR_DEV uint4 mip_descriptor(const Tex& m) {
+  const uint64_t base = (uint64_t)m.p;
+  return make_uint4((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)m.pitch, (uint32_t)m.w | ((uint32_t)m.h << 16));
+}
+// initial_advance_ray (screen_trace.glsl:8-15) at most_detailed_mip = 0
+VKR_DEV float initial_advance(const MarchEnv& env, const RayConst& rc) {
+  const f2 uv_offset = mk2(rc.direction.x < 0.0f ? -env.uv_offset_abs.x : env.uv_offset_abs.x,
+                           rc.direction.y < 0.0f ? -env.uv_offset_abs.y : env.uv_offset_abs.y);
+  const f2 floor_offset = mk2(rc.direction.x < 0.0f ? 0.0f : 1.0f, rc.direction.y < 0.0f ? 0.0f : 1.0f);
+  const f2 cur_pos = env.screen_size * xy(rc.origin);
+  f2 xy_plane = mk2(floorf(cur_pos.x), floorf(cur_pos.y)) + floor_offset;
+  xy_plane = xy_plane * env.screen_size_inv + uv_offset;
+  const f2 t = (xy_plane - xy(rc.origin)) * xy(rc.inv_direction);
+  return vmin(t.x, t.y);
+}
+VKR_DEV f3 safe_inverse(f3 d) {  // screen_trace.glsl:54-57
+  return mk3(d.x != 0.0f ? 1.0f / d.x : 3.402823466e+38f, d.y != 0.0f ? 1.0f / d.y : 3.402823466e+38f,
+             d.z != 0.0f ? 1.0f / d.z : 3.402823466e+38f);
+}
+// smallest float x with sqrtf(x) >= 0.3f: |v| < 0.3f <=> dot(v,v) < x (correctly rounded sqrt is monotone)
+inline float horizon_threshold_d2() {
+  float x = 0.3f * 0.3f;
+  while (sqrtf(x) >= 0.3f) x = nextafterf(x, 0.0f);
+  while (sqrtf(x) < 0.3f) x = nextafterf(x, 1.0f);
+  return x;
+}
+
+}  // namespace vkr

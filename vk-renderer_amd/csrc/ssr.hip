@@ -7,6 +7,7 @@
 // march is a chain of <= 80 dependent texel fetches per ray and the blur up to 23x23 taps,
 // so trace is latency-bound and blur ALU/LDS-bound.
 #include "vkr_host.hpp"
+#include "hiz_march.hpp"
 
 namespace vkr {
 
@@ -69,71 +70,6 @@ VKR_DEV f3 sampleGGXVNDF(f3 Ve, float alpha_x, float alpha_y, float U1, float co
   return normalize(mk3(alpha_x * Nh.x, alpha_y * Nh.y, vmax(0.0f, Nh.z)));
 }
 
-// ---- the Hi-Z march -----------------------------------------------------------------------------
-// State of one ray between steps of hierarchical_raymarch_find_hor (trace.comp:206-268).  `position`
-// is always origin + current_t * direction and the mip resolution is screen_size * 2^-mip (exact
-// power-of-two scalings), so (current_t, mip, i, h) is the whole mutable state.
-struct RayConst {
-  f3 origin, direction, inv_direction;
-  f3 normal, view_vec;  // pixel_normal (w0 of the horizon test) and camera_start
-};
-struct RayState { float t, h; int mip, i; };
-struct MarchEnv {
-  const uint4* mip_table;  // LDS: {base lo, base hi, pitch, w | h << 16} per pyramid level
-  int mip_count;
-  f2 screen_size, screen_size_inv;
-  f2 uv_offset_abs;
-  Proj pr;
-  float horizon_d2;  // smallest d2 with sqrtf(d2) >= 0.3f: |v| < 0.3 <=> dot(v,v) < horizon_d2
-};
-
-// One step of the march; returns false when the ray is finished (trace.comp:241).
-VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st) {
-  const float scale = __builtin_ldexpf(1.0f, -st.mip), scale_inv = __builtin_ldexpf(1.0f, st.mip);
-  const f2 res = mk2(env.screen_size.x * scale, env.screen_size.y * scale);
-  const f2 res_inv = mk2(env.screen_size_inv.x * scale_inv, env.screen_size_inv.y * scale_inv);
-  const f3 position = rc.origin + st.t * rc.direction;
-  const f2 mip_pos = res * xy(position);
-  // texelFetch(depth_tex, ivec2(p), mip): beyond the last mip or outside the mip extent -> 0
-  float surface_z = 0.0f;
-  if ((unsigned)st.mip < (unsigned)env.mip_count) {
-    const uint4 m = env.mip_table[st.mip];
-    const int tx = f2i(mip_pos.x), ty = f2i(mip_pos.y);
-    if (tx >= 0 && ty >= 0 && tx < (int)(m.w & 0xFFFFu) && ty < (int)(m.w >> 16)) {
-      typedef const __attribute__((address_space(1))) uint32_t* gptr_t;  // a global, not flat, address
-      const uint64_t addr = (((uint64_t)m.y << 32) | m.x) + (uint64_t)ty * m.z + (uint64_t)tx * 4u;
-      surface_z = d24_to_float(*(gptr_t)addr);
-    }
-  }
-  // advance_ray (screen_trace.glsl:17-45)
-  const f2 uv_offset = mk2(rc.direction.x < 0.0f ? -env.uv_offset_abs.x : env.uv_offset_abs.x,
-                           rc.direction.y < 0.0f ? -env.uv_offset_abs.y : env.uv_offset_abs.y);
-  const f2 floor_offset = mk2(rc.direction.x < 0.0f ? 0.0f : 1.0f, rc.direction.y < 0.0f ? 0.0f : 1.0f);
-  f2 xy_plane = mk2(floorf(mip_pos.x), floorf(mip_pos.y)) + floor_offset;
-  xy_plane = xy_plane * res_inv + uv_offset;
-  f3 t = (mk3(xy_plane.x, xy_plane.y, surface_z) - rc.origin) * rc.inv_direction;
-  t.z = rc.direction.z > 0.0f ? t.z : 3.402823466e+38f;
-  const float t_min = vmin(vmin(t.x, t.y), t.z);
-  const bool above_surface = surface_z > position.z;
-  const bool skipped_tile = (t_min != t.z) && above_surface;
-  st.t = above_surface ? t_min : st.t;
-  // trace.comp:245-250: the first 15 steps stay on the finest mip
-  if (st.i >= 15) st.mip += skipped_tile ? 1 : -1;
-  ++st.i;
-  // trace.comp:253-262: horizon tracking around the new position
-  if (st.mip <= 1) {
-    const f3 np = rc.origin + st.t * rc.direction;
-    const f3 v = reconstruct_view_vec(xy(np), surface_z, env.pr) - rc.view_vec;
-    const float d2 = dot(v, v);
-    if (d2 < env.horizon_d2) {  // length(v) < 0.3, decided exactly on the squared length
-      // h only feeds acos() of the (smooth) occlusion term: the hardware rsq is accurate enough
-      const float h2 = dot(rc.normal, v) * __builtin_amdgcn_rsqf(d2);
-      st.h = vmax(st.h, h2);
-    }
-  }
-  return st.i < 80 && st.mip >= 0;
-}
-
 // One thread per ray in the prologue / epilogue; the march in between runs in rounds of
 // TRACE_ROUND steps with the block's unfinished rays compacted in LDS between rounds, because
 // rays of one 8x8 tile finish anywhere between 16 and 80 steps (mean 30, per-wave maximum mean 59
@@ -150,11 +86,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   __shared__ int s_count[2];
   const int tid = threadIdx.x;
   srgb_lut_stage(s_lut, tid, TRACE_THREADS);
-  if (tid < 16) {
-    const Tex& m = a.depth.mip[tid < a.depth.count ? tid : 0];
-    const uint64_t base = (uint64_t)m.p;
-    s_mip[tid] = make_uint4((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)m.pitch, (uint32_t)m.w | ((uint32_t)m.h << 16));
-  }
+  if (tid < 16) s_mip[tid] = mip_descriptor(a.depth.mip[tid < a.depth.count ? tid : 0]);
   if (tid < 2) s_count[tid] = 0;
   __syncthreads();
   // 256 threads = 4 waves; wave w owns the 8x8 tile (blockIdx.x*4 + w, blockIdx.y)
@@ -218,26 +150,15 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
 
     rc.origin = ray_start;
     rc.direction = ray_dir;
-    rc.inv_direction = mk3(ray_dir.x != 0.0f ? 1.0f / ray_dir.x : 3.402823466e+38f,
-                           ray_dir.y != 0.0f ? 1.0f / ray_dir.y : 3.402823466e+38f,
-                           ray_dir.z != 0.0f ? 1.0f / ray_dir.z : 3.402823466e+38f);
-    {  // initial_advance_ray (screen_trace.glsl:8-15)
-      const f2 uv_offset = mk2(ray_dir.x < 0.0f ? -env.uv_offset_abs.x : env.uv_offset_abs.x,
-                               ray_dir.y < 0.0f ? -env.uv_offset_abs.y : env.uv_offset_abs.y);
-      const f2 floor_offset = mk2(ray_dir.x < 0.0f ? 0.0f : 1.0f, ray_dir.y < 0.0f ? 0.0f : 1.0f);
-      const f2 cur_pos = env.screen_size * xy(rc.origin);
-      f2 xy_plane = mk2(floorf(cur_pos.x), floorf(cur_pos.y)) + floor_offset;
-      xy_plane = xy_plane * env.screen_size_inv + uv_offset;
-      const f2 t = (xy_plane - xy(rc.origin)) * xy(rc.inv_direction);
-      st.t = vmin(t.x, t.y);
-    }
+    rc.inv_direction = safe_inverse(ray_dir);
+    st.t = initial_advance(env, rc);
     st.h = 0.0f;  // trace.comp:239
     st.mip = 0;
     st.i = 0;
     // round 0: the first 15 steps never leave mip 0, so every ray runs exactly 16 steps here
     running = true;
 #pragma unroll 1
-    for (int k = 0; k < TRACE_ROUND && running; k++) running = march_step(env, rc, st);
+    for (int k = 0; k < TRACE_ROUND && running; k++) running = march_step<true, 15>(env, rc, st, 80);
   }
   // park the unfinished rays in LDS
   if (running) {
@@ -274,7 +195,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
       rs.mip = (int)(int8_t)(mi & 0xFF); rs.i = mi >> 8;
       bool more = true;
 #pragma unroll 1
-      for (int k = 0; k < TRACE_ROUND && more; k++) more = march_step(env, q, rs);
+      for (int k = 0; k < TRACE_ROUND && more; k++) more = march_step<true, 15>(env, q, rs, 80);
       s_rc[15][ray] = rs.t; s_rc[16][ray] = rs.h;
       s_mi[ray] = (rs.mip & 0xFF) | (rs.i << 8);
       if (more) {
@@ -688,12 +609,7 @@ extern "C" int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const
   load_proj(a.pr, params->fovy, params->aspect, params->znear, params->zfar);
   a.frame_random = params->frame_random;
   a.max_roughness = push->max_roughness;
-  {  // |v| < 0.3f  <=>  dot(v,v) < horizon_d2, because correctly rounded sqrtf is monotone
-    float x = 0.3f * 0.3f;
-    while (sqrtf(x) >= 0.3f) x = nextafterf(x, 0.0f);
-    while (sqrtf(x) < 0.3f) x = nextafterf(x, 1.0f);
-    a.horizon_d2 = x;
-  }
+  a.horizon_d2 = horizon_threshold_d2();
   dim3 block(TRACE_THREADS, 1);
   dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 7) / 8);
   hipLaunchKernelGGL(k_sssr_trace, grid, block, 0, (hipStream_t)stream, a);

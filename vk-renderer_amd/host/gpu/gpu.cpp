@@ -158,14 +158,19 @@ void write_binding(VkDescriptorSet set, const SSBOBinding& b) {
 namespace {
 std::map<std::string, ProgramFn>& programs() { static std::map<std::string, ProgramFn> p; return p; }
 
-vkr_img tex(const LaunchState& st, uint32_t slot, SetSlot::Kind kind, const char* prog) {
+// `nearest_border`: the one non-default sampler of the path (ssr.cpp:21-28: NEAREST, U clamp-to-border)
+vkr_img tex(const LaunchState& st, uint32_t slot, SetSlot::Kind kind, const char* prog, bool nearest_border = false) {
   const SetSlot& s = st.set ? st.set->slots[slot] : SetSlot{};
   if (!st.set || s.kind != kind || !s.view.image)
     throw std::runtime_error{std::string{prog} + ": binding " + std::to_string(slot) + " is not bound as expected"};
   if (kind == SetSlot::Texture) {
+    if (!s.sampler) throw std::runtime_error{std::string{prog} + ": binding " + std::to_string(slot) + " has no sampler"};
     const auto& si = sampler_info(s.sampler);
-    if (!s.sampler || si.magFilter != VK_FILTER_LINEAR || si.addressModeU != VK_SAMPLER_ADDRESS_MODE_CLAMP_TO_EDGE)
-      throw std::runtime_error{std::string{prog} + ": only gpu::DEFAULT_SAMPLER is implemented on this path"};
+    const bool is_default = si.magFilter == VK_FILTER_LINEAR && si.addressModeU == VK_SAMPLER_ADDRESS_MODE_CLAMP_TO_EDGE;
+    const bool is_nearest_border = si.magFilter == VK_FILTER_NEAREST && si.minFilter == VK_FILTER_NEAREST &&
+                                   si.addressModeU == VK_SAMPLER_ADDRESS_MODE_CLAMP_TO_BORDER && si.addressModeV == VK_SAMPLER_ADDRESS_MODE_CLAMP_TO_EDGE;
+    if (nearest_border ? !is_nearest_border : !is_default)
+      throw std::runtime_error{std::string{prog} + ": binding " + std::to_string(slot) + ": sampler not implemented on this path"};
   }
   return s.view.image->describe(s.view.range.base_mip, s.view.range.mips_count);
 }
@@ -267,6 +272,14 @@ void register_hot_path_programs() {
       vkr_img hist = tex(st, 0, T, P), hdepth = tex(st, 1, T, P), depth = tex(st, 2, T, P), velocity = tex(st, 3, T, P);
       vkr_img color = tex(st, 4, T, P), out = tex(st, 5, S, P);
       return vkr_taa_resolve(&hist, &hdepth, &depth, &velocity, &color, &out, ubo<vkr_reproject_params>(st, 6, P), st.stream);
+    });
+    // ssr/shader.frag: set {0 normal, 1 depth (nearest/border sampler), 2 frame, 3 SSRParams, 4 material}; attachment {out}
+    create_program("ssr", [=](LaunchState& st) {
+      const char* P = "ssr";
+      if (st.attachments.size() != 1) throw std::runtime_error{"ssr: expects one colour attachment"};
+      vkr_img normal = tex(st, 0, T, P), depth = tex(st, 1, T, P, true), frame = tex(st, 2, T, P), material = tex(st, 4, T, P);
+      vkr_img out = st.attachments[0].image->describe(st.attachments[0].range.base_mip, 1);
+      return vkr_ssr(&normal, &depth, &frame, ubo<vkr_ssr_params>(st, 3, P), &material, &out, st.stream);
     });
     // synthetic G-buffer "raster" program: attachments {albedo, normal, material, velocity, depth} or {depth}
     create_program("synthetic_gbuffer", [=](LaunchState& st) {
