@@ -129,6 +129,20 @@ typedef struct vkr_ssr_params {
   float fovy, aspect, znear, zfar;
 } vkr_ssr_params;
 
+/* ShaderConstants of the deferred-shading composite, defered_shading.cpp:4-12 / shader.frag:15-23 */
+typedef struct vkr_shading_params {
+  vkr_mat4 inverse_camera;
+  vkr_mat4 camera;
+  vkr_mat4 shadow_mvp;
+  float fovy, aspect, znear, zfar;
+} vkr_shading_params;
+
+/* push constants, defered_shading.cpp:68-72 / shader.frag:30-33 (vec2 + uint) */
+typedef struct vkr_shading_push {
+  float    min_max_roughness[2];
+  uint32_t show_ao;
+} vkr_shading_push;
+
 /* Parameters of the synthetic G-buffer generator (replaces the raster stage
  * scene_renderer.cpp:140-220 + gbuf/opaque_taa.{vert,frag}). */
 typedef struct vkr_synth_params {
@@ -207,6 +221,18 @@ int vkr_taa_resolve(const vkr_img* history_color, const vkr_img* history_depth,
  * depth: all mips of the full-res depth image.                                                  */
 int vkr_ssr(const vkr_img* normal, const vkr_img* depth, const vkr_img* frame, const vkr_ssr_params* params,
             const vkr_img* material, const vkr_img* out, void* stream);
+
+/* program "brdf_preintegrate": advanced_ssr.cpp:116-136 + preintegrate_ssr.comp:12-44 (split-sum LUT,
+ * RG16F; consumed by the deferred-shading composite).  halton: the HaltonBuffer of vkr_sssr_trace.   */
+int vkr_brdf_preintegrate(const float* halton_vec4 /*device*/, const vkr_img* out_brdf, void* stream);
+
+/* program "defered_shading": defered_shading.cpp:47-118 + defered_shading/shader.frag:41-130
+ * (bindings 0 albedo, 1 normal, 2 material, 3 depth [all mips], 4 Constants, 5 shadow map — bound by
+ * the reference but never sampled, omitted here —, 6 occlusion, 7 brdf LUT, 8 reflections; colour
+ * attachment RGBA8_SRGB).  SURVEY.md 8(f) #1.                                                        */
+int vkr_defered_shading(const vkr_img* albedo, const vkr_img* normal, const vkr_img* material, const vkr_img* depth,
+                        const vkr_shading_params* consts, const vkr_img* occlusion, const vkr_img* brdf,
+                        const vkr_img* reflections, const vkr_img* out, const vkr_shading_push* push, void* stream);
 
 /* synthetic G-buffer generator (no reference program).  Any of the
  * colour outputs may be NULL when VKR_SYNTH_DEPTH_ONLY is set.                          */

@@ -296,3 +296,27 @@ def test_filter_all_rays_invalid_gives_zero():
     c.ssr_filter()
     out = c.reflections.raw(0)
     assert np.all(out[1:-1, 1:-1, :3] == 0)  # interior: every tap is an invalid ray (edge taps fetch out of bounds = valid garbage)
+
+
+# (12) deferred shading ------------------------------------------------------------------------------------------------------
+def test_shading_show_ao_writes_srgb_of_occlusion():
+    """show_ao != 0: out = (occlusion, occlusion, occlusion) written to an sRGB attachment (shader.frag:96-97)."""
+    c = _plane_chain(use_mis=1, static_camera=True)
+    c.downsample()
+    c.preintegrate_brdf()
+    acc = np.zeros((16, 32, 2), dtype=np.float16)
+    acc[..., 0] = 0.5
+    c.acc_ao.set_raw(acc)
+    c.blurred.set_raw(np.zeros((16, 32, 4), dtype=np.uint8))
+    c.shading(show_ao=1)
+    out = c.color_out.raw(0)
+    assert np.all(out[..., :3] == 188) and np.all(out[..., 3] == 0)  # sRGB code of 0.5, alpha 0
+
+
+def test_brdf_lut_is_a_split_sum():
+    """A + B = mean(G2/G1) <= 1 and both non-negative; at roughness -> 0 and NdotV -> 1 the lobe is a mirror: A ~ 1, B ~ 0."""
+    c = PostFxChain(64, 32, backend="oracle")
+    c.preintegrate_brdf()
+    lut = c.brdf.decode()
+    assert np.all(lut[..., :2] >= -1e-3) and np.all(lut[..., 0] + lut[..., 1] <= 1.0 + 2e-3)
+    assert lut[1020, 2, 0] == pytest.approx(1.0, abs=2e-2) and lut[1020, 2, 1] == pytest.approx(0.0, abs=2e-2)

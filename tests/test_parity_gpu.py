@@ -147,3 +147,73 @@ def test_simple_ssr(size, oracle_lib):
     lit = int((ref.ssr_out.raw(0)[..., :3].max(axis=-1) > 0).sum())
     print(f"[parity] ssr_out lit texels {lit}")
     assert lit > 0.01 * size[0] * size[1], "simple SSR produced (almost) no reflections: the test scene does not exercise it"
+
+
+def test_brdf_lut(oracle_lib):
+    ref, gpu = _pair(64, 32, oracle_lib)
+    ref.preintegrate_brdf()
+    gpu.preintegrate_brdf()
+    gpu.sync()
+    n, _ = report("brdf_lut", abi.FMT_RG16_SFLOAT, gpu.brdf.decode(), ref.brdf.decode())
+    assert n == 0
+
+
+@pytest.mark.parametrize("size", [(256, 144), (640, 360)])
+def test_defered_shading(size, oracle_lib):
+    """SURVEY 8(f) #1: the composite between GTAO/SSR and TAA (defered_shading/shader.frag)."""
+    ref, gpu = _pair(*size, oracle_lib)
+    ref.synth()
+    ref.build_prev_hiz()
+    ref.init_histories()
+    ref.preintegrate_pdf()
+    ref.preintegrate_brdf()
+    ref.frame()
+    gpu.preintegrate_brdf()
+    _sync_inputs(ref, gpu)
+    gpu.brdf.copy_from(ref.brdf)
+    for show_ao in (0, 1):
+        ref.shading(show_ao=show_ao)
+        gpu.shading(show_ao=show_ao)
+        _compare(ref, gpu, ("color_out",), budget=1e-4)
+    # TAA then resolves the shaded colour (main.cpp:390-391)
+    ref.shading()
+    gpu.shading()
+    ref.taa(color=ref.color_out)
+    gpu.taa(color=gpu.color_out)
+    _compare(ref, gpu, ("taa_target",), budget=1e-4)
+
+
+def test_host_mirror_frame_with_shading(oracle_lib):
+    """The C++ host mirror (rendergraph + pass structs, host/frame.cpp) drives the whole frame including the
+    deferred-shading composite; every output must match the oracle driven through the flat Python chain."""
+    import torch
+
+    from vk_renderer_amd import host
+    from vk_renderer_amd.camera import FrameSetup
+    from parity import mismatches
+
+    W, H = 640, 360
+    setup = FrameSetup(W, H)
+    frame = host.HostFrame(setup, device="cuda")
+    frame.run(host.STAGE_LUT | host.STAGE_BRDF_LUT | host.STAGE_GBUFFER | host.STAGE_PREV_DEPTH)
+    ref = PostFxChain(W, H, backend="oracle", setup=setup)
+    ref.synth(); ref.build_prev_hiz(); ref.init_histories(); ref.preintegrate_pdf(); ref.preintegrate_brdf()
+    frame.upload("taa_hist", ref.taa_hist.host)
+    frame.upload("acc_hist", ref.acc_hist.host)
+    for _ in range(2):
+        frame.run(host.STAGE_CHAIN | host.STAGE_SHADING)
+        frame.end_frame()
+        ref.downsample(); ref.ssr_trace(frame_random=ref.frame_index % 16); ref.ssr_filter(); ref.ssr_blur()
+        ref.gtao_main(); ref.gtao_filter(); ref.gtao_accumulate(); ref.shading(); ref.taa(color=ref.color_out)
+        ref.frame_index += 1
+        ref.swap_histories()
+    torch.cuda.synchronize()
+    assert frame.last_tasks() == ["DownsampleGbuffer", "DownsampleDepth", "SSSR_trace", "SSSR_filter", "SSSR_blur", "GTAO_main",
+                                  "GTAO_filter", "GTAO_accumulate", "DeferedShading", "TAA"]
+    for hname, rimg in (("color_out", ref.color_out), ("taa_hist", ref.taa_hist), ("acc_hist", ref.acc_hist),
+                        ("blurred_hist", ref.blurred_hist), ("rays", ref.rays), ("brdf", ref.brdf)):
+        got = frame.download(hname)
+        bad = int(mismatches(rimg.format, got.decode(0), rimg.decode(0)).sum())
+        print(f"[parity] host {hname:13s} outside-tol {bad}")
+        assert bad <= 2e-4 * rimg.width * rimg.height, f"host frame {hname}: {bad} texels outside tolerance"
+    frame.close()

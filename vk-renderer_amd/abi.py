@@ -112,6 +112,15 @@ class SsrParams(C.Structure):
     _fields_ = [("normal_mat", Mat4), ("fovy", C.c_float), ("aspect", C.c_float), ("znear", C.c_float), ("zfar", C.c_float)]
 
 
+class ShadingParams(C.Structure):
+    _fields_ = [("inverse_camera", Mat4), ("camera", Mat4), ("shadow_mvp", Mat4), ("fovy", C.c_float), ("aspect", C.c_float),
+                ("znear", C.c_float), ("zfar", C.c_float)]
+
+
+class ShadingPush(C.Structure):
+    _fields_ = [("min_max_roughness", C.c_float * 2), ("show_ao", C.c_uint32)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("camera_to_world", Mat4), ("prev_mvp", Mat4), ("mvp", Mat4), ("fovy", C.c_float), ("aspect", C.c_float),
                 ("znear", C.c_float), ("zfar", C.c_float), ("seed", C.c_uint32), ("flags", C.c_uint32)]
@@ -135,6 +144,8 @@ ENTRY_ARGS = {
     "taa_resolve": [_IMG, _IMG, _IMG, _IMG, _IMG, _IMG, P(ReprojectParams)],
     "synth_gbuffer": [_IMG, _IMG, _IMG, _IMG, _IMG, P(SynthParams)],
     "ssr": [_IMG, _IMG, _IMG, P(SsrParams), _IMG, _IMG],
+    "brdf_preintegrate": [C.c_void_p, _IMG],
+    "defered_shading": [_IMG, _IMG, _IMG, _IMG, P(ShadingParams), _IMG, _IMG, _IMG, _IMG, P(ShadingPush)],
 }
 
 

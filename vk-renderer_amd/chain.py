@@ -250,6 +250,26 @@ class PostFxChain:
         self.call("ssr", C.byref(self.normal.desc()), C.byref(self.depth.desc()), C.byref(color.desc()), C.byref(p),
                   C.byref(self.material.desc()), C.byref(self.ssr_out.desc()))
 
+    def preintegrate_brdf(self):
+        if not hasattr(self, "brdf"):
+            self.brdf = ImageBuf(abi.FMT_RG16_SFLOAT, PDF_LUT_SIZE, PDF_LUT_SIZE, device=self.device)
+        self.call("brdf_preintegrate", self._halton_ptr(), C.byref(self.brdf.desc()))
+
+    def shading(self, min_roughness=0.0, max_roughness=1.0, show_ao=0):
+        """src/defered_shading.cpp DeferedShadingPass::draw -> color_out (RGBA8_SRGB); SURVEY.md 8(f) #1."""
+        if not hasattr(self, "color_out"):
+            self.color_out = ImageBuf(abi.FMT_RGBA8_SRGB, self.albedo.width, self.albedo.height, device=self.device,
+                                      full=self.albedo.full, origin=self.albedo.origin)
+        p = abi.ShadingParams()
+        p.inverse_camera = abi.Mat4.from_np(self.setup.inv_view)
+        p.camera = abi.Mat4.from_np(self.setup.view)
+        p.shadow_mvp = abi.Mat4.from_np(np.eye(4))
+        p.fovy, p.aspect, p.znear, p.zfar = [float(v) for v in self.setup.fazz]
+        push = abi.ShadingPush((C.c_float * 2)(min_roughness, max_roughness), show_ao)
+        self.call("defered_shading", C.byref(self.albedo.desc()), C.byref(self.normal.desc()), C.byref(self.material.desc()),
+                  C.byref(self.depth.desc()), C.byref(p), C.byref(self.acc_ao.desc()), C.byref(self.brdf.desc()),
+                  C.byref(self.blurred.desc()), C.byref(self.color_out.desc()), C.byref(push))
+
     def frame(self):
         """One steady-state frame of the chain: D1 D2 S1 S2 S3 G1 G2 G3 T (main.cpp:347-391)."""
         self.downsample()

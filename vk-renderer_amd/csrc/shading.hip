@@ -1,0 +1,165 @@
+// shading.hip — programs "brdf_preintegrate" and "defered_shading" (SURVEY.md 8(f) #1): the step
+// between GTAO/SSR and TAA that produces TAA's colour input in the reference frame loop
+// (main.cpp:390-391).  Reference: src/defered_shading.cpp:47-118, shaders/defered_shading/shader.frag,
+// src/advanced_ssr.cpp:116-136, shaders/advanced_ssr/preintegrate_ssr.comp.
+// Full resolution, HBM-bound in the compulsory model: 23 B per pixel (albedo 4 + normal 4 + material 4
+// + depth0 4 + depth1 1 + ao 1 + reflections 1 read, colour 4 written).
+#include "vkr_host.hpp"
+
+namespace vkr {
+
+// brdf.glsl:135-155 with cos/sin(2*PI*U2) supplied (vkr_halton23_fill)
+VKR_DEV f3 sampleGGXVNDF_cs(f3 Ve, float alpha_x, float alpha_y, float U1, float cos_phi, float sin_phi) {
+  f3 Vh = normalize(mk3(alpha_x * Ve.x, alpha_y * Ve.y, Ve.z));
+  float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+  f3 T1 = lensq > 0.0f ? mk3(-Vh.y, Vh.x, 0.0f) * (1.0f / sqrtf(lensq)) : mk3(1, 0, 0);
+  f3 T2 = cross(Vh, T1);
+  float r = sqrtf(U1);
+  float t1 = r * cos_phi;
+  float t2 = r * sin_phi;
+  float s = 0.5f * (1.0f + Vh.z);
+  t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
+  f3 Nh = (t1 * T1 + t2 * T2) + sqrtf(vmax(0.0f, (1.0f - t1 * t1) - t2 * t2)) * Vh;
+  return normalize(mk3(alpha_x * Nh.x, alpha_y * Nh.y, vmax(0.0f, Nh.z)));
+}
+
+// preintegrate_ssr.comp:12-44 (one-time LUT; literal arithmetic)
+__global__ __launch_bounds__(256) void k_brdf_preintegrate(const float4* __restrict__ halton, Tex out) {
+  __shared__ float4 s_h[VKR_HALTON_SEQ_SIZE];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  if (tid < VKR_HALTON_SEQ_SIZE) s_h[tid] = halton[tid];
+  __syncthreads();
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= out.w || y >= out.h) return;
+  const float roughness = ((float)x + 0.5f) / (float)out.fw;
+  const float NdotV = ((float)y + 0.5f) / (float)out.fh;
+  const float roughness2 = roughness * roughness;
+  const f3 V = mk3(sqrtf(1.0f - NdotV * NdotV), 0.0f, NdotV);
+  float A = 0.0f, B = 0.0f;
+  for (int i = 0; i < VKR_HALTON_SEQ_SIZE; i++) {
+    const float4 hv = s_h[i];
+    const f3 H = sampleGGXVNDF_cs(V, roughness2, roughness2, hv.x, hv.z, hv.w);
+    const f3 L = normalize(reflect(-V, H));
+    const float NdotL = L.z;
+    const float alpha = powf(1.0f - dot(V, H), 5.0f);
+    const float G1 = brdfG1(roughness2, NdotV);
+    const float G2 = brdfG2(NdotV, NdotL, roughness2);
+    A += (G2 / G1) * (1.0f - alpha);
+    B += (G2 / G1) * alpha;
+  }
+  A *= 1.0f / (float)VKR_HALTON_SEQ_SIZE;
+  B *= 1.0f / (float)VKR_HALTON_SEQ_SIZE;
+  *texel_ptr<uint32_t>(out, x, y) = float_to_half_bits(A) | (float_to_half_bits(B) << 16);
+}
+
+struct ShadingArgs {
+  Tex albedo, normal, material, depth0, depth1, occlusion, brdf, reflections, out;
+  Mat4 inverse_camera;
+  Proj pr;
+  float min_roughness, max_roughness;
+  uint32_t show_ao;
+};
+
+// brdf.glsl:31-38
+VKR_DEV float distribution_ggx(f3 N, f3 H, float alpha) {
+  const float NoH = dot(N, H);
+  const float alpha2 = alpha * alpha;
+  const float NoH2 = NoH * NoH;
+  const float den = NoH2 * alpha2 + (1.0f - NoH2);
+  return (((NoH2 > 0.0f) ? 1.0f : 0.0f) * alpha2) / ((VKR_PI * den) * den);
+}
+
+// shader.frag:41-130.  The 2x2 nearest-depth pick (sample_ocllusion_ssr) compares exactly computed
+// bilinear depths; the shading terms after it are smooth and written to an 8-bit sRGB target.
+__global__ __launch_bounds__(256) void k_defered_shading(ShadingArgs a) {
+  __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
+  srgb_lut_stage(s_lut, threadIdx.y * blockDim.x + threadIdx.x, 256);
+  __syncthreads();
+  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+  if (lx >= a.out.w || ly >= a.out.h) return;
+  const int gx = a.out.ox + lx, gy = a.out.oy + ly;
+  const f2 screen_uv = mk2(((float)gx + 0.5f) / (float)a.out.fw, ((float)gy + 0.5f) / (float)a.out.fh);
+  const f3 N = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
+  const f3 albedo = sample_srgb_rgb(a.albedo, screen_uv, s_lut);
+  const float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
+  const float metallic = mixf(0.1f, 1.0f, sample_srgb_channel(a.material, screen_uv, 2, s_lut));
+  const float depth = sample<FmtD24>(a.depth0, screen_uv);
+  // sample_ocllusion_ssr (:103-130)
+  float occlusion;
+  f3 reflection;
+  {
+    const float d0 = fabsf(sample<FmtD24>(a.depth1, screen_uv, 0, 0) - depth), d1 = fabsf(sample<FmtD24>(a.depth1, screen_uv, 1, 0) - depth);
+    const float d2 = fabsf(sample<FmtD24>(a.depth1, screen_uv, 0, 1) - depth), d3 = fabsf(sample<FmtD24>(a.depth1, screen_uv, 1, 1) - depth);
+    const float min_delta = vmin(vmin(d0, d1), vmin(d2, d3));
+    int ox = 1, oy = 1;
+    if (min_delta == d0) { ox = 0; oy = 0; }
+    else if (min_delta == d1) { ox = 1; oy = 0; }
+    else if (min_delta == d2) { ox = 0; oy = 1; }
+    occlusion = sample<FmtRG16F>(a.occlusion, screen_uv, ox, oy).x;
+    reflection = sample<FmtRGBA8>(a.reflections, screen_uv, ox, oy);
+  }
+  const f3 vv = reconstruct_view_vec(screen_uv, depth, a.pr);
+  const f3 world_pos = xyz(mul(a.inverse_camera, mk4(vv.x, vv.y, vv.z, 1.0f)));
+  const f3 camera_pos = xyz(mul(a.inverse_camera, mk4(0, 0, 0, 1)));
+  const f3 LIGHT_POS = mk3(-1.85867f, 5.81832f, -0.247114f);
+  const f3 V = normalize(camera_pos - world_pos);
+  const f3 F0 = F0_approximation(albedo, metallic);
+  const f3 Lv = LIGHT_POS - world_pos;
+  const f3 L = normalize(Lv);
+  const f3 H = normalize(V + L);
+  const float light_distance = length(Lv);
+  const float rad = 0.1f * vmin(100.0f / (light_distance * light_distance), 100.0f);
+  const float NdotL = vmax(dot(N, L), 0.0f), NdotV = vmax(dot(N, V), 0.0f);
+  const float NDF = distribution_ggx(N, H, roughness);
+  const float G = brdfG2(NdotV, NdotL, roughness * roughness);
+  const f3 F = fresnelSchlick(vmax(dot(H, V), 0.0f), F0);
+  const f3 kD = (mk3(1.0f, 1.0f, 1.0f) - F) * (1.0f - metallic);
+  const f3 specular = ((NDF * G) * F) / ((4.0f * NdotV) * NdotL + 0.0001f);
+  const float biased_rougness = mixf(a.min_roughness, a.max_roughness, roughness);
+  const f2 ssr_brdf = sample<FmtRG16F>(a.brdf, mk2(biased_rougness, NdotV));
+  f3 Lo = (((kD * albedo) / VKR_PI + specular) * rad) * NdotL;
+  Lo = Lo + reflection * (F0 * ssr_brdf.x + mk3(ssr_brdf.y, ssr_brdf.y, ssr_brdf.y));
+  const f3 color = occlusion * (mk3(0.6f, 0.6f, 0.6f) * albedo + Lo);
+  const f3 o = a.show_ao ? mk3(occlusion, occlusion, occlusion) : color;
+  *texel_ptr<uint32_t>(a.out, lx, ly) = float_to_srgb8(o.x) | (float_to_srgb8(o.y) << 8) | (float_to_srgb8(o.z) << 16);  // alpha 0
+}
+
+}  // namespace vkr
+
+using namespace vkr;
+
+extern "C" int vkr_brdf_preintegrate(const float* halton_vec4, const vkr_img* out_brdf, void* stream) {
+  if (!halton_vec4 || ((uintptr_t)halton_vec4 % 16) != 0) { set_error("brdf_preintegrate: halton buffer must be a 16-byte aligned device pointer"); return VKR_ERR_NULL; }
+  Tex out;
+  VKR_TRY(make_tex(out_brdf, 0, VKR_FMT_RG16_SFLOAT, "brdf_preintegrate.out", &out));
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_brdf_preintegrate, grid2d(out.w, out.h, block), block, 0, (hipStream_t)stream, (const float4*)halton_vec4, out);
+  return launch_status("brdf_preintegrate");
+}
+
+extern "C" int vkr_defered_shading(const vkr_img* albedo, const vkr_img* normal, const vkr_img* material, const vkr_img* depth,
+                                   const vkr_shading_params* consts, const vkr_img* occlusion, const vkr_img* brdf,
+                                   const vkr_img* reflections, const vkr_img* out, const vkr_shading_push* push, void* stream) {
+  if (!consts || !push) { set_error("defered_shading: NULL params"); return VKR_ERR_NULL; }
+  ShadingArgs a;
+  VKR_TRY(make_tex(albedo, 0, VKR_FMT_RGBA8_SRGB, "defered_shading.albedo", &a.albedo));
+  VKR_TRY(make_tex(normal, 0, VKR_FMT_RG16_UNORM, "defered_shading.normal", &a.normal));
+  VKR_TRY(make_tex(material, 0, VKR_FMT_RGBA8_SRGB, "defered_shading.material", &a.material));
+  VKR_TRY(make_tex(depth, 0, VKR_FMT_D24_UNORM_S8, "defered_shading.depth", &a.depth0));
+  VKR_TRY(make_tex(depth, 1, VKR_FMT_D24_UNORM_S8, "defered_shading.depth (lod 1)", &a.depth1));
+  VKR_TRY(make_tex(occlusion, 0, VKR_FMT_RG16_SFLOAT, "defered_shading.occlusion", &a.occlusion));
+  VKR_TRY(make_tex(brdf, 0, VKR_FMT_RG16_SFLOAT, "defered_shading.brdf", &a.brdf));
+  VKR_TRY(make_tex(reflections, 0, VKR_FMT_RGBA8_UNORM, "defered_shading.reflections", &a.reflections));
+  VKR_TRY(make_tex(out, 0, VKR_FMT_RGBA8_SRGB, "defered_shading.out", &a.out));
+  load_mat(a.inverse_camera, consts->inverse_camera);
+  a.pr.tg = tanf(consts->fovy / 2.0f);
+  a.pr.aspect = consts->aspect; a.pr.znear = consts->znear; a.pr.zfar = consts->zfar;
+  a.min_roughness = push->min_max_roughness[0];
+  a.max_roughness = push->min_max_roughness[1];
+  a.show_ao = push->show_ao;
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_defered_shading, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  return launch_status("defered_shading");
+}

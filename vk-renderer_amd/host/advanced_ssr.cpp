@@ -38,6 +38,7 @@ AdvancedSSR::AdvancedSSR(rendergraph::RenderGraph &graph, uint32_t w, uint32_t h
   filter_pass = gpu::create_compute_pipeline("sssr_filter");
   blur_pass = gpu::create_compute_pipeline("sssr_blur");
   preintegrate_pass = gpu::create_compute_pipeline("pdf_preintegrate");
+  preintegrate_brdf_pass = gpu::create_compute_pipeline("brdf_preintegrate");
 
   // xy: the reference's table (advanced_ssr.cpp:22-34); zw: cos/sin of 2*PI*y evaluated on the host
   // for the HIP trace kernel (vkr_halton23_fill, include/vkr_postfx.h) — zero in the reference
@@ -87,8 +88,23 @@ void AdvancedSSR::preintegrate_pdf(rendergraph::RenderGraph &graph) {
     });
 }
 
-void AdvancedSSR::preintegrate_brdf(rendergraph::RenderGraph &) {
-  throw std::runtime_error {"AdvancedSSR::preintegrate_brdf: the split-sum LUT feeds deferred shading only; not on the HIP path yet"};
+// advanced_ssr.cpp:116-136
+void AdvancedSSR::preintegrate_brdf(rendergraph::RenderGraph &graph) {
+  struct Input { rendergraph::ImageViewId out_brdf; };
+  graph.add_task<Input>("BRDF_preintegrate",
+    [&](Input &in, rendergraph::RenderGraphBuilder &builder) {
+      in.out_brdf = builder.use_storage_image(preintegrated_brdf, VK_SHADER_STAGE_COMPUTE_BIT, 0, 0);
+    },
+    [=](Input &in, rendergraph::RenderResources &resources, gpu::CmdContext &cmd) {
+      auto set = resources.allocate_set(preintegrate_brdf_pass, 0);
+      gpu::write_set(set,
+        gpu::UBOBinding {0, halton_buffer},
+        gpu::StorageTextureBinding {1, resources.get_view(in.out_brdf)});
+      const auto extent = resources.get_image(in.out_brdf)->get_extent();
+      cmd.bind_pipeline(preintegrate_brdf_pass);
+      cmd.bind_descriptors_compute(0, {set}, {0});
+      cmd.dispatch((extent.width + 7)/8, (extent.height + 3)/4, 1);
+    });
 }
 
 struct TraceParams {

@@ -1,8 +1,8 @@
 // advanced_ssr.hpp — stochastic Hi-Z screen-space reflections, public interface of
 // src/advanced_ssr.hpp:7-113.  Implemented: run() = trace -> filter -> blur (advanced_ssr.cpp:551-553),
-// preintegrate_pdf, remap_images, the getters.  The reference's disabled experiments (tile
-// classification, indirect trace, tile regression; advanced_ssr.cpp:547-550) and preintegrate_brdf
-// (consumed only by deferred shading) are outside the hot path.
+// preintegrate_pdf / preintegrate_brdf, remap_images, the getters.  The reference's disabled experiments
+// (tile classification, indirect trace, tile regression; advanced_ssr.cpp:547-550) are outside the
+// hot path.
 #ifndef ADVANCED_SSR_HPP_INCLUDED
 #define ADVANCED_SSR_HPP_INCLUDED
 
@@ -63,6 +63,7 @@ private:
   gpu::ComputePipeline filter_pass;
   gpu::ComputePipeline blur_pass;
   gpu::ComputePipeline preintegrate_pass;
+  gpu::ComputePipeline preintegrate_brdf_pass;
 
   VkSampler sampler;
 

@@ -11,6 +11,7 @@
 #include <string>
 
 #include "advanced_ssr.hpp"
+#include "defered_shading.hpp"
 #include "downsample_pass.hpp"
 #include "gtao.hpp"
 #include "scene_renderer.hpp"
@@ -36,6 +37,8 @@ struct PostFxFrame {
   GTAO gtao;
   AdvancedSSR ssr;
   TAA taa_pass;
+  DeferedShadingPass shading_pass;
+  rendergraph::ImageResourceId color_out_tex;
   SyntheticGbuffer synth;
 
   DrawTAAParams draw_params{};
@@ -48,8 +51,12 @@ struct PostFxFrame {
         gbuffer{graph, c.width, c.height},
         gtao{graph, c.width, c.height, false, true},  // main.cpp:265: (graph, W, H, USE_RAY_QUERY = 0, half_res = 1)
         ssr{graph, c.width, c.height},
-        taa_pass{graph, c.width, c.height} {
+        taa_pass{graph, c.width, c.height},
+        shading_pass{graph, nullptr} {
     if (c.tiled) gbuffer.enable_tiling(graph, c.full_width, c.full_height);
+    // main.cpp:289-291
+    color_out_tex = graph.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R8G8B8A8_SRGB, VK_IMAGE_ASPECT_COLOR_BIT, c.width, c.height},
+                                       VK_IMAGE_TILING_OPTIMAL, VK_IMAGE_USAGE_COLOR_ATTACHMENT_BIT | VK_IMAGE_USAGE_SAMPLED_BIT);
   }
 
   void set_camera(const vkrh_camera& cam) {
@@ -70,6 +77,7 @@ struct PostFxFrame {
     if (!has_camera && (mask & ~uint32_t(VKRH_STAGE_LUT))) throw std::runtime_error{"vkrh_run: camera not set"};
     const glm::vec4 fazz = draw_params.fovy_aspect_znear_zfar;
     if (mask & VKRH_STAGE_LUT) ssr.preintegrate_pdf(graph);
+    if (mask & VKRH_STAGE_BRDF_LUT) ssr.preintegrate_brdf(graph);
     if (mask & VKRH_STAGE_PREV_DEPTH) {
       // what the previous frame left behind: its depth in `prev_depth`, including the Hi-Z mips
       synth.draw_depth(graph, gbuffer.prev_depth, prev_view, draw_params.prev_mvp, fazz);
@@ -94,9 +102,14 @@ struct PostFxFrame {
       gtao.add_filter_pass(graph, gtao_params, gbuffer.depth);
       gtao.add_accumulate_pass(graph, draw_params, gbuffer);
     }
-    // main.cpp:390-391: the colour input of TAA is the deferred-shading output; until that pass
-    // exists on this path TAA resolves the albedo attachment.
-    if (mask & VKRH_STAGE_TAA) taa_pass.run(graph, gbuffer, gbuffer.albedo, draw_params);
+    // main.cpp:343,390-391: shading composes albedo / AO / reflections into color_out_tex, which TAA
+    // resolves.  Without the shading stage TAA resolves the albedo attachment (the headline
+    // composite of BASELINE.json is the nine passes without shading).
+    if (mask & VKRH_STAGE_SHADING) {
+      shading_pass.update_params(view, glm::mat4{1.f}, fazz.x, fazz.y, fazz.z, fazz.w);
+      shading_pass.draw(graph, gbuffer, rendergraph::ImageResourceId{}, gtao.accumulated_ao, ssr.get_preintegrated_brdf(), ssr.get_blurred(), color_out_tex);
+    }
+    if (mask & VKRH_STAGE_TAA) taa_pass.run(graph, gbuffer, (mask & VKRH_STAGE_SHADING) ? color_out_tex : gbuffer.albedo, draw_params);
     graph.submit();
     task_names.clear();
     for (const auto& n : graph.last_submitted_tasks()) { task_names += n; task_names += '\n'; }
@@ -116,7 +129,7 @@ struct PostFxFrame {
         {"depth", 0}, {"prev_depth", 1}, {"normal", 2}, {"albedo", 3}, {"material", 4}, {"velocity", 5}, {"dn", 6}, {"dv", 7},
         {"raw", 8}, {"filtered", 9}, {"acc_ao", 10}, {"acc_hist", 11}, {"rays", 12}, {"reflections", 13}, {"blurred", 14},
         {"blurred_hist", 15}, {"pdf", 16}, {"taa_hist", 17}, {"taa_target", 18}, {"frame_hiz", 19}, {"frame_normals", 20},
-        {"frame_albedo", 21}};
+        {"frame_albedo", 21}, {"color_out", 22}, {"brdf", 23}};
     auto it = ids.find(name);
     if (it == ids.end()) throw std::runtime_error{"vkrh_image: unknown image '" + name + "'"};
     switch (it->second) {
@@ -126,7 +139,8 @@ struct PostFxFrame {
       case 10: return gtao.accumulated_ao; case 11: return gtao.accumulated_history; case 12: return ssr.get_rays();
       case 13: return ssr.get_ouput(); case 14: return ssr.get_blurred(); case 15: return ssr.get_blurred_history();
       case 16: return ssr.get_preintegrated_pdf(); case 17: return taa_pass.get_history(); case 18: return taa_pass.get_output();
-      case 19: return gbuffer.frame_hiz; case 20: return gbuffer.frame_normals; default: return gbuffer.frame_albedo;
+      case 19: return gbuffer.frame_hiz; case 20: return gbuffer.frame_normals; case 21: return gbuffer.frame_albedo;
+      case 22: return color_out_tex; default: return ssr.get_preintegrated_brdf();
     }
   }
 };

@@ -94,9 +94,11 @@ vkr_img Image::describe(uint32_t base_mip, uint32_t count) const {
   return d;
 }
 
-Buffer::Buffer(VmaMemoryUsage memory, uint64_t sz, VkBufferUsageFlags) : size{sz} {
+Buffer::Buffer(VmaMemoryUsage memory, uint64_t sz, VkBufferUsageFlags usage) : size{sz} {
   dev = device_alloc((sz + 255) & ~uint64_t(255));
-  if (memory != VMA_MEMORY_USAGE_GPU_ONLY) shadow.resize(sz);
+  // host shadow: mapped (CPU_TO_GPU) buffers, and uniform buffers — their contents become kernel
+  // arguments of the C-ABI call, so the program reads them on the host
+  if (memory != VMA_MEMORY_USAGE_GPU_ONLY || (usage & VK_BUFFER_USAGE_UNIFORM_BUFFER_BIT)) shadow.resize(sz);
 }
 Buffer::~Buffer() { device_free(dev); }
 void* Buffer::device_ptr(void* stream) {
@@ -176,9 +178,11 @@ vkr_img tex(const LaunchState& st, uint32_t slot, SetSlot::Kind kind, const char
 }
 template <typename T> const T* ubo(const LaunchState& st, uint32_t slot, const char* prog) {
   const SetSlot& s = st.set ? st.set->slots[slot] : SetSlot{};
-  if (!st.set || s.kind != SetSlot::Ubo || !s.host_data || s.host_size < sizeof(T))
-    throw std::runtime_error{std::string{prog} + ": uniform block " + std::to_string(slot) + " is not bound"};
-  return (const T*)s.host_data;
+  if (!st.set || s.kind != SetSlot::Ubo) throw std::runtime_error{std::string{prog} + ": uniform block " + std::to_string(slot) + " is not bound"};
+  const void* data = s.host_data ? s.host_data : (s.buffer ? s.buffer->host_data() : nullptr);
+  const uint64_t size = s.host_data ? s.host_size : (s.buffer ? s.buffer->get_size() : 0);
+  if (!data || size < sizeof(T)) throw std::runtime_error{std::string{prog} + ": uniform block " + std::to_string(slot) + " is not bound"};
+  return (const T*)data;
 }
 template <typename T> const T* push(const LaunchState& st, const char* prog) {
   if (st.push_size < sizeof(T)) throw std::runtime_error{std::string{prog} + ": push constants missing"};
@@ -280,6 +284,22 @@ void register_hot_path_programs() {
       vkr_img normal = tex(st, 0, T, P), depth = tex(st, 1, T, P, true), frame = tex(st, 2, T, P), material = tex(st, 4, T, P);
       vkr_img out = st.attachments[0].image->describe(st.attachments[0].range.base_mip, 1);
       return vkr_ssr(&normal, &depth, &frame, ubo<vkr_ssr_params>(st, 3, P), &material, &out, st.stream);
+    });
+    create_program("brdf_preintegrate", [=](LaunchState& st) {
+      const SetSlot& h = st.set->slots[0];
+      if (h.kind != SetSlot::Ubo || !h.buffer) throw std::runtime_error{"brdf_preintegrate: Halton buffer (binding 0) is not bound"};
+      vkr_img out = tex(st, 1, S, "brdf_preintegrate");
+      return vkr_brdf_preintegrate((const float*)h.buffer->device_ptr(st.stream), &out, st.stream);
+    });
+    // defered_shading/shader.frag: set {0 albedo, 1 normal, 2 material, 3 depth, 4 Constants, 5 shadow (unused), 6 occlusion, 7 brdf, 8 reflections}
+    create_program("defered_shading", [=](LaunchState& st) {
+      const char* P = "defered_shading";
+      if (st.attachments.size() != 1) throw std::runtime_error{"defered_shading: expects one colour attachment"};
+      vkr_img albedo = tex(st, 0, T, P), normal = tex(st, 1, T, P), material = tex(st, 2, T, P), depth = tex(st, 3, T, P);
+      vkr_img occlusion = tex(st, 6, T, P), brdf = tex(st, 7, T, P), refl = tex(st, 8, T, P);
+      vkr_img out = st.attachments[0].image->describe(st.attachments[0].range.base_mip, 1);
+      return vkr_defered_shading(&albedo, &normal, &material, &depth, ubo<vkr_shading_params>(st, 4, P), &occlusion, &brdf, &refl, &out,
+                                 push<vkr_shading_push>(st, P), st.stream);
     });
     // synthetic G-buffer "raster" program: attachments {albedo, normal, material, velocity, depth} or {depth}
     create_program("synthetic_gbuffer", [=](LaunchState& st) {

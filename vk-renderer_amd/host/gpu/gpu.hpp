@@ -92,6 +92,7 @@ struct Buffer {
   uint64_t get_size() const { return size; }
   // CPU_TO_GPU buffers: host shadow, uploaded to the device copy when next bound
   void* get_mapped_ptr() { dirty = true; return shadow.data(); }
+  const void* host_data() const { return shadow.empty() ? nullptr : shadow.data(); }
   void* device_ptr(void* stream);
 
  private:

@@ -162,6 +162,7 @@ struct RenderGraph {  // rendergraph.hpp:112-158
   // standalone image that always covers the whole frame at full >> k (gathered Hi-Z pyramid, ...)
   ImageResourceId create_frame_image(const gpu::ImageInfo& info);
   gpu::ImagePtr& get_image(ImageResourceId id) { return resources.get_image(id); }
+  gpu::BufferPtr& get_buffer(BufferResourceId id) { return resources.get_buffer(id); }
   const std::vector<std::string>& last_submitted_tasks() const { return submitted_names; }
   // Per-task device timing: HIP events recorded around every task on the graph's stream (the
   // counterpart of the reference's per-task debug labels, rendergraph.cpp:289-304).  Events are
