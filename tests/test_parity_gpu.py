@@ -200,11 +200,13 @@ def test_host_mirror_frame_with_shading(oracle_lib):
     ref.synth(); ref.build_prev_hiz(); ref.init_histories(); ref.preintegrate_pdf(); ref.preintegrate_brdf()
     frame.upload("taa_hist", ref.taa_hist.host)
     frame.upload("acc_hist", ref.acc_hist.host)
-    for _ in range(2):
+    angle_table = [60.0, 300.0, 180.0, 240.0, 120.0, 0.0, 300.0, 60.0, 180.0, 120.0, 240.0, 0.0]  # gtao.cpp:109
+    for k in range(2):
         frame.run(host.STAGE_CHAIN | host.STAGE_SHADING)
         frame.end_frame()
         ref.downsample(); ref.ssr_trace(frame_random=ref.frame_index % 16); ref.ssr_filter(); ref.ssr_blur()
-        ref.gtao_main(); ref.gtao_filter(); ref.gtao_accumulate(); ref.shading(); ref.taa(color=ref.color_out)
+        ref.gtao_main(angle_offset=float(np.float32(angle_table[k % 12]) / np.float32(360.0)))
+        ref.gtao_filter(); ref.gtao_accumulate(); ref.shading(); ref.taa(color=ref.color_out)
         ref.frame_index += 1
         ref.swap_histories()
     torch.cuda.synchronize()
