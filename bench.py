@@ -35,6 +35,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # Algorithmic bytes per FULL-RES pixel of each task: surface-compulsory model of SURVEY.md 8(d)
 # (every input surface read once, every output written once, at storage-format size).
 BYTES_PER_PX = {
+    "DeferedShading": 23.0,
     "DownsampleGbuffer": 15.0,
     "DownsampleDepth": 1.667,  # the whole chain mips 2..L-1 (one task, two launches)
     "SSSR_trace": 10.333,
@@ -96,7 +97,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--tile", type=str, default=f"{TILE_W}x{TILE_H}", help="per-GPU tile, WxH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c5"],
+                    help="BASELINE.json configs: c1 1920x1080 GTAO main only (non-MIS); c2 3840x2160 composite (default, the "
+                         "metric's config); c3 7680x4320 composite (analytic scene: Sponza.bin is absent from the reference mount); "
+                         "c5 3840x2160 with 8 x (trace, filter, blur) + TAA")
+    ap.add_argument("--shading", action="store_true", help="add the deferred-shading composite (SURVEY 8(f) #1) between GTAO and TAA")
     args = ap.parse_args()
+    if args.config != "c2" and args.gpus != 1:
+        raise SystemExit("--config c1/c3/c5 are single-GPU configurations")
+    if args.config == "c1":
+        args.tile = "1920x1080"
+    elif args.config == "c3":
+        args.tile = "7680x4320"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -114,11 +126,22 @@ def main():
     tw, th = (int(v) for v in args.tile.lower().split("x"))
     cols, rows = grid_for(world)
     W, H = tw * cols, th * rows
-    setup = FrameSetup(W, H)
+    setup = FrameSetup(W, H, use_mis=0 if args.config == "c1" else 1)
     tiled = TiledFrame(setup, rank, world, cols, rows, device)
     frame = tiled.frame
+    if args.config == "c1":      # GTAO main pass only (BASELINE configs[0]); non-MIS: 1+4 read, 2 written = 7 B/px
+        tiled.stage_plan = [host.STAGE_GTAO_MAIN_ONLY]
+        BYTES_PER_PX["GTAO_main"] = 7.0
+    elif args.config == "c5":    # 8 rays per pixel = 8 x (trace, filter, blur) with frame_random = 0..7, then TAA
+        tiled.stage_plan = [host.STAGE_DOWNSAMPLE] + [host.STAGE_SSR] * 8 + [host.STAGE_TAA]
+    elif args.shading:
+        tiled.stage_plan = [host.STAGE_CHAIN | host.STAGE_SHADING]
+    if args.shading or args.config == "c5":
+        frame.run(host.STAGE_BRDF_LUT)
 
     tiled.prepare()  # LUT, G-buffer (tile + halo), prev depth, histories
+    if args.config == "c1":
+        frame.run(host.STAGE_DOWNSAMPLE)  # GTAO reads depth mip 1; built once, outside the timed pass
     for _ in range(args.warmup):
         tiled.step()
 
@@ -171,7 +194,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{W}x{H} synthetic G-buffer: Hi-Z downsample + SSR (trace, filter, blur) + GTAO (main, filter, accumulate) + TAA",
+                "workload": {"c1": f"{W}x{H} synthetic G-buffer: GTAO main pass only (non-MIS)",
+                             "c5": f"{W}x{H} synthetic G-buffer: Hi-Z downsample + 8 x SSR (trace, filter, blur) + TAA"}.get(
+                    args.config, f"{W}x{H} synthetic G-buffer: Hi-Z downsample + SSR (trace, filter, blur) + GTAO (main, filter, accumulate)"
+                                 + (" + deferred shading" if args.shading else "") + " + TAA"),
+                "baseline_config": args.config,
                 "frame": [W, H],
                 "tile_per_gpu": [tw, th],
                 "grid": [cols, rows],
@@ -188,13 +215,13 @@ def main():
                 "avg_launch_ms": avg_launch_ms,
                 "algorithmic_bytes_per_launch": algo_bytes_launch,
             },
-            "composite_gbps": COMPOSITE_BYTES_PER_PX * px * args.steps / elapsed / 1e9,
+            "composite_gbps": sum(BYTES_PER_PX.get(k, 0.0) * v[1] / args.steps for k, v in task_times.items()) * tile_px / (elapsed / args.steps) / 1e9 * world,
             "per_pass_ms": per_pass_ms,
             "per_pass_gbps": {k: BYTES_PER_PX[k] * tile_px / (v * 1e-3) / 1e9 for k, v in per_pass_ms.items() if k in BYTES_PER_PX and v > 0},
             "exchange_ms": tiled.exchange_ms(args.steps),
             "measured_read_gbps": measured_read_bandwidth(device),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "c2" and not args.shading:
             out["cpu_baseline"] = cpu_baseline(frame, setup)
         print(json.dumps(out))
     if world > 1:

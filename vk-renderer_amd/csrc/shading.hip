@@ -74,24 +74,38 @@ VKR_DEV float distribution_ggx(f3 N, f3 H, float alpha) {
 // bilinear depths; the shading terms after it are smooth and written to an 8-bit sRGB target.
 __global__ __launch_bounds__(256) void k_defered_shading(ShadingArgs a) {
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
-  srgb_lut_stage(s_lut, threadIdx.y * blockDim.x + threadIdx.x, 256);
+  __shared__ float s_thresh[VKR_SRGB_LUT_SIZE];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  srgb_lut_stage(s_lut, tid, 256);
+  srgb_thresh_stage(s_thresh, tid, 256);
   __syncthreads();
   const int lx = blockIdx.x * blockDim.x + threadIdx.x;
   const int ly = blockIdx.y * blockDim.y + threadIdx.y;
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   const f2 screen_uv = mk2(((float)gx + 0.5f) / (float)a.out.fw, ((float)gy + 0.5f) / (float)a.out.fh);
-  const f3 N = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
+  // Exact: the depths that decide the 2x2 pick.  Everything after the pick is shading arithmetic
+  // written to an 8-bit sRGB target: hardware rsq / rcp.
+  const f3 N = decode_normal_fast(sample<FmtRG16U>(a.normal, screen_uv));
   const f3 albedo = sample_srgb_rgb(a.albedo, screen_uv, s_lut);
   const float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
   const float metallic = mixf(0.1f, 1.0f, sample_srgb_channel(a.material, screen_uv, 2, s_lut));
   const float depth = sample<FmtD24>(a.depth0, screen_uv);
-  // sample_ocllusion_ssr (:103-130)
+  // sample_ocllusion_ssr (:103-130): the four textureLodOffset taps share one 3x3 texel footprint
   float occlusion;
   f3 reflection;
   {
-    const float d0 = fabsf(sample<FmtD24>(a.depth1, screen_uv, 0, 0) - depth), d1 = fabsf(sample<FmtD24>(a.depth1, screen_uv, 1, 0) - depth);
-    const float d2 = fabsf(sample<FmtD24>(a.depth1, screen_uv, 0, 1) - depth), d3 = fabsf(sample<FmtD24>(a.depth1, screen_uv, 1, 1) - depth);
+    const float hx = screen_uv.x * (float)a.depth1.fw - 0.5f, hy = screen_uv.y * (float)a.depth1.fh - 0.5f;
+    const float hx0f = floorf(hx), hy0f = floorf(hy);
+    const float fx = hx - hx0f, fy = hy - hy0f;
+    const int x0 = f2i(hx0f), y0 = f2i(hy0f);
+    float t[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int i = 0; i < 3; i++) t[j][i] = fetch_clamped<FmtD24>(a.depth1, x0 + i, y0 + j);
+    auto bil = [&](int ox, int oy) { return mixf(mixf(t[oy][ox], t[oy][ox + 1], fx), mixf(t[oy + 1][ox], t[oy + 1][ox + 1], fx), fy); };
+    const float d0 = fabsf(bil(0, 0) - depth), d1 = fabsf(bil(1, 0) - depth), d2 = fabsf(bil(0, 1) - depth), d3 = fabsf(bil(1, 1) - depth);
     const float min_delta = vmin(vmin(d0, d1), vmin(d2, d3));
     int ox = 1, oy = 1;
     if (min_delta == d0) { ox = 0; oy = 0; }
@@ -104,26 +118,35 @@ __global__ __launch_bounds__(256) void k_defered_shading(ShadingArgs a) {
   const f3 world_pos = xyz(mul(a.inverse_camera, mk4(vv.x, vv.y, vv.z, 1.0f)));
   const f3 camera_pos = xyz(mul(a.inverse_camera, mk4(0, 0, 0, 1)));
   const f3 LIGHT_POS = mk3(-1.85867f, 5.81832f, -0.247114f);
-  const f3 V = normalize(camera_pos - world_pos);
+  const f3 V = normalize_fast(camera_pos - world_pos);
   const f3 F0 = F0_approximation(albedo, metallic);
   const f3 Lv = LIGHT_POS - world_pos;
-  const f3 L = normalize(Lv);
-  const f3 H = normalize(V + L);
-  const float light_distance = length(Lv);
-  const float rad = 0.1f * vmin(100.0f / (light_distance * light_distance), 100.0f);
+  const float ld2 = dot(Lv, Lv);
+  const f3 L = Lv * fast_rsq(ld2);
+  const f3 H = normalize_fast(V + L);
+  const float rad = 0.1f * vmin(100.0f * fast_rcp(ld2), 100.0f);
   const float NdotL = vmax(dot(N, L), 0.0f), NdotV = vmax(dot(N, V), 0.0f);
-  const float NDF = distribution_ggx(N, H, roughness);
-  const float G = brdfG2(NdotV, NdotL, roughness * roughness);
-  const f3 F = fresnelSchlick(vmax(dot(H, V), 0.0f), F0);
+  // DistributionGGX (brdf.glsl:31-38) and brdfG2 (:49-56) with hardware rcp / sqrt
+  const float NoH = dot(N, H), NoH2 = NoH * NoH, alpha2 = roughness * roughness;
+  const float den = NoH2 * alpha2 + (1.0f - NoH2);
+  const float NDF = (NoH2 > 0.0f ? alpha2 : 0.0f) * fast_rcp((VKR_PI * den) * den);
+  // G = brdfG2(NdotV, NdotL, roughness * roughness)
+  const float NdotV2 = NdotV * NdotV, NdotL2 = NdotL * NdotL;
+  const float L1 = fast_sqrt(1.0f + (alpha2 * (1.0f - NdotV2)) * fast_rcp(NdotV2));
+  const float L2 = fast_sqrt(1.0f + (alpha2 * (1.0f - NdotL2)) * fast_rcp(NdotL2));
+  const float G = 2.0f * fast_rcp(L1 + L2);
+  const float om = vclamp(1.0f - vmax(dot(H, V), 0.0f), 0.0f, 1.0f), om2 = om * om;
+  const f3 F = F0 + (mk3(1.0f, 1.0f, 1.0f) - F0) * ((om2 * om2) * om);
   const f3 kD = (mk3(1.0f, 1.0f, 1.0f) - F) * (1.0f - metallic);
-  const f3 specular = ((NDF * G) * F) / ((4.0f * NdotV) * NdotL + 0.0001f);
+  const f3 specular = ((NDF * G) * F) * fast_rcp((4.0f * NdotV) * NdotL + 0.0001f);
   const float biased_rougness = mixf(a.min_roughness, a.max_roughness, roughness);
   const f2 ssr_brdf = sample<FmtRG16F>(a.brdf, mk2(biased_rougness, NdotV));
-  f3 Lo = (((kD * albedo) / VKR_PI + specular) * rad) * NdotL;
+  f3 Lo = (((kD * albedo) * (1.0f / VKR_PI) + specular) * rad) * NdotL;
   Lo = Lo + reflection * (F0 * ssr_brdf.x + mk3(ssr_brdf.y, ssr_brdf.y, ssr_brdf.y));
   const f3 color = occlusion * (mk3(0.6f, 0.6f, 0.6f) * albedo + Lo);
   const f3 o = a.show_ao ? mk3(occlusion, occlusion, occlusion) : color;
-  *texel_ptr<uint32_t>(a.out, lx, ly) = float_to_srgb8(o.x) | (float_to_srgb8(o.y) << 8) | (float_to_srgb8(o.z) << 16);  // alpha 0
+  *texel_ptr<uint32_t>(a.out, lx, ly) =
+      float_to_srgb8_lds(o.x, s_thresh) | (float_to_srgb8_lds(o.y, s_thresh) << 8) | (float_to_srgb8_lds(o.z, s_thresh) << 16);  // alpha 0
 }
 
 }  // namespace vkr

@@ -212,6 +212,20 @@ template <class F> VKR_DEV typename F::T sample(const Tex& t, f2 uv, int offx = 
 VKR_DEV void srgb_lut_stage(float* lds_lut, int tid, int nthreads) {
   for (int i = tid; i < VKR_SRGB_LUT_SIZE; i += nthreads) lds_lut[i] = __uint_as_float(k_srgb_decode_bits[i]);
 }
+// linear -> sRGB8 against a threshold table staged in LDS (same binary search as float_to_srgb8)
+VKR_DEV void srgb_thresh_stage(float* lds_thresh, int tid, int nthreads) {
+  for (int i = tid; i < VKR_SRGB_LUT_SIZE; i += nthreads) lds_thresh[i] = __uint_as_float(k_srgb_thresh_bits[i]);
+}
+VKR_DEV uint32_t float_to_srgb8_lds(float x, const float* thresh) {
+  if (x != x) return 0u;
+  int lo = 0, hi = 255;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (thresh[mid] <= x) lo = mid; else hi = mid - 1;
+  }
+  return (uint32_t)lo;
+}
 VKR_DEV uint32_t load_u32_clamped(const Tex& t, int gx, int gy) {
   int lx = iclamp(gx - t.ox, 0, t.w - 1), ly = iclamp(gy - t.oy, 0, t.h - 1);
   return *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);

@@ -10,7 +10,7 @@ from . import abi
 
 STAGE_LUT, STAGE_GBUFFER, STAGE_PREV_DEPTH, STAGE_DOWNSAMPLE = 1, 2, 4, 8
 STAGE_HIZ_TAIL, STAGE_SSR, STAGE_GTAO, STAGE_TAA = 16, 32, 64, 128
-STAGE_SHADING, STAGE_BRDF_LUT = 256, 512
+STAGE_SHADING, STAGE_BRDF_LUT, STAGE_GTAO_MAIN_ONLY = 256, 512, 1024
 STAGE_CHAIN = STAGE_DOWNSAMPLE | STAGE_SSR | STAGE_GTAO | STAGE_TAA
 
 

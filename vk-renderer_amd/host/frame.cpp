@@ -97,6 +97,8 @@ struct PostFxFrame {
     const GTAOParams gtao_params{normal_mat, fazz.x, fazz.y, fazz.z, fazz.w};
     const AdvancedSSRParams assr_params{normal_mat, fazz.x, fazz.y, fazz.z, fazz.w};
     if (mask & VKRH_STAGE_SSR) ssr.run(graph, assr_params, draw_params, gbuffer, gtao.raw);  // main.cpp:375
+    if (mask & VKRH_STAGE_GTAO_MAIN_ONLY)
+      gtao.add_main_pass(graph, gtao_params, gbuffer.depth, gbuffer.normal, gbuffer.material, ssr.get_preintegrated_pdf());
     if (mask & VKRH_STAGE_GTAO) {                                                           // main.cpp:384-388
       gtao.add_main_pass(graph, gtao_params, gbuffer.depth, gbuffer.normal, gbuffer.material, ssr.get_preintegrated_pdf());
       gtao.add_filter_pass(graph, gtao_params, gbuffer.depth);

@@ -36,6 +36,7 @@ enum {
   VKRH_STAGE_TAA        = 1u << 7,  /* taa_pass.run (main.cpp:391)                                       */
   VKRH_STAGE_SHADING    = 1u << 8,  /* shading_pass.draw -> color_out_tex, which TAA then resolves (main.cpp:390) */
   VKRH_STAGE_BRDF_LUT   = 1u << 9,  /* ssr.preintegrate_brdf (main.cpp:270)                             */
+  VKRH_STAGE_GTAO_MAIN_ONLY = 1u << 10, /* gtao.add_main_pass alone (BASELINE configs[0])                 */
   VKRH_STAGE_CHAIN      = (1u << 3) | (1u << 5) | (1u << 6) | (1u << 7)
 };
 

@@ -153,6 +153,7 @@ class TiledFrame:
         self.device = self.backend.device
         self._xchg_s = 0.0
         self._gather_buf = None
+        self.stage_plan = None  # single-GPU only: list of stage masks run per step instead of STAGE_CHAIN
 
     # ---- set-up ---------------------------------------------------------------------------------
     def prepare(self):
@@ -184,7 +185,11 @@ class TiledFrame:
     # ---- one frame ----------------------------------------------------------------------------------
     def step(self):
         if not self.tiled:
-            self.backend.run_all()
+            if self.stage_plan:
+                for mask in self.stage_plan:
+                    self.frame.run(mask)
+            else:
+                self.backend.run_all()
             self.backend.end_frame()
             return
         self.backend.run_pre()
