@@ -143,6 +143,30 @@ typedef struct vkr_shading_push {
   uint32_t show_ao;
 } vkr_shading_push;
 
+/* ---- dormant GTAO variants ------------------------------------------- */
+/* gtao/main.frag:17-19 push constants (gtao.cpp:355-357)                                           */
+typedef struct vkr_gtao_gfx_push { float angle_offset; } vkr_gtao_gfx_push;
+/* gtao/reproject.comp:11-17 == GTAOReprojection (gtao.hpp:28-34)                                   */
+typedef struct vkr_gtao_reprojection {
+  vkr_mat4 camera_to_prev_frame;
+  float fovy, aspect, znear, zfar;
+} vkr_gtao_reprojection;
+/* gtao_opt/deinterleave.comp:6-8 (gtao.cpp:464)                                                    */
+typedef struct vkr_deinterleave_push { int32_t pattern_step; } vkr_deinterleave_push;
+/* gtao_opt/main_deinterleaved.comp:17-21 (gtao.cpp:474-478)                                        */
+typedef struct vkr_gtao_deinterleaved_push { int32_t pattern_n; uint32_t layer; float angle_offset; } vkr_gtao_deinterleaved_push;
+
+/* ---- ScreenSpaceTrace ------------------------------------------------- */
+/* screen_trace/trace.comp:14-22 == GpuParams (screen_trace.cpp:30-38)                              */
+typedef struct vkr_screen_trace_params {
+  vkr_mat4 normal_mat;
+  float random_offset, angle_offset, fovy, aspect, znear, zfar;
+} vkr_screen_trace_params;
+/* screen_trace/filter.comp:8-11 (screen_trace.cpp:103-106)                                         */
+typedef struct vkr_screen_trace_filter_push { float znear, zfar; } vkr_screen_trace_filter_push;
+/* screen_trace/accumulate.comp:7-12 (screen_trace.cpp:148-153)                                     */
+typedef struct vkr_screen_trace_accum_push { float fovy, aspect, znear, zfar; } vkr_screen_trace_accum_push;
+
 /* Parameters of the synthetic G-buffer generator (replaces the raster stage
  * scene_renderer.cpp:140-220 + gbuf/opaque_taa.{vert,frag}). */
 typedef struct vkr_synth_params {
@@ -233,6 +257,50 @@ int vkr_brdf_preintegrate(const float* halton_vec4 /*device*/, const vkr_img* ou
 int vkr_defered_shading(const vkr_img* albedo, const vkr_img* normal, const vkr_img* material, const vkr_img* depth,
                         const vkr_shading_params* consts, const vkr_img* occlusion, const vkr_img* brdf,
                         const vkr_img* reflections, const vkr_img* out, const vkr_shading_push* push, void* stream);
+
+/* program "gtao_main" (graphics): gtao.cpp:349-413 + gtao/main.frag:45-48,164-196 — full-screen
+ * triangle into `raw`; one slice, 20 samples, radius min(200/|P|, 32) px, sky -> 1.  Bindings 0 depth
+ * (view mip depth_lod), 1 GTAOParams, 2 normal; colour attachment RGBA16F (only .r is written by the
+ * shader; the unwritten components are frozen to 0).  The debug heat-map of trace_samples.glsl
+ * (binding 7, compiled out on the host side by GTAO_TRACE_SAMPLES 0) is not reproduced.            */
+int vkr_gtao_main_graphics(const vkr_img* depth, const vkr_gtao_params* params, const vkr_img* normal,
+                           const vkr_img* out_raw, const vkr_gtao_gfx_push* push, void* stream);
+
+/* program "gtao_reproject": gtao.cpp:241-284 + gtao/reproject.comp:27-66 (STATIC_REPROJECT mode:
+ * same-pixel history, mix 0.05 when |z_prev - z_cur| < 1e-6).  Bindings 0 params, 1 depth, 2 prev
+ * depth, 3 current ao (filtered), 4 previous ao, 5 out (R16F).  Floor dispatch (w/8, h/4).           */
+int vkr_gtao_reproject(const vkr_gtao_reprojection* params, const vkr_img* depth, const vkr_img* prev_depth,
+                       const vkr_img* current_ao, const vkr_img* prev_ao, const vkr_img* out, void* stream);
+
+/* program "deinterleave_depth": gtao.cpp:445-470 + gtao_opt/deinterleave.comp:10-21.  `layers` is the
+ * R32F array image, one descriptor per layer (layer = ((y & m) << step) + (x & m)).  The dispatch is
+ * (layer_w/8, layer_h/4) groups exactly as the reference records it (gtao.cpp:468), so only source
+ * texels below that extent are scattered.                                                          */
+int vkr_deinterleave_depth(const vkr_img* depth, const vkr_img* layers, uint32_t layer_count,
+                           const vkr_deinterleave_push* push, void* stream);
+
+/* program "main_deinterleaved": gtao.cpp:472-526 + gtao_opt/main_deinterleaved.comp:38-124.  One
+ * dispatch of (out_w/8, out_h/4) groups for push->layer; stores outside `out` are dropped.          */
+int vkr_gtao_main_deinterleaved(const vkr_img* layers, uint32_t layer_count, const vkr_gtao_params* params,
+                                const vkr_img* normal, const vkr_img* out_raw,
+                                const vkr_gtao_deinterleaved_push* push, void* stream);
+
+/* program "screen_trace_main": screen_trace.cpp:23-95 + screen_trace/trace.comp:27-37,230-343
+ * (trace_tangent_space, 1 direction).  Bindings 0 depth (mip 0), 1 normal, 2 colour, 3 material,
+ * 4 out RGBA16F, 5 Params.  Floor dispatch (w/8, h/8).  The 8x8 tile exchange through shared memory
+ * is resolved as if `barrier()` followed the stores (trace.comp:310-311 has only a memory barrier);
+ * slots of sky pixels, which return before writing theirs, read as "no hit".                       */
+int vkr_screen_trace_main(const vkr_img* depth, const vkr_img* normal, const vkr_img* color, const vkr_img* material,
+                          const vkr_img* out_raw, const vkr_screen_trace_params* params, void* stream);
+
+/* program "screen_trace_filter": screen_trace.cpp:97-140 + screen_trace/filter.comp:13-39.           */
+int vkr_screen_trace_filter(const vkr_img* raw, const vkr_img* depth, const vkr_img* out_filtered,
+                            const vkr_screen_trace_filter_push* push, void* stream);
+
+/* program "screen_trace_accumulate": screen_trace.cpp:142-181 + screen_trace/accumulate.comp:21-40
+ * (accum is read and written in place).                                                            */
+int vkr_screen_trace_accumulate(const vkr_img* depth, const vkr_img* prev_depth, const vkr_img* current,
+                                const vkr_img* accum_inout, const vkr_screen_trace_accum_push* push, void* stream);
 
 /* synthetic G-buffer generator (no reference program).  Any of the
  * colour outputs may be NULL when VKR_SYNTH_DEPTH_ONLY is set.                          */

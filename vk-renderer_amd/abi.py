@@ -121,6 +121,35 @@ class ShadingPush(C.Structure):
     _fields_ = [("min_max_roughness", C.c_float * 2), ("show_ao", C.c_uint32)]
 
 
+class GtaoGfxPush(C.Structure):
+    _fields_ = [("angle_offset", C.c_float)]
+
+
+class GtaoReprojection(C.Structure):
+    _fields_ = [("camera_to_prev_frame", Mat4), ("fovy", C.c_float), ("aspect", C.c_float), ("znear", C.c_float), ("zfar", C.c_float)]
+
+
+class DeinterleavePush(C.Structure):
+    _fields_ = [("pattern_step", C.c_int32)]
+
+
+class GtaoDeinterleavedPush(C.Structure):
+    _fields_ = [("pattern_n", C.c_int32), ("layer", C.c_uint32), ("angle_offset", C.c_float)]
+
+
+class ScreenTraceParams(C.Structure):
+    _fields_ = [("normal_mat", Mat4), ("random_offset", C.c_float), ("angle_offset", C.c_float), ("fovy", C.c_float),
+                ("aspect", C.c_float), ("znear", C.c_float), ("zfar", C.c_float)]
+
+
+class ScreenTraceFilterPush(C.Structure):
+    _fields_ = [("znear", C.c_float), ("zfar", C.c_float)]
+
+
+class ScreenTraceAccumPush(C.Structure):
+    _fields_ = [("fovy", C.c_float), ("aspect", C.c_float), ("znear", C.c_float), ("zfar", C.c_float)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("camera_to_world", Mat4), ("prev_mvp", Mat4), ("mvp", Mat4), ("fovy", C.c_float), ("aspect", C.c_float),
                 ("znear", C.c_float), ("zfar", C.c_float), ("seed", C.c_uint32), ("flags", C.c_uint32)]
@@ -146,6 +175,15 @@ ENTRY_ARGS = {
     "ssr": [_IMG, _IMG, _IMG, P(SsrParams), _IMG, _IMG],
     "brdf_preintegrate": [C.c_void_p, _IMG],
     "defered_shading": [_IMG, _IMG, _IMG, _IMG, P(ShadingParams), _IMG, _IMG, _IMG, _IMG, P(ShadingPush)],
+    # dormant GTAO variants; `layers` = array of per-layer descriptors + count
+    "gtao_main_graphics": [_IMG, P(GtaoParams), _IMG, _IMG, P(GtaoGfxPush)],
+    "gtao_reproject": [P(GtaoReprojection), _IMG, _IMG, _IMG, _IMG, _IMG],
+    "deinterleave_depth": [_IMG, _IMG, C.c_uint32, P(DeinterleavePush)],
+    "gtao_main_deinterleaved": [_IMG, C.c_uint32, P(GtaoParams), _IMG, _IMG, P(GtaoDeinterleavedPush)],
+    # ScreenSpaceTrace (row R2)
+    "screen_trace_main": [_IMG, _IMG, _IMG, _IMG, _IMG, P(ScreenTraceParams)],
+    "screen_trace_filter": [_IMG, _IMG, _IMG, P(ScreenTraceFilterPush)],
+    "screen_trace_accumulate": [_IMG, _IMG, _IMG, _IMG, P(ScreenTraceAccumPush)],
 }
 
 

@@ -270,6 +270,77 @@ class PostFxChain:
                   C.byref(self.depth.desc()), C.byref(p), C.byref(self.acc_ao.desc()), C.byref(self.brdf.desc()),
                   C.byref(self.blurred.desc()), C.byref(self.color_out.desc()), C.byref(push))
 
+    # ---- passes the reference ships but never records ------------------
+    def _half_img(self, fmt, name):
+        if not hasattr(self, name):
+            setattr(self, name, ImageBuf(fmt, self.raw.width, self.raw.height, device=self.device, full=self.raw.full, origin=self.raw.origin))
+        return getattr(self, name)
+
+    def gtao_main_graphics(self, angle_offset=60.0 / 360.0):
+        """gtao.cpp:349-413 add_main_pass_graphics -> raw (program "gtao_main")."""
+        push = abi.GtaoGfxPush(angle_offset)
+        self.call("gtao_main_graphics", C.byref(self.depth.desc(1, 1)), C.byref(self.setup.gtao_params()), C.byref(self.normal.desc()),
+                  C.byref(self.raw.desc()), C.byref(push))
+
+    def gtao_reproject(self):
+        """gtao.cpp:241-284 add_reprojection_pass: filtered + prev_frame -> output (all R16F)."""
+        prev, out = self._half_img(abi.FMT_R16_SFLOAT, "ao_prev_frame"), self._half_img(abi.FMT_R16_SFLOAT, "ao_output")
+        p = abi.GtaoReprojection()
+        p.camera_to_prev_frame = abi.Mat4.from_np(np.eye(4))
+        p.fovy, p.aspect, p.znear, p.zfar = [float(v) for v in self.setup.fazz]
+        self.call("gtao_reproject", C.byref(p), C.byref(self.depth.desc(1, 1)), C.byref(self.prev_depth.desc(1, 1)),
+                  C.byref(self.filtered.desc()), C.byref(prev.desc()), C.byref(out.desc()))
+
+    def _layer_descs(self, pattern_n):
+        step = 1 << pattern_n
+        if not hasattr(self, "deint_layers"):
+            self.deint_layers = [ImageBuf(abi.FMT_R32_SFLOAT, self.raw.width // step, self.raw.height // step, device=self.device)
+                                 for _ in range(step * step)]
+        arr = (abi.VkrImg * len(self.deint_layers))()
+        for i, l in enumerate(self.deint_layers):
+            arr[i] = l.desc()
+        return arr
+
+    def deinterleave_depth(self, pattern_n=2):
+        """gtao.cpp:445-470 deinterleave_depth (program "deinterleave_depth")."""
+        arr = self._layer_descs(pattern_n)
+        self.call("deinterleave_depth", C.byref(self.depth.desc(1, 1)), arr, len(arr), C.byref(abi.DeinterleavePush(pattern_n)))
+
+    def gtao_main_deinterleaved(self, layer=0, pattern_n=2, angle_offset=60.0 / 360.0):
+        """gtao.cpp:472-526 add_main_pass_deinterleaved, one dispatch (program "main_deinterleaved")."""
+        arr = self._layer_descs(pattern_n)
+        push = abi.GtaoDeinterleavedPush(pattern_n, layer, angle_offset)
+        self.call("gtao_main_deinterleaved", arr, len(arr), C.byref(self.setup.gtao_params()), C.byref(self.normal.desc()),
+                  C.byref(self.raw.desc()), C.byref(push))
+
+    def _full_img(self, name):
+        if not hasattr(self, name):
+            setattr(self, name, ImageBuf(abi.FMT_RGBA16_SFLOAT, self.albedo.width, self.albedo.height, device=self.device))
+        return getattr(self, name)
+
+    def screen_trace(self, angle_offset=60.0 / 360.0, random_offset=0.25, color=None):
+        """screen_trace.cpp:23-95 ScreenSpaceTrace::add_main_pass -> st_raw (full-res RGBA16F)."""
+        out = self._full_img("st_raw")
+        p = abi.ScreenTraceParams()
+        p.normal_mat = abi.Mat4.from_np(self.setup.normal_mat)
+        p.random_offset, p.angle_offset = random_offset, angle_offset
+        p.fovy, p.aspect, p.znear, p.zfar = [float(v) for v in self.setup.fazz]
+        color = color or self.albedo
+        self.call("screen_trace_main", C.byref(self.depth.desc(0, 1)), C.byref(self.normal.desc()), C.byref(color.desc()),
+                  C.byref(self.material.desc()), C.byref(out.desc()), C.byref(p))
+
+    def screen_trace_filter(self):
+        """screen_trace.cpp:97-140: st_raw -> st_filtered."""
+        znear, zfar = float(self.setup.fazz[2]), float(self.setup.fazz[3])
+        self.call("screen_trace_filter", C.byref(self._full_img("st_raw").desc()), C.byref(self.depth.desc(0, 1)),
+                  C.byref(self._full_img("st_filtered").desc()), C.byref(abi.ScreenTraceFilterPush(znear, zfar)))
+
+    def screen_trace_accumulate(self):
+        """screen_trace.cpp:142-181: st_filtered -> st_accumulated (in place)."""
+        push = abi.ScreenTraceAccumPush(*[float(v) for v in self.setup.fazz])
+        self.call("screen_trace_accumulate", C.byref(self.depth.desc(0, 1)), C.byref(self.prev_depth.desc(0, 1)),
+                  C.byref(self._full_img("st_filtered").desc()), C.byref(self._full_img("st_accumulated").desc()), C.byref(push))
+
     def frame(self):
         """One steady-state frame of the chain: D1 D2 S1 S2 S3 G1 G2 G3 T (main.cpp:347-391)."""
         self.downsample()

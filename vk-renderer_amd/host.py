@@ -11,6 +11,7 @@ from . import abi
 STAGE_LUT, STAGE_GBUFFER, STAGE_PREV_DEPTH, STAGE_DOWNSAMPLE = 1, 2, 4, 8
 STAGE_HIZ_TAIL, STAGE_SSR, STAGE_GTAO, STAGE_TAA = 16, 32, 64, 128
 STAGE_SHADING, STAGE_BRDF_LUT, STAGE_GTAO_MAIN_ONLY = 256, 512, 1024
+STAGE_GTAO_GRAPHICS, STAGE_GTAO_DEINTERLEAVED, STAGE_SCREEN_TRACE = 2048, 4096, 8192
 STAGE_CHAIN = STAGE_DOWNSAMPLE | STAGE_SSR | STAGE_GTAO | STAGE_TAA
 
 
@@ -43,6 +44,8 @@ def lib():
         l.vkrh_run.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_end_frame.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_image.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(abi.VkrImg)]
+        l.vkrh_image_layer.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(abi.VkrImg)]
+        l.vkrh_pin_screen_trace.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint32]
         l.vkrh_last_tasks.argtypes = [C.c_void_p]
         l.vkrh_last_tasks.restype = C.c_char_p
         l.vkrh_enable_task_timing.argtypes = [C.c_void_p, C.c_uint32]
@@ -122,6 +125,9 @@ class HostFrame:
         """angle_offset = table[frame_count % 12]/360 + jitter (gtao.cpp:109-111); SURVEY 8(d) pins 60/360 + 0."""
         self._check(lib().vkrh_pin_randoms(self.h, angle_jitter, gtao_frame_count, ssr_counter))
 
+    def pin_screen_trace(self, angle_jitter=0.0, random_offset=0.25, frame_count=0):
+        self._check(lib().vkrh_pin_screen_trace(self.h, angle_jitter, random_offset, frame_count))
+
     def run(self, mask):
         self._check(lib().vkrh_run(self.h, mask))
 
@@ -150,11 +156,15 @@ class HostFrame:
     def last_tasks(self):
         return lib().vkrh_last_tasks(self.h).decode().split()
 
-    def download(self, name):
-        """Copies the named image into a host ImageBuf with the same layout rules (tests)."""
+    def download(self, name, layer=None):
+        """Copies the named image (or one layer of an array image) into a host ImageBuf with the same layout rules (tests)."""
         from .images import ImageBuf
 
-        d = self.image(name)
+        if layer is None:
+            d = self.image(name)
+        else:
+            d = abi.VkrImg()
+            self._check(lib().vkrh_image_layer(self.h, name.encode(), layer, C.byref(d)))
         buf = ImageBuf(d.format, d.width, d.height, d.mip_count, full=(d.full_width, d.full_height), origin=(d.origin_x, d.origin_y))
         for i in range(d.mip_count):
             assert buf.pitch[i] == d.pitch_bytes[i] and buf.offset[i] == d.mip_offset[i], "layout rules diverged"

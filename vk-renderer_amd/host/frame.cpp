@@ -15,6 +15,7 @@
 #include "downsample_pass.hpp"
 #include "gtao.hpp"
 #include "scene_renderer.hpp"
+#include "screen_trace.hpp"
 #include "synthetic_gbuffer.hpp"
 #include "taa.hpp"
 
@@ -40,6 +41,7 @@ struct PostFxFrame {
   DeferedShadingPass shading_pass;
   rendergraph::ImageResourceId color_out_tex;
   SyntheticGbuffer synth;
+  ScreenSpaceTrace screen_trace;
 
   DrawTAAParams draw_params{};
   glm::mat4 projection, view, prev_view;
@@ -52,7 +54,8 @@ struct PostFxFrame {
         gtao{graph, c.width, c.height, false, true},  // main.cpp:265: (graph, W, H, USE_RAY_QUERY = 0, half_res = 1)
         ssr{graph, c.width, c.height},
         taa_pass{graph, c.width, c.height},
-        shading_pass{graph, nullptr} {
+        shading_pass{graph, nullptr},
+        screen_trace{graph, c.width, c.height} {
     if (c.tiled) gbuffer.enable_tiling(graph, c.full_width, c.full_height);
     // main.cpp:289-291
     color_out_tex = graph.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R8G8B8A8_SRGB, VK_IMAGE_ASPECT_COLOR_BIT, c.width, c.height},
@@ -104,6 +107,23 @@ struct PostFxFrame {
       gtao.add_filter_pass(graph, gtao_params, gbuffer.depth);
       gtao.add_accumulate_pass(graph, draw_params, gbuffer);
     }
+    // ---- passes the reference ships but never records ----
+    if (mask & VKRH_STAGE_GTAO_GRAPHICS) {
+      gtao.add_main_pass_graphics(graph, gtao_params, gbuffer.depth, gbuffer.normal);
+      gtao.add_filter_pass(graph, gtao_params, gbuffer.depth);
+      const GTAOReprojection reprojection{prev_view * glm::inverse(view), fazz.x, fazz.y, fazz.z, fazz.w};
+      gtao.add_reprojection_pass(graph, reprojection, gbuffer.depth, gbuffer.prev_depth);
+    }
+    if (mask & VKRH_STAGE_GTAO_DEINTERLEAVED) {
+      gtao.deinterleave_depth(graph, gbuffer.depth);
+      gtao.add_main_pass_deinterleaved(graph, gtao_params, gbuffer.normal);
+    }
+    if (mask & VKRH_STAGE_SCREEN_TRACE) {
+      const ScreenTraceParams st_params{normal_mat, fazz.x, fazz.y, fazz.z, fazz.w};
+      screen_trace.add_main_pass(graph, st_params, gbuffer.depth, gbuffer.normal, gbuffer.albedo, gbuffer.material);
+      screen_trace.add_filter_pass(graph, st_params, gbuffer.depth);
+      screen_trace.add_accumulate_pass(graph, st_params, gbuffer.depth, gbuffer.prev_depth);
+    }
     // main.cpp:343,390-391: shading composes albedo / AO / reflections into color_out_tex, which TAA
     // resolves.  Without the shading stage TAA resolves the albedo attachment (the headline
     // composite of BASELINE.json is the nine passes without shading).
@@ -131,7 +151,8 @@ struct PostFxFrame {
         {"depth", 0}, {"prev_depth", 1}, {"normal", 2}, {"albedo", 3}, {"material", 4}, {"velocity", 5}, {"dn", 6}, {"dv", 7},
         {"raw", 8}, {"filtered", 9}, {"acc_ao", 10}, {"acc_hist", 11}, {"rays", 12}, {"reflections", 13}, {"blurred", 14},
         {"blurred_hist", 15}, {"pdf", 16}, {"taa_hist", 17}, {"taa_target", 18}, {"frame_hiz", 19}, {"frame_normals", 20},
-        {"frame_albedo", 21}, {"color_out", 22}, {"brdf", 23}};
+        {"frame_albedo", 21}, {"color_out", 22}, {"brdf", 23}, {"ao_prev_frame", 24}, {"ao_output", 25}, {"deinterleaved_depth", 26},
+        {"st_raw", 27}, {"st_filtered", 28}, {"st_accumulated", 29}};
     auto it = ids.find(name);
     if (it == ids.end()) throw std::runtime_error{"vkrh_image: unknown image '" + name + "'"};
     switch (it->second) {
@@ -142,7 +163,9 @@ struct PostFxFrame {
       case 13: return ssr.get_ouput(); case 14: return ssr.get_blurred(); case 15: return ssr.get_blurred_history();
       case 16: return ssr.get_preintegrated_pdf(); case 17: return taa_pass.get_history(); case 18: return taa_pass.get_output();
       case 19: return gbuffer.frame_hiz; case 20: return gbuffer.frame_normals; case 21: return gbuffer.frame_albedo;
-      case 22: return color_out_tex; default: return ssr.get_preintegrated_brdf();
+      case 22: return color_out_tex; case 23: return ssr.get_preintegrated_brdf(); case 24: return gtao.prev_frame;
+      case 25: return gtao.output; case 26: return gtao.deinterleaved_depth; case 27: return screen_trace.raw;
+      case 28: return screen_trace.filtered; default: return screen_trace.accumulated;
     }
   }
 };
@@ -185,6 +208,13 @@ int vkrh_pin_randoms(void* frame, float jitter, uint32_t gtao_frame_count, uint3
     f->ssr.set_counter(ssr_counter);
   });
 }
+int vkrh_pin_screen_trace(void* frame, float angle_jitter, float random_offset, uint32_t frame_count) {
+  return guarded([&] {
+    auto* f = (PostFxFrame*)frame;
+    f->screen_trace.pin_randoms(angle_jitter, random_offset);
+    f->screen_trace.set_frame_count(frame_count);
+  });
+}
 int vkrh_set_gtao_mode(void* frame, uint32_t use_mis, uint32_t two_directions) {
   return guarded([&] { auto* f = (PostFxFrame*)frame; f->gtao.set_mis(use_mis != 0); f->gtao.set_two_directions(two_directions != 0); });
 }
@@ -197,6 +227,13 @@ int vkrh_image(void* frame, const char* name, uint32_t base_mip, uint32_t mip_co
     auto& img = f->graph.get_image(f->lookup(name));
     if (mip_count == 0) mip_count = img->get_mip_levels() - base_mip;
     *out = img->describe(base_mip, mip_count);
+  });
+}
+int vkrh_image_layer(void* frame, const char* name, uint32_t layer, vkr_img* out) {
+  return guarded([&] {
+    auto* f = (PostFxFrame*)frame;
+    if (!f || !name || !out) throw std::runtime_error{"NULL argument"};
+    *out = f->graph.get_image(f->lookup(name))->describe_layer(layer);
   });
 }
 int vkrh_enable_task_timing(void* frame, uint32_t on) { return guarded([&] { ((PostFxFrame*)frame)->graph.enable_task_timing(on != 0); }); }

@@ -37,6 +37,10 @@ enum {
   VKRH_STAGE_SHADING    = 1u << 8,  /* shading_pass.draw -> color_out_tex, which TAA then resolves (main.cpp:390) */
   VKRH_STAGE_BRDF_LUT   = 1u << 9,  /* ssr.preintegrate_brdf (main.cpp:270)                             */
   VKRH_STAGE_GTAO_MAIN_ONLY = 1u << 10, /* gtao.add_main_pass alone (BASELINE configs[0])                 */
+  /* passes the reference ships but never records                           */
+  VKRH_STAGE_GTAO_GRAPHICS      = 1u << 11, /* gtao.add_main_pass_graphics, add_filter_pass, add_reprojection_pass */
+  VKRH_STAGE_GTAO_DEINTERLEAVED = 1u << 12, /* gtao.deinterleave_depth, add_main_pass_deinterleaved                */
+  VKRH_STAGE_SCREEN_TRACE       = 1u << 13, /* ScreenSpaceTrace main, filter, accumulate                           */
   VKRH_STAGE_CHAIN      = (1u << 3) | (1u << 5) | (1u << 6) | (1u << 7)
 };
 
@@ -53,6 +57,8 @@ const char* vkrh_last_error(void);
 int vkrh_set_camera(void* frame, const vkrh_camera* cam);
 /* pin the host-side randoms of the reference (gtao.cpp:109-111 rand(), advanced_ssr.cpp:168-171 counter) */
 int vkrh_pin_randoms(void* frame, float gtao_angle_jitter, uint32_t gtao_frame_count, uint32_t ssr_counter);
+/* pin ScreenSpaceTrace's per-frame randoms (screen_trace.cpp:49-53) */
+int vkrh_pin_screen_trace(void* frame, float angle_jitter, float random_offset, uint32_t frame_count);
 int vkrh_set_gtao_mode(void* frame, uint32_t use_mis, uint32_t two_directions);
 /* record the stages in `mask` (canonical order) and submit them on the stream */
 int vkrh_run(void* frame, uint32_t stage_mask);
@@ -60,6 +66,8 @@ int vkrh_run(void* frame, uint32_t stage_mask);
 int vkrh_end_frame(void* frame, uint32_t swap_depth);
 /* current descriptor of a named image ("depth", "taa_target", ...) */
 int vkrh_image(void* frame, const char* name, uint32_t base_mip, uint32_t mip_count, vkr_img* out);
+/* one layer of a named array image ("deinterleaved_depth") */
+int vkrh_image_layer(void* frame, const char* name, uint32_t layer, vkr_img* out);
 /* per-task device timing with HIP events on the frame's stream */
 int vkrh_enable_task_timing(void* frame, uint32_t on);
 /* synchronises and returns "name total_ms launches\n" lines accumulated since the last call */

@@ -94,6 +94,13 @@ vkr_img Image::describe(uint32_t base_mip, uint32_t count) const {
   return d;
 }
 
+vkr_img Image::describe_layer(uint32_t layer) const {
+  if (layer >= get_array_layers() || info.mip_levels != 1) throw std::runtime_error{"Image layer view outside the array"};
+  vkr_img d = describe(0, 1);
+  d.base = (uint8_t*)d.base + uint64_t(pitch[0]) * info.height * layer;
+  return d;
+}
+
 Buffer::Buffer(VmaMemoryUsage memory, uint64_t sz, VkBufferUsageFlags usage) : size{sz} {
   dev = device_alloc((sz + 255) & ~uint64_t(255));
   // host shadow: mapped (CPU_TO_GPU) buffers, and uniform buffers — their contents become kernel
@@ -300,6 +307,57 @@ void register_hot_path_programs() {
       vkr_img out = st.attachments[0].image->describe(st.attachments[0].range.base_mip, 1);
       return vkr_defered_shading(&albedo, &normal, &material, &depth, ubo<vkr_shading_params>(st, 4, P), &occlusion, &brdf, &refl, &out,
                                  push<vkr_shading_push>(st, P), st.stream);
+    });
+    // ---- dormant GTAO variants ----
+    // gtao/main.frag: set {0 depth, 1 GTAOParams, 2 normal}; colour attachment raw
+    create_program("gtao_main", [=](LaunchState& st) {
+      const char* P = "gtao_main";
+      if (st.attachments.size() != 1) throw std::runtime_error{"gtao_main: expects one colour attachment"};
+      vkr_img depth = tex(st, 0, T, P), normal = tex(st, 2, T, P);
+      vkr_img out = st.attachments[0].image->describe(st.attachments[0].range.base_mip, 1);
+      return vkr_gtao_main_graphics(&depth, ubo<vkr_gtao_params>(st, 1, P), &normal, &out, push<vkr_gtao_gfx_push>(st, P), st.stream);
+    });
+    create_program("gtao_reproject", [=](LaunchState& st) {
+      const char* P = "gtao_reproject";
+      vkr_img depth = tex(st, 1, T, P), pdepth = tex(st, 2, T, P), ao = tex(st, 3, T, P), pao = tex(st, 4, T, P), out = tex(st, 5, S, P);
+      return vkr_gtao_reproject(ubo<vkr_gtao_reprojection>(st, 0, P), &depth, &pdepth, &ao, &pao, &out, st.stream);
+    });
+    auto layers_of = [](const LaunchState& st, uint32_t slot, SetSlot::Kind kind, const char* prog) {
+      const SetSlot& s = st.set ? st.set->slots[slot] : SetSlot{};
+      if (!st.set || s.kind != kind || !s.view.image)
+        throw std::runtime_error{std::string{prog} + ": binding " + std::to_string(slot) + " is not bound as expected"};
+      std::vector<vkr_img> layers;
+      for (uint32_t l = 0; l < s.view.image->get_array_layers(); l++) layers.push_back(s.view.image->describe_layer(l));
+      return layers;
+    };
+    create_program("deinterleave_depth", [=](LaunchState& st) {
+      const char* P = "deinterleave_depth";
+      vkr_img depth = tex(st, 0, T, P);
+      auto layers = layers_of(st, 1, S, P);
+      return vkr_deinterleave_depth(&depth, layers.data(), (uint32_t)layers.size(), push<vkr_deinterleave_push>(st, P), st.stream);
+    });
+    create_program("main_deinterleaved", [=](LaunchState& st) {
+      const char* P = "main_deinterleaved";
+      auto layers = layers_of(st, 0, T, P);
+      vkr_img normal = tex(st, 2, T, P), out = tex(st, 3, S, P);
+      return vkr_gtao_main_deinterleaved(layers.data(), (uint32_t)layers.size(), ubo<vkr_gtao_params>(st, 1, P), &normal, &out,
+                                         push<vkr_gtao_deinterleaved_push>(st, P), st.stream);
+    });
+    // ---- ScreenSpaceTrace (row R2) ----
+    create_program("screen_trace_main", [=](LaunchState& st) {
+      const char* P = "screen_trace_main";
+      vkr_img depth = tex(st, 0, T, P), normal = tex(st, 1, T, P), color = tex(st, 2, T, P), material = tex(st, 3, T, P), out = tex(st, 4, S, P);
+      return vkr_screen_trace_main(&depth, &normal, &color, &material, &out, ubo<vkr_screen_trace_params>(st, 5, P), st.stream);
+    });
+    create_program("screen_trace_filter", [=](LaunchState& st) {
+      const char* P = "screen_trace_filter";
+      vkr_img raw = tex(st, 0, T, P), depth = tex(st, 1, T, P), out = tex(st, 2, S, P);
+      return vkr_screen_trace_filter(&raw, &depth, &out, push<vkr_screen_trace_filter_push>(st, P), st.stream);
+    });
+    create_program("screen_trace_accumulate", [=](LaunchState& st) {
+      const char* P = "screen_trace_accumulate";
+      vkr_img depth = tex(st, 0, T, P), pdepth = tex(st, 1, T, P), cur = tex(st, 2, T, P), acc = tex(st, 3, S, P);
+      return vkr_screen_trace_accumulate(&depth, &pdepth, &cur, &acc, push<vkr_screen_trace_accum_push>(st, P), st.stream);
     });
     // synthetic G-buffer "raster" program: attachments {albedo, normal, material, velocity, depth} or {depth}
     create_program("synthetic_gbuffer", [=](LaunchState& st) {

@@ -68,10 +68,13 @@ struct Image {
   const ImageInfo& get_info() const { return info; }
   VkExtent3D get_extent() const { return info.extent3D(); }
   uint32_t get_mip_levels() const { return info.mip_levels; }
+  uint32_t get_array_layers() const { return info.array_layers ? info.array_layers : 1; }
   void* device_ptr() const { return base; }
   size_t size_bytes() const { return bytes; }
   // C-ABI view of mips [base_mip, base_mip + count)
   vkr_img describe(uint32_t base_mip, uint32_t count) const;
+  // one layer of a (single-mip) array image
+  vkr_img describe_layer(uint32_t layer) const;
 
  private:
   ImageInfo info;

@@ -41,6 +41,14 @@ GTAO::GTAO(rendergraph::RenderGraph &graph, uint32_t width, uint32_t height, boo
   deinterleaved_depth = make(VK_FORMAT_R32_SFLOAT, width/pattern_step, height/pattern_step, pattern_step * pattern_step, 0);
 
   main_pipeline = gpu::create_compute_pipeline("gtao_compute_main");
+  reproject_pipeline = gpu::create_compute_pipeline("gtao_reproject");
+  deinterleave_pipeline = gpu::create_compute_pipeline("deinterleave_depth");
+  main_deinterleaved_pipeline = gpu::create_compute_pipeline("main_deinterleaved");
+  main_pipeline_gfx = gpu::create_graphics_pipeline();
+  main_pipeline_gfx.set_program("gtao_main");
+  main_pipeline_gfx.set_registers({});
+  main_pipeline_gfx.set_vertex_input({});
+  main_pipeline_gfx.set_rendersubpass({false, {graph.get_descriptor(raw).format}});
   filter_pipeline = gpu::create_compute_pipeline("gtao_filter");
   accumulate_pipeline = gpu::create_compute_pipeline("gtao_accumulate");
   sampler = gpu::create_sampler(gpu::DEFAULT_SAMPLER);
@@ -60,10 +68,7 @@ void GTAO::add_main_pass(rendergraph::RenderGraph &graph, const GTAOParams &para
   static_assert(sizeof(PushConsts) == sizeof(vkr_gtao_push), "push constants must match the C-ABI");
   static_assert(sizeof(GTAOParams) == sizeof(vkr_gtao_params), "GTAOParams must match the C-ABI");
 
-  static const float angle_offsets[12] {60.f, 300.f, 180.f, 240.f, 120.f, 0.f, 300.f, 60.f, 180.f, 120.f, 240.f, 0.f};
-  float base_angle = angle_offsets[frame_count % 12]/360.f;
-  base_angle += std::isnan(pinned_jitter)? (rand()/float(RAND_MAX) - 0.5f) : pinned_jitter;
-  frame_count += 1;
+  const float base_angle = next_base_angle();
 
   const PushConsts push_consts {base_angle, weight_ratio, mis_gtao, two_directions? 255u : 0u, only_reflections? 255u : 0u};
   const auto lod = depth_lod;
@@ -173,10 +178,143 @@ void GTAO::add_accumulate_pass(rendergraph::RenderGraph &graph, const DrawTAAPar
     });
 }
 
-static void dormant(const char *what) {
-  throw std::runtime_error {std::string {"GTAO::"} + what + ": not implemented on the HIP path (dormant in the reference frame loop)"};
+// ---- variants the reference's frame loop never records -------------------
+// Shared by the three main-pass flavours: 12-entry angle table + jitter (gtao.cpp:109-111,362-364,487-489).
+float GTAO::next_base_angle() {
+  static const float table[12] {60.f, 300.f, 180.f, 240.f, 120.f, 0.f, 300.f, 60.f, 180.f, 120.f, 240.f, 0.f};
+  const float jitter = std::isnan(pinned_jitter)? (rand()/float(RAND_MAX) - 0.5f) : pinned_jitter;
+  return table[frame_count++ % 12]/360.f + jitter;
 }
-void GTAO::add_main_pass_graphics(rendergraph::RenderGraph &, const GTAOParams &, rendergraph::ImageResourceId, rendergraph::ImageResourceId) { dormant("add_main_pass_graphics"); }
-void GTAO::add_reprojection_pass(rendergraph::RenderGraph &, const GTAOReprojection &, rendergraph::ImageResourceId, rendergraph::ImageResourceId) { dormant("add_reprojection_pass"); }
-void GTAO::deinterleave_depth(rendergraph::RenderGraph &, rendergraph::ImageResourceId) { dormant("deinterleave_depth"); }
-void GTAO::add_main_pass_deinterleaved(rendergraph::RenderGraph &, const GTAOParams &, rendergraph::ImageResourceId) { dormant("add_main_pass_deinterleaved"); }
+
+// gtao.cpp:349-413: full-screen triangle into `raw`, fragment program "gtao_main".
+void GTAO::add_main_pass_graphics(rendergraph::RenderGraph &graph, const GTAOParams &params,
+  rendergraph::ImageResourceId depth, rendergraph::ImageResourceId normal)
+{
+  struct Views { rendergraph::ImageViewId rt, depth, norm; };
+  const vkr_gtao_gfx_push pc {next_base_angle()};
+  const auto lod = depth_lod;
+
+  graph.add_task<Views>("GTAO",
+    [&](Views &v, rendergraph::RenderGraphBuilder &builder) {
+      const auto fs = VK_SHADER_STAGE_FRAGMENT_BIT;
+      v.depth = builder.sample_image(depth, fs, VK_IMAGE_ASPECT_DEPTH_BIT, lod, 1, 0, 1);
+      v.norm = builder.sample_image(normal, fs);
+      v.rt = builder.use_color_attachment(raw, 0, 0);
+    },
+    [=](Views &v, rendergraph::RenderResources &resources, gpu::CmdContext &cmd) {
+      auto ubo = cmd.allocate_ubo<GTAOParams>();
+      *ubo.ptr = params;
+      auto set = resources.allocate_set(main_pipeline_gfx, 0);
+      gpu::write_set(set,
+        gpu::TextureBinding {0, resources.get_view(v.depth), sampler},
+        gpu::UBOBinding {1, cmd.get_ubo_pool(), ubo},
+        gpu::TextureBinding {2, resources.get_view(v.norm), sampler});
+
+      const auto ext = resources.get_image(v.rt)->get_extent();
+      cmd.set_framebuffer(ext.width, ext.height, {resources.get_image_range(v.rt)});
+      cmd.bind_pipeline(main_pipeline_gfx);
+      cmd.bind_viewport(0.f, 0.f, float(ext.width), float(ext.height), 0.f, 1.f);
+      cmd.bind_scissors(0, 0, ext.width, ext.height);
+      cmd.bind_descriptors_graphics(0, {set}, {ubo.offset});
+      cmd.push_constants_graphics(VK_SHADER_STAGE_FRAGMENT_BIT, 0, sizeof(pc), &pc);
+      cmd.draw(3, 1, 0, 0);
+      cmd.end_renderpass();
+    });
+}
+
+// gtao.cpp:241-284: filtered + prev_frame -> output, program "gtao_reproject".
+void GTAO::add_reprojection_pass(rendergraph::RenderGraph &graph, const GTAOReprojection &params,
+  rendergraph::ImageResourceId depth, rendergraph::ImageResourceId prev_depth)
+{
+  static_assert(sizeof(GTAOReprojection) == sizeof(vkr_gtao_reprojection), "GTAOReprojection must match the C-ABI");
+  struct Views { rendergraph::ImageViewId out, ao, prev_ao, depth, prev_depth; };
+  const auto lod = depth_lod;
+
+  graph.add_task<Views>("GTAO_reproject",
+    [&](Views &v, rendergraph::RenderGraphBuilder &builder) {
+      const auto cs = VK_SHADER_STAGE_COMPUTE_BIT;
+      v.depth = builder.sample_image(depth, cs, VK_IMAGE_ASPECT_DEPTH_BIT, lod, 1, 0, 1);
+      v.prev_depth = builder.sample_image(prev_depth, cs, VK_IMAGE_ASPECT_DEPTH_BIT, lod, 1, 0, 1);
+      v.ao = builder.sample_image(filtered, cs);
+      v.prev_ao = builder.sample_image(prev_frame, cs);
+      v.out = builder.use_storage_image(output, cs, 0, 0);
+    },
+    [=](Views &v, rendergraph::RenderResources &resources, gpu::CmdContext &cmd) {
+      auto ubo = cmd.allocate_ubo<GTAOReprojection>();
+      *ubo.ptr = params;
+      auto set = resources.allocate_set(reproject_pipeline, 0);
+      gpu::write_set(set,
+        gpu::UBOBinding {0, cmd.get_ubo_pool(), ubo},
+        gpu::TextureBinding {1, resources.get_view(v.depth), sampler},
+        gpu::TextureBinding {2, resources.get_view(v.prev_depth), sampler},
+        gpu::TextureBinding {3, resources.get_view(v.ao), sampler},
+        gpu::TextureBinding {4, resources.get_view(v.prev_ao), sampler},
+        gpu::StorageTextureBinding {5, resources.get_view(v.out)});
+
+      const auto ext = resources.get_image(v.out)->get_extent();
+      cmd.bind_pipeline(reproject_pipeline);
+      cmd.bind_descriptors_compute(0, {set}, {ubo.offset});
+      cmd.dispatch(ext.width/8, ext.height/4, 1);
+    });
+}
+
+// gtao.cpp:445-470: depth (lod view) -> R32F array, program "deinterleave_depth".  The dispatch is
+// sized by the *array* extent, as in the reference.
+void GTAO::deinterleave_depth(rendergraph::RenderGraph &graph, rendergraph::ImageResourceId depth) {
+  struct Views { rendergraph::ImageViewId depth, out; };
+  const auto lod = depth_lod;
+  const vkr_deinterleave_push pc {deinterleave_n};
+
+  graph.add_task<Views>("GTAO_deinterleave",
+    [&](Views &v, rendergraph::RenderGraphBuilder &builder) {
+      v.depth = builder.sample_image(depth, VK_SHADER_STAGE_COMPUTE_BIT, VK_IMAGE_ASPECT_DEPTH_BIT, lod, 1, 0, 1);
+      v.out = builder.use_storage_image_array(deinterleaved_depth, VK_SHADER_STAGE_COMPUTE_BIT);
+    },
+    [=](Views &v, rendergraph::RenderResources &resources, gpu::CmdContext &cmd) {
+      auto set = resources.allocate_set(deinterleave_pipeline, 0);
+      gpu::write_set(set,
+        gpu::TextureBinding {0, resources.get_view(v.depth), sampler},
+        gpu::StorageTextureBinding {1, resources.get_view(v.out)});
+
+      const auto ext = resources.get_image(v.out)->get_extent();
+      cmd.bind_pipeline(deinterleave_pipeline);
+      cmd.bind_descriptors_compute(0, {set}, {});
+      cmd.push_constants_compute(0, sizeof(pc), &pc);
+      cmd.dispatch(ext.width/8, ext.height/4, 1);
+    });
+}
+
+// gtao.cpp:472-526: program "main_deinterleaved", one dispatch per array layer of the *output* image
+// (raw has one), exactly as the reference loops.
+void GTAO::add_main_pass_deinterleaved(rendergraph::RenderGraph &graph, const GTAOParams &params, rendergraph::ImageResourceId normal) {
+  struct Views { rendergraph::ImageViewId out, depth, norm; };
+  const float base_angle = next_base_angle();
+  const int pattern = deinterleave_n;
+
+  graph.add_task<Views>("GTAO_deinterleaved",
+    [&](Views &v, rendergraph::RenderGraphBuilder &builder) {
+      const auto cs = VK_SHADER_STAGE_COMPUTE_BIT;
+      v.depth = builder.sample_image(deinterleaved_depth, cs);
+      v.norm = builder.sample_image(normal, cs);
+      v.out = builder.use_storage_image(raw, cs, 0, 0);
+    },
+    [=](Views &v, rendergraph::RenderResources &resources, gpu::CmdContext &cmd) {
+      auto ubo = cmd.allocate_ubo<GTAOParams>();
+      *ubo.ptr = params;
+      const auto &target = resources.get_image(v.out);
+      const auto ext = target->get_extent();
+      for (uint32_t layer = 0; layer < target->get_array_layers(); layer++) {
+        auto set = resources.allocate_set(main_deinterleaved_pipeline, 0);
+        gpu::write_set(set,
+          gpu::TextureBinding {0, resources.get_view(v.depth), sampler},
+          gpu::UBOBinding {1, cmd.get_ubo_pool(), ubo},
+          gpu::TextureBinding {2, resources.get_view(v.norm), sampler},
+          gpu::StorageTextureBinding {3, resources.get_view(v.out)});
+        const vkr_gtao_deinterleaved_push pc {pattern, layer, base_angle};
+        cmd.bind_pipeline(main_deinterleaved_pipeline);
+        cmd.bind_descriptors_compute(0, {set}, {ubo.offset});
+        cmd.push_constants_compute(0, sizeof(pc), &pc);
+        cmd.dispatch(ext.width/8, ext.height/4, 1);
+      }
+    });
+}

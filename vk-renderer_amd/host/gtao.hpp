@@ -1,9 +1,11 @@
 // gtao.hpp — ground-truth ambient occlusion pass, public interface of src/gtao.hpp:10-121.
-// Implemented: the passes the reference's frame loop runs (main.cpp:384-388) — add_main_pass,
-// add_filter_pass, add_accumulate_pass, remap — over the C-ABI programs gtao_compute_main /
-// gtao_filter / gtao_accumulate.  The dormant variants of the reference (graphics main pass,
-// static reprojection, deinterleaved, ray-query; gtao.cpp:150-196,241-284,349-526) throw
-// "not implemented on the HIP path" until their kernels exist.
+// The passes the reference's frame loop runs (main.cpp:384-388) — add_main_pass, add_filter_pass,
+// add_accumulate_pass, remap — over the C-ABI programs gtao_compute_main / gtao_filter /
+// gtao_accumulate, and the variants it ships but never records: graphics
+// main pass ("gtao_main"), static reprojection ("gtao_reproject"), deinterleaved depth + main pass
+// ("deinterleave_depth", "main_deinterleaved").  The ray-query pass (add_main_rt_pass,
+// gtao.cpp:150-196) needs a scene acceleration structure and is not part of this path: the
+// constructor throws when use_ray_query is set.
 #ifndef GTAO_HPP_INCLUDED
 #define GTAO_HPP_INCLUDED
 
@@ -92,6 +94,12 @@ struct GTAO {
   void set_frame_count(uint32_t n) { frame_count = n; }
 
 private:
+  float next_base_angle();
+
+  gpu::GraphicsPipeline main_pipeline_gfx;
+  gpu::ComputePipeline reproject_pipeline;
+  gpu::ComputePipeline deinterleave_pipeline;
+  gpu::ComputePipeline main_deinterleaved_pipeline;
   gpu::ComputePipeline main_pipeline;
   gpu::ComputePipeline filter_pipeline;
   gpu::ComputePipeline accumulate_pipeline;
