@@ -143,6 +143,12 @@ typedef struct vkr_shading_push {
   uint32_t show_ao;
 } vkr_shading_push;
 
+/* ---- tile-classified trace -------------------------------------------------- */
+/* classification.comp:26-30 (advanced_ssr.cpp:463-471)                                             */
+typedef struct vkr_classification_push { int32_t width, height; float max_roughness, glossy_value; } vkr_classification_push;
+/* trace_indirect.comp:25-28 (advanced_ssr.cpp:231-236)                                             */
+typedef struct vkr_trace_indirect_push { uint32_t reflection_type; float max_roughness; } vkr_trace_indirect_push;
+
 /* ---- dormant GTAO variants ------------------------------------------- */
 /* gtao/main.frag:17-19 push constants (gtao.cpp:355-357)                                           */
 typedef struct vkr_gtao_gfx_push { float angle_offset; } vkr_gtao_gfx_push;
@@ -257,6 +263,29 @@ int vkr_brdf_preintegrate(const float* halton_vec4 /*device*/, const vkr_img* ou
 int vkr_defered_shading(const vkr_img* albedo, const vkr_img* normal, const vkr_img* material, const vkr_img* depth,
                         const vkr_shading_params* consts, const vkr_img* occlusion, const vkr_img* brdf,
                         const vkr_img* reflections, const vkr_img* out, const vkr_shading_push* push, void* stream);
+
+/* SSSR_Clear (advanced_ssr.cpp:440-452): VkDispatchIndirectCommand{0,1,1} into both 3-word device
+ * argument buffers.                                                                                */
+int vkr_sssr_clear_indirect(uint32_t* reflective_args, uint32_t* glossy_args, void* stream);
+
+/* program "sssr_classification": advanced_ssr.cpp:454-495 + classification.comp:38-98.  Appends
+ * every 8x8 tile of the half-res extent (push->width/height = extent of `rays`) to the reflective
+ * list when its mean roughness is below push->glossy_value, else to the glossy list; the tile
+ * counts accumulate in word 0 of the argument buffers.  List order is unspecified (atomics), as in
+ * the reference.  Bindings 0 material, 1/2 tile lists, 3/4 indirect arguments.                      */
+int vkr_sssr_classification(const vkr_img* material, int32_t* reflective_tiles, int32_t* glossy_tiles,
+                            uint32_t* reflective_args, uint32_t* glossy_args,
+                            const vkr_classification_push* push, void* stream);
+
+/* program "sssr_trace_indirect": advanced_ssr.cpp:216-302 + trace_indirect.comp:43-135, one
+ * dispatch_indirect (push->reflection_type 0 = mirror: march from mip 0, <= 50 steps; 1 = glossy:
+ * from mip 1, <= 25 steps).  Bindings 0 depth (view of mips 1..L-1), 1 normal, 2 material,
+ * 3 TraceParams, 4 Halton, 5 rays, 6 tile list.  `indirect_args` word 0 is read on the device;
+ * `max_tiles` = capacity of the tile list (launch bound).                                          */
+int vkr_sssr_trace_indirect(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                            const vkr_trace_params* params, const float* halton_vec4 /*device*/, const vkr_img* out_rays,
+                            const int32_t* tiles /*device*/, const uint32_t* indirect_args /*device*/, uint32_t max_tiles,
+                            const vkr_trace_indirect_push* push, void* stream);
 
 /* program "gtao_main" (graphics): gtao.cpp:349-413 + gtao/main.frag:45-48,164-196 — full-screen
  * triangle into `raw`; one slice, 20 samples, radius min(200/|P|, 32) px, sky -> 1.  Bindings 0 depth

@@ -361,3 +361,111 @@ extern "C" int vkr_ref_sssr_blur(const vkr_img* depth, const vkr_img* normal, co
   }
   return 0;
 }
+
+// ---- tile-classified trace (advanced_ssr.cpp:216-302,440-495) --------------------
+
+// advanced_ssr.cpp:447-450
+extern "C" int vkr_ref_sssr_clear_indirect(uint32_t* reflective_args, uint32_t* glossy_args) {
+  const uint32_t initial[3] = {0, 1, 1};
+  std::memcpy(reflective_args, initial, sizeof(initial));
+  std::memcpy(glossy_args, initial, sizeof(initial));
+  return 0;
+}
+
+// classification.comp:38-98.  Tiles are visited in row-major order here; the shader appends them in
+// whatever order its atomics resolve, so only the *set* of each list is defined.
+extern "C" int vkr_ref_sssr_classification(const vkr_img* material, int32_t* reflective_tiles, int32_t* glossy_tiles,
+                                           uint32_t* reflective_args, uint32_t* glossy_args,
+                                           const vkr_classification_push* push) {
+  Image MATERIAL_TEX(*material);
+  const int TILE = 8;
+  const int W = push->width, H = push->height;
+  const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
+  for (int ty = 0; ty < tiles_y; ty++) {
+    for (int tx = 0; tx < tiles_x; tx++) {
+      float g_roughness[64];
+      for (int t = 0; t < 64; t++) {
+        const int px = tx * TILE + (t & 7), py = ty * TILE + (t >> 3);
+        float sampled_roughness = 1.0f;
+        if (px < W && py < H) sampled_roughness = MATERIAL_TEX.sample(vec2((float)px / (float)W, (float)py / (float)H)).y;
+        g_roughness[t] = mix(0.0f, push->max_roughness, sampled_roughness);
+      }
+      for (uint32_t offset = 32; offset != 0; offset /= 2)  // :72-80, all threads of a step read before any writes
+        for (uint32_t t = 0; t < offset; t++) g_roughness[t] += g_roughness[t + offset];
+      const float average_roughness = g_roughness[0] / 64.0f;
+      const int tile_index = ty * tiles_x + tx;
+      if (average_roughness < push->glossy_value) reflective_tiles[reflective_args[0]++] = tile_index;
+      else glossy_tiles[glossy_args[0]++] = tile_index;
+    }
+  }
+  return 0;
+}
+
+// trace_indirect.comp:43-135, for the indirect_args[0] tiles of the list
+extern "C" int vkr_ref_sssr_trace_indirect(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                                           const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_rays,
+                                           const int32_t* tiles, const uint32_t* indirect_args, uint32_t max_tiles,
+                                           const vkr_trace_indirect_push* push) {
+  Image DEPTH(*depth), NORMAL(*normal), MATERIAL(*material), OUT_RAY(*out_rays);
+  const vkr_trace_params& p = *params;
+  mat4 normal_mat;
+  std::memcpy(normal_mat.m, p.normal_mat.m, 64);
+  const int TILE = 8;
+  const int tw = OUT_RAY.fw(), th = OUT_RAY.fh();
+  const int tile_width = (tw + TILE - 1) / TILE;
+  const uint32_t count = indirect_args[0] < max_tiles ? indirect_args[0] : max_tiles;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (uint32_t g = 0; g < count; g++) {
+    const int tile_index = tiles[g];
+    for (int t = 0; t < TILE * TILE; t++) {
+      const int gx = TILE * (tile_index % tile_width) + (t & 7), gy = TILE * (tile_index / tile_width) + (t >> 3);
+      const vec2 tex_size((float)tw, (float)th);
+      const vec2 screen_uv((float)gx / tex_size.x, (float)gy / tex_size.y);
+      if (gx >= tw || gy >= th) continue;
+      float roughness = MATERIAL.sample(screen_uv).y;
+      roughness = mix(0.0f, push->max_roughness, roughness);
+      roughness *= roughness;
+      const float pixel_depth = DEPTH.sample(screen_uv).x;
+      const vec3 pixel_normal_world = sample_gbuffer_normal(NORMAL, screen_uv);
+      const vec3 pixel_normal = normalize((normal_mat * vec4(pixel_normal_world, 0.0f)).xyz());
+      const vec3 view_vec = reconstruct_view_vec(screen_uv, pixel_depth, p.fovy, p.aspect, p.znear, p.zfar);
+      const uint32_t base_index = f2u(rand_co(screen_uv) * (float)VKR_HALTON_SEQ_SIZE);
+      const uint32_t index = (base_index + p.frame_random) & (VKR_HALTON_SEQ_SIZE - 1);
+      const vec2 rnd(halton_vec4[4 * index + 0], halton_vec4[4 * index + 1]);
+      vec3 tangent = get_tangent(pixel_normal);
+      const vec3 bitangent = normalize(cross(pixel_normal, tangent));
+      tangent = normalize(cross(bitangent, pixel_normal));
+      vec3 view_dir = -normalize(view_vec);
+      view_dir = vec3(dot(view_dir, tangent), dot(view_dir, bitangent), dot(view_dir, pixel_normal));
+      const vec3 brdf_norm = sampleGGXVNDF(view_dir, roughness, roughness, rnd.x, rnd.y);
+      const vec3 N = (brdf_norm.x * tangent + brdf_norm.y * bitangent) + brdf_norm.z * pixel_normal;
+      const vec3 R = reflect(view_vec, N);
+      vec3 ray_start = project_view_vec(view_vec + 0.001f * pixel_normal, p.fovy, p.aspect, p.znear, p.zfar);
+      ray_start.z -= 0.0001f;
+      vec3 ray_dir = project_view_vec(view_vec + R, p.fovy, p.aspect, p.znear, p.zfar);
+      ray_dir -= ray_start;
+      ray_dir *= (1.0f - ray_start.z) / ray_dir.z;
+      bool valid_hit = false;
+      vec3 out_r;
+      if (push->reflection_type == 0) out_r = hierarchical_raymarch(DEPTH, ray_start, ray_dir, 0, 50, valid_hit);
+      else out_r = hierarchical_raymarch(DEPTH, ray_start, ray_dir, 1, 25, valid_hit);
+      if (valid_hit) {
+        const vec2 ray_step = abs(out_r.xy() - ray_start.xy()) * tex_size;
+        if (max(ray_step.x, ray_step.y) < 2.0f) valid_hit = false;
+      }
+      if (valid_hit) {
+        const vec3 hit_normal_world = sample_gbuffer_normal(NORMAL, out_r.xy());
+        const vec3 hit_normal = (normal_mat * vec4(hit_normal_world, 0.0f)).xyz();
+        if (dot(hit_normal, R) > 0.0f || dot(pixel_normal, R) < 0.0f) valid_hit = false;
+      }
+      if (valid_hit && push->reflection_type == 0) {
+        const float hit_depth = DEPTH.sample(out_r.xy(), 0).x;
+        const float hit_z = linearize_depth2(hit_depth, p.znear, p.zfar);
+        const float ray_z = linearize_depth2(out_r.z, p.znear, p.zfar);
+        if (ray_z > hit_z + 0.3f || ray_z < hit_z - 0.1f) valid_hit = false;
+      }
+      OUT_RAY.store(gx, gy, vec4(out_r, valid_hit ? pixel_depth : 1.0f));
+    }
+  }
+  return 0;
+}

@@ -52,3 +52,38 @@ def test_remap_and_ordering(report):
 def test_misc_errors(report):
     assert "ray-query" in report["ray_query_gtao"]
     assert report["ubo_ring_overflow"] == "Not enough space in uniform buffer"
+
+
+def test_capture_writers(tmp_path):
+    """the capture formats of main.cpp:118-176 — CSV of 24-bit hex depth with the reference's
+    exact header / separators, PNG of the masked depth words, PNG of RGBA8 with alpha forced to 255."""
+    import numpy as np
+    from PIL import Image
+
+    if not os.path.exists(abi.HOST_LIB):
+        pytest.skip("host library not built yet")
+    from vk_renderer_amd import host
+
+    l = host.lib()
+    l.vkrh_selftest_writers.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32]
+    W, H = 37, 11
+    assert l.vkrh_selftest_writers(str(tmp_path).encode(), W, H) == 0, l.vkrh_last_error().decode()
+    x, y = np.meshgrid(np.arange(W, dtype=np.uint64), np.arange(H, dtype=np.uint64))
+    depth = ((x * 65537 + y * 257 + 0xAB000000) & 0xFFFFFFFF).astype(np.uint32) & 0xFFFFFF
+
+    lines = (tmp_path / "depth.csv").read_text().split("\n")
+    assert lines[0] == "y, " + ",".join(str(i) for i in range(W))  # main.cpp:123-131
+    assert lines[-1] == "" and len(lines) == H + 2
+    for row in range(H):
+        cells = lines[1 + row].split(",")
+        assert cells[0] == str(row)
+        assert cells[1:] == ["0x%x" % v for v in depth[row]]  # std::hex: lower case, no padding
+
+    png = np.array(Image.open(tmp_path / "depth.png"))
+    assert png.shape == (H, W, 4)
+    words = png.astype(np.uint32)
+    assert np.array_equal(words[..., 0] | (words[..., 1] << 8) | (words[..., 2] << 16) | (words[..., 3] << 24), depth)
+
+    col = np.array(Image.open(tmp_path / "color.png"))
+    assert np.array_equal(col[..., 0], (x & 0xFF).astype(np.uint8)) and np.array_equal(col[..., 1], (y & 0xFF).astype(np.uint8))
+    assert np.array_equal(col[..., 2], ((x ^ y) & 0xFF).astype(np.uint8)) and np.all(col[..., 3] == 255)

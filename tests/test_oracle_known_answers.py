@@ -402,3 +402,24 @@ def test_screen_trace_sky_and_range(oracle_lib):
     a = raw[:th, :tw, 3]
     assert a.min() >= 0.0 and a.max() <= 1.0 + 1e-3
     assert uvx[0] == 0.0
+
+
+def test_tile_classification_partition(oracle_lib):
+    """classification.comp: every 8x8 tile lands in exactly one list; the threshold moves tiles monotonically from
+    glossy to reflective; glossy_value above max_roughness classifies everything as reflective."""
+    c = _variant_chain(256, 144)
+    w2, h2 = 128, 72
+    total = ((w2 + 7) // 8) * ((h2 + 7) // 8)
+    prev_reflective = -1
+    for g in (0.0, 0.3, 0.5, 0.8, 1.01):
+        c.ssr_classify(glossy_value=g)
+        nr, ng = int(c.reflective_args[0]), int(c.glossy_args[0])
+        assert list(c.reflective_args[1:]) == [1, 1] and list(c.glossy_args[1:]) == [1, 1]
+        assert nr + ng == total
+        both = np.concatenate([c.reflective_tiles[:nr], c.glossy_tiles[:ng]])
+        assert np.array_equal(np.sort(both), np.arange(total))
+        assert nr >= prev_reflective
+        prev_reflective = nr
+    assert prev_reflective == total
+    c.ssr_classify(glossy_value=0.0)
+    assert int(c.reflective_args[0]) == 0

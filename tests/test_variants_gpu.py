@@ -170,3 +170,99 @@ def test_host_mirror_variants(oracle_lib):
     ref.screen_trace_accumulate()
     check("st_accumulated", ref.st_accumulated)
     frame.close()
+
+
+def test_readback_captures(tmp_path, oracle_lib):
+    """ReadBackSystem (image_readback.cpp) + capture writers on real device images: the CSV / PNG files hold exactly
+    the bytes of the images they were read from."""
+    import numpy as np
+    from PIL import Image
+
+    from vk_renderer_amd import host
+    from vk_renderer_amd.camera import FrameSetup
+
+    W, H = 256, 144
+    frame = host.HostFrame(FrameSetup(W, H), device="cuda")
+    frame.run(host.STAGE_GBUFFER | host.STAGE_PREV_DEPTH)
+    frame.run(host.STAGE_DOWNSAMPLE)
+    for mip in (0, 1):
+        frame.capture("depth", tmp_path / f"d{mip}.csv", host.HostFrame.CAPTURE_DEPTH_CSV, mip=mip)
+        want = frame.download("depth").raw(mip)[..., 0] & 0xFFFFFF
+        rows = (tmp_path / f"d{mip}.csv").read_text().split("\n")[1:-1]
+        got = np.array([[int(c, 16) for c in r.split(",")[1:]] for r in rows], dtype=np.uint32)
+        assert np.array_equal(got, want)
+    frame.capture("depth", tmp_path / "d.png", host.HostFrame.CAPTURE_DEPTH_PNG)
+    png = np.array(Image.open(tmp_path / "d.png")).astype(np.uint32)
+    want = frame.download("depth").raw(0)[..., 0] & 0xFFFFFF
+    assert np.array_equal(png[..., 0] | (png[..., 1] << 8) | (png[..., 2] << 16), want) and np.all(png[..., 3] == 0)
+    frame.capture("albedo", tmp_path / "a.png", host.HostFrame.CAPTURE_RGBA_PNG)
+    col = np.array(Image.open(tmp_path / "a.png"))
+    raw = frame.download("albedo").raw(0)
+    assert np.array_equal(col[..., :3], raw[..., :3]) and np.all(col[..., 3] == 255)
+    frame.close()
+
+
+@pytest.mark.parametrize("size,glossy", [((256, 144), 0.5), ((648, 360), 0.35)])
+def test_tile_classified_trace(size, glossy, oracle_lib):
+    """SSSR_Clear + classification.comp + trace_indirect.comp.  The tile lists are sets (the shader
+    appends with atomics); the rays image they produce is compared texel by texel."""
+    ref, gpu = _prepared(size, oracle_lib)
+    for c in (ref, gpu):
+        c.ssr_classify(glossy_value=glossy)
+    ra, ga = ref.buffer_to_host(ref.reflective_args), gpu.buffer_to_host(gpu.reflective_args)
+    rg, gg = ref.buffer_to_host(ref.glossy_args), gpu.buffer_to_host(gpu.glossy_args)
+    assert list(ra) == list(ga) and list(rg) == list(gg) and list(ra[1:]) == [1, 1]
+    w2, h2 = size[0] // 2, size[1] // 2
+    assert int(ra[0]) + int(rg[0]) == ((w2 + 7) // 8) * ((h2 + 7) // 8)
+    print(f"[parity] tiles: reflective {int(ra[0])} glossy {int(rg[0])}")
+    assert int(ra[0]) > 0 and int(rg[0]) > 0, "the test scene must populate both tile classes"
+    for name, n in (("reflective_tiles", int(ra[0])), ("glossy_tiles", int(rg[0]))):
+        a = np.sort(ref.buffer_to_host(getattr(ref, name))[:n])
+        b = np.sort(gpu.buffer_to_host(getattr(gpu, name))[:n])
+        assert np.array_equal(a, b), f"{name}: tile sets differ"
+    # sentinel fill: every texel of the window must be written by exactly one of the two dispatches
+    for c in (ref, gpu):
+        h = c.rays.to_host()
+        h[:] = 0x5A
+        c.rays.upload(h)
+        c.ssr_trace_indirect(frame_random=3)
+    _compare(ref, gpu, ("rays",), budget=1e-4)
+    raw = ref.rays.raw(0)
+    assert not np.all(raw == 0x5A5A, axis=-1).any(), "some texels were not traced"
+    valid = int((raw[..., 3] != 0xFFFF).sum())
+    print(f"[parity] indirect trace valid hits {valid}")
+    assert valid > 0.01 * w2 * h2
+
+
+def test_host_mirror_classified_ssr(oracle_lib):
+    """AdvancedSSR::run with Settings::use_tile_classification: SSSR_Clear, SSSR_Classification, two indirect trace
+    dispatches, then filter and blur — through the rendergraph mirror, against the oracle chain."""
+    from vk_renderer_amd import host
+    from vk_renderer_amd.camera import FrameSetup
+    from vk_renderer_amd.chain import PostFxChain
+    from parity import mismatches
+
+    W, H = 512, 288
+    setup = FrameSetup(W, H)
+    frame = host.HostFrame(setup, device="cuda")
+    frame.run(host.STAGE_LUT | host.STAGE_GBUFFER | host.STAGE_PREV_DEPTH)
+    frame.run(host.STAGE_DOWNSAMPLE)
+    ref = PostFxChain(W, H, backend="oracle", setup=setup)
+    for name in ("depth", "prev_depth", "normal", "albedo", "material", "velocity", "dn", "dv"):
+        getattr(ref, name).upload(frame.download(name).to_host())
+    frame.pin_randoms(0.0, 0, 5)
+    frame.run(host.STAGE_SSR_CLASSIFIED)
+    assert frame.last_tasks() == ["SSSR_Clear", "SSSR_Classification", "SSSR_trace", "SSSR_filter", "SSSR_blur"]
+    ref.ssr_classify()
+    nr, ng = int(ref.reflective_args[0]), int(ref.glossy_args[0])
+    assert list(frame.read_buffer("reflective_indirect")) == [nr, 1, 1] and list(frame.read_buffer("glossy_indirect")) == [ng, 1, 1]
+    assert np.array_equal(np.sort(frame.read_buffer("reflective_tiles")[:nr]), np.sort(ref.reflective_tiles[:nr]))
+    assert np.array_equal(np.sort(frame.read_buffer("glossy_tiles")[:ng]), np.sort(ref.glossy_tiles[:ng]))
+    ref.ssr_trace_indirect(frame_random=5)
+    ref.ssr_filter()
+    ref.ssr_blur()
+    for host_name, img in (("rays", ref.rays), ("reflections", ref.reflections), ("blurred", ref.blurred)):
+        bad = int(mismatches(img.format, frame.download(host_name).decode(), img.decode()).sum())
+        print(f"[parity] host {host_name:14s} outside-tol {bad}")
+        assert bad <= 1e-4 * img.width * img.height
+    frame.close()

@@ -121,6 +121,14 @@ class ShadingPush(C.Structure):
     _fields_ = [("min_max_roughness", C.c_float * 2), ("show_ao", C.c_uint32)]
 
 
+class ClassificationPush(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_roughness", C.c_float), ("glossy_value", C.c_float)]
+
+
+class TraceIndirectPush(C.Structure):
+    _fields_ = [("reflection_type", C.c_uint32), ("max_roughness", C.c_float)]
+
+
 class GtaoGfxPush(C.Structure):
     _fields_ = [("angle_offset", C.c_float)]
 
@@ -175,6 +183,10 @@ ENTRY_ARGS = {
     "ssr": [_IMG, _IMG, _IMG, P(SsrParams), _IMG, _IMG],
     "brdf_preintegrate": [C.c_void_p, _IMG],
     "defered_shading": [_IMG, _IMG, _IMG, _IMG, P(ShadingParams), _IMG, _IMG, _IMG, _IMG, P(ShadingPush)],
+    # tile-classified trace: tile lists / indirect args are raw device (oracle: host) pointers
+    "sssr_clear_indirect": [C.c_void_p, C.c_void_p],
+    "sssr_classification": [_IMG, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(ClassificationPush)],
+    "sssr_trace_indirect": [_IMG, _IMG, _IMG, P(TraceParams), C.c_void_p, _IMG, C.c_void_p, C.c_void_p, C.c_uint32, P(TraceIndirectPush)],
     # dormant GTAO variants; `layers` = array of per-layer descriptors + count
     "gtao_main_graphics": [_IMG, P(GtaoParams), _IMG, _IMG, P(GtaoGfxPush)],
     "gtao_reproject": [P(GtaoReprojection), _IMG, _IMG, _IMG, _IMG, _IMG],

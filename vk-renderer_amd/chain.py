@@ -270,6 +270,49 @@ class PostFxChain:
                   C.byref(self.depth.desc()), C.byref(p), C.byref(self.acc_ao.desc()), C.byref(self.brdf.desc()),
                   C.byref(self.blurred.desc()), C.byref(self.color_out.desc()), C.byref(push))
 
+    # ---- tile-classified trace (advanced_ssr.cpp:216-302,440-495; commented out of AdvancedSSR::run) ----
+    def _i32_buffer(self, n):
+        if self.device is None:
+            return np.zeros(n, dtype=np.int32)
+        import torch
+
+        return torch.zeros(n, dtype=torch.int32, device=self.device)
+
+    @staticmethod
+    def _buf_ptr(b):
+        return C.c_void_p(b.ctypes.data if isinstance(b, np.ndarray) else b.data_ptr())
+
+    def buffer_to_host(self, b):
+        if isinstance(b, np.ndarray):
+            return b.copy()
+        self.sync()
+        return b.cpu().numpy()
+
+    def ssr_classify(self, max_roughness=1.0, glossy_value=0.5):
+        """SSSR_Clear + SSSR_Classification: fills reflective/glossy tile lists and their indirect arguments."""
+        w2, h2 = self.rays.full
+        if not hasattr(self, "reflective_tiles"):
+            # advanced_ssr.cpp:81-83: sizeof(int) * (w*h/64) with the full-res extent
+            cap = max(1, (w2 * 2) * (h2 * 2) // 64)
+            self.tile_capacity = cap
+            self.reflective_tiles, self.glossy_tiles = self._i32_buffer(cap), self._i32_buffer(cap)
+            self.reflective_args, self.glossy_args = self._i32_buffer(3), self._i32_buffer(3)
+        self.call("sssr_clear_indirect", self._buf_ptr(self.reflective_args), self._buf_ptr(self.glossy_args))
+        push = abi.ClassificationPush(w2, h2, max_roughness, glossy_value)
+        self.call("sssr_classification", C.byref(self.material.desc()), self._buf_ptr(self.reflective_tiles), self._buf_ptr(self.glossy_tiles),
+                  self._buf_ptr(self.reflective_args), self._buf_ptr(self.glossy_args), C.byref(push))
+
+    def ssr_trace_indirect(self, frame_random=None, max_roughness=1.0):
+        """run_trace_indirect_pass: mirror tiles then glossy tiles into `rays`."""
+        tp = self.setup.trace_params(frame_random)
+        dview = self.frame_hiz.desc() if self.tiled else self.depth.desc(1, self.depth.mips - 1)
+        normal = self.frame_normals if self.tiled else self.dn
+        for kind, tiles, args in ((0, self.reflective_tiles, self.reflective_args), (1, self.glossy_tiles, self.glossy_args)):
+            push = abi.TraceIndirectPush(kind, max_roughness)
+            self.call("sssr_trace_indirect", C.byref(dview), C.byref(normal.desc()), C.byref(self.material.desc()), C.byref(tp),
+                      self._halton_ptr(), C.byref(self.rays.desc()), self._buf_ptr(tiles), self._buf_ptr(args), self.tile_capacity,
+                      C.byref(push))
+
     # ---- passes the reference ships but never records (SURVEY 8a rows G4, R2) ------------------
     def _half_img(self, fmt, name):
         if not hasattr(self, name):

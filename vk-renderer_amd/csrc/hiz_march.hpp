@@ -21,6 +21,7 @@ struct MarchEnv {
   f2 uv_offset_abs;
   Proj pr;
   float horizon_d2;  // smallest d2 with sqrtf(d2) >= 0.3f: |v| < 0.3 <=> dot(v,v) < horizon_d2
+  int min_mip = 0;   // most_detailed_mip: the march ends when it would refine below it; uv_offset_abs carries its 2^min_mip
 };
 
 // One step of the march; returns false when the ray is finished.  HORIZON / PIN_STEPS = 15 / max 80 is
@@ -70,7 +71,7 @@ VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, i
       st.h = vmax(st.h, h2);
     }
   }
-  return st.i < max_steps && st.mip >= 0;
+  return st.i < max_steps && st.mip >= env.min_mip;
 }
 
 
@@ -79,14 +80,17 @@ VKR_DEV uint4 mip_descriptor(const Tex& m) {
   const uint64_t base = (uint64_t)m.p;
   return make_uint4((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)m.pitch, (uint32_t)m.w | ((uint32_t)m.h << 16));
 }
-// initial_advance_ray (screen_trace.glsl:8-15) at most_detailed_mip = 0
+// initial_advance_ray (screen_trace.glsl:8-15) on the resolution of most_detailed_mip (env.min_mip)
 VKR_DEV float initial_advance(const MarchEnv& env, const RayConst& rc) {
   const f2 uv_offset = mk2(rc.direction.x < 0.0f ? -env.uv_offset_abs.x : env.uv_offset_abs.x,
                            rc.direction.y < 0.0f ? -env.uv_offset_abs.y : env.uv_offset_abs.y);
   const f2 floor_offset = mk2(rc.direction.x < 0.0f ? 0.0f : 1.0f, rc.direction.y < 0.0f ? 0.0f : 1.0f);
-  const f2 cur_pos = env.screen_size * xy(rc.origin);
+  const float scale = __builtin_ldexpf(1.0f, -env.min_mip), scale_inv = __builtin_ldexpf(1.0f, env.min_mip);
+  const f2 res = mk2(env.screen_size.x * scale, env.screen_size.y * scale);
+  const f2 res_inv = mk2(env.screen_size_inv.x * scale_inv, env.screen_size_inv.y * scale_inv);
+  const f2 cur_pos = res * xy(rc.origin);
   f2 xy_plane = mk2(floorf(cur_pos.x), floorf(cur_pos.y)) + floor_offset;
-  xy_plane = xy_plane * env.screen_size_inv + uv_offset;
+  xy_plane = xy_plane * res_inv + uv_offset;
   const f2 t = (xy_plane - xy(rc.origin)) * xy(rc.inv_direction);
   return vmin(t.x, t.y);
 }

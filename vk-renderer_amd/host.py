@@ -12,6 +12,7 @@ STAGE_LUT, STAGE_GBUFFER, STAGE_PREV_DEPTH, STAGE_DOWNSAMPLE = 1, 2, 4, 8
 STAGE_HIZ_TAIL, STAGE_SSR, STAGE_GTAO, STAGE_TAA = 16, 32, 64, 128
 STAGE_SHADING, STAGE_BRDF_LUT, STAGE_GTAO_MAIN_ONLY = 256, 512, 1024
 STAGE_GTAO_GRAPHICS, STAGE_GTAO_DEINTERLEAVED, STAGE_SCREEN_TRACE = 2048, 4096, 8192
+STAGE_SSR_CLASSIFIED = 16384
 STAGE_CHAIN = STAGE_DOWNSAMPLE | STAGE_SSR | STAGE_GTAO | STAGE_TAA
 
 
@@ -46,6 +47,8 @@ def lib():
         l.vkrh_image.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(abi.VkrImg)]
         l.vkrh_image_layer.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(abi.VkrImg)]
         l.vkrh_pin_screen_trace.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint32]
+        l.vkrh_capture.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p]
+        l.vkrh_read_buffer.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         l.vkrh_last_tasks.argtypes = [C.c_void_p]
         l.vkrh_last_tasks.restype = C.c_char_p
         l.vkrh_enable_task_timing.argtypes = [C.c_void_p, C.c_uint32]
@@ -138,6 +141,19 @@ class HostFrame:
         d = abi.VkrImg()
         self._check(lib().vkrh_image(self.h, name.encode(), base_mip, mip_count, C.byref(d)))
         return d
+
+    CAPTURE_DEPTH_CSV, CAPTURE_DEPTH_PNG, CAPTURE_RGBA_PNG = 0, 1, 2
+
+    def capture(self, name, path, kind, mip=0):
+        """ReadBackSystem + the capture writers of main.cpp:118-176 (SURVEY.md 8(f) #3)."""
+        self._check(lib().vkrh_capture(self.h, name.encode(), mip, kind, str(path).encode()))
+
+    def read_buffer(self, name, max_bytes=1 << 24):
+        """int32 contents of a named device buffer of the SSR pass (tile lists, indirect arguments)."""
+        dst = np.zeros(max_bytes // 4, dtype=np.int32)
+        n = C.c_uint64(0)
+        self._check(lib().vkrh_read_buffer(self.h, name.encode(), C.c_void_p(dst.ctypes.data), dst.nbytes, C.byref(n)))
+        return dst[: n.value // 4]
 
     def enable_task_timing(self, on=True):
         self._check(lib().vkrh_enable_task_timing(self.h, 1 if on else 0))

@@ -39,6 +39,8 @@ AdvancedSSR::AdvancedSSR(rendergraph::RenderGraph &graph, uint32_t w, uint32_t h
   blur_pass = gpu::create_compute_pipeline("sssr_blur");
   preintegrate_pass = gpu::create_compute_pipeline("pdf_preintegrate");
   preintegrate_brdf_pass = gpu::create_compute_pipeline("brdf_preintegrate");
+  classification_pass = gpu::create_compute_pipeline("sssr_classification");
+  trace_indirect_pass = gpu::create_compute_pipeline("sssr_trace_indirect");
 
   // xy: the reference's table (advanced_ssr.cpp:22-34); zw: cos/sin of 2*PI*y evaluated on the host
   // for the HIP trace kernel (vkr_halton23_fill, include/vkr_postfx.h) — zero in the reference
@@ -70,6 +72,14 @@ AdvancedSSR::AdvancedSSR(rendergraph::RenderGraph &graph, uint32_t w, uint32_t h
   preintegrated_brdf = make(VK_FORMAT_R16G16_SFLOAT, 1024, 1024);
 
   sampler = gpu::create_sampler(gpu::DEFAULT_SAMPLER);
+
+  // advanced_ssr.cpp:77-83: indirect arguments and one tile-index slot per 8x8 block of the full-res frame
+  const auto indirect_usage = VK_BUFFER_USAGE_STORAGE_BUFFER_BIT|VK_BUFFER_USAGE_INDIRECT_BUFFER_BIT|VK_BUFFER_USAGE_TRANSFER_DST_BIT;
+  reflective_indirect = graph.create_buffer(VMA_MEMORY_USAGE_GPU_ONLY, sizeof(VkDispatchIndirectCommand), indirect_usage);
+  glossy_indirect = graph.create_buffer(VMA_MEMORY_USAGE_GPU_ONLY, sizeof(VkDispatchIndirectCommand), indirect_usage);
+  const uint64_t tile_bytes = sizeof(int) * std::max<uint64_t>(1, uint64_t(w) * h/64);
+  reflective_tiles = graph.create_buffer(VMA_MEMORY_USAGE_GPU_ONLY, tile_bytes, VK_BUFFER_USAGE_STORAGE_BUFFER_BIT);
+  glossy_tiles = graph.create_buffer(VMA_MEMORY_USAGE_GPU_ONLY, tile_bytes, VK_BUFFER_USAGE_STORAGE_BUFFER_BIT);
 }
 
 void AdvancedSSR::preintegrate_pdf(rendergraph::RenderGraph &graph) {
@@ -268,10 +278,115 @@ void AdvancedSSR::run_blur_pass(rendergraph::RenderGraph &graph, const AdvancedS
     });
 }
 
+// advanced_ssr.cpp:440-452
+void AdvancedSSR::clear_indirect_params(rendergraph::RenderGraph &graph) {
+  struct Nothing {};
+  graph.add_task<Nothing>("SSSR_Clear",
+    [&](Nothing &, rendergraph::RenderGraphBuilder &builder) {
+      builder.transfer_write(reflective_indirect);
+      builder.transfer_write(glossy_indirect);
+    },
+    [=](Nothing &, rendergraph::RenderResources &resources, gpu::CmdContext &cmd) {
+      const VkDispatchIndirectCommand none {0, 1, 1};
+      for (auto id : {reflective_indirect, glossy_indirect})
+        cmd.update_buffer(resources.get_buffer(id)->api_buffer(), 0, none);
+    });
+}
+
+// advanced_ssr.cpp:454-495
+void AdvancedSSR::run_classification_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &, const Gbuffer &gbuff) {
+  struct Input { rendergraph::ImageViewId material_tex; };
+  const auto extent = graph.get_descriptor(rays).extent2D();
+  const vkr_classification_push pc {int(extent.width), int(extent.height), settings.max_rougness, settings.glossy_roughness_value};
+
+  graph.add_task<Input>("SSSR_Classification",
+    [&](Input &in, rendergraph::RenderGraphBuilder &builder) {
+      const auto cs = VK_SHADER_STAGE_COMPUTE_BIT;
+      in.material_tex = builder.sample_image(gbuff.material, cs);
+      for (auto id : {reflective_indirect, glossy_indirect, reflective_tiles, glossy_tiles})
+        builder.use_storage_buffer(id, cs, false);
+    },
+    [=](Input &in, rendergraph::RenderResources &resources, gpu::CmdContext &cmd) {
+      auto set = resources.allocate_set(classification_pass, 0);
+      gpu::write_set(set,
+        gpu::TextureBinding {0, resources.get_view(in.material_tex), sampler},
+        gpu::SSBOBinding {1, resources.get_buffer(reflective_tiles)},
+        gpu::SSBOBinding {2, resources.get_buffer(glossy_tiles)},
+        gpu::SSBOBinding {3, resources.get_buffer(reflective_indirect)},
+        gpu::SSBOBinding {4, resources.get_buffer(glossy_indirect)});
+
+      cmd.bind_pipeline(classification_pass);
+      cmd.bind_descriptors_compute(0, {set});
+      cmd.push_constants_compute(0, sizeof(pc), &pc);
+      cmd.dispatch((extent.width + 7)/8, (extent.height + 7)/8, 1);
+    });
+}
+
+// advanced_ssr.cpp:216-302: two indirect dispatches of one program, mirror tiles then glossy tiles
+void AdvancedSSR::run_trace_indirect_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff) {
+  const TraceParams config {params.normal_mat, counter, params.fovy, params.aspect, params.znear, params.zfar};
+  const float max_roughness = settings.max_rougness;
+
+  if (settings.update_random) {
+    counter++;
+    counter = counter % settings.max_accumulated_rays;
+  }
+
+  struct Input { rendergraph::ImageViewId depth, normal, material, out; };
+  const bool tiled = gbuff.tiled;
+  const auto hiz = tiled? gbuff.frame_hiz : gbuff.depth;
+  const auto normals = tiled? gbuff.frame_normals : gbuff.downsampled_normals;
+  const auto mips_count = graph.get_descriptor(hiz).mip_levels;
+
+  graph.add_task<Input>("SSSR_trace",
+    [&](Input &in, rendergraph::RenderGraphBuilder &builder) {
+      const auto cs = VK_SHADER_STAGE_COMPUTE_BIT;
+      in.depth = tiled? builder.sample_image(hiz, cs, VK_IMAGE_ASPECT_DEPTH_BIT, 0, mips_count, 0, 1)
+                      : builder.sample_image(hiz, cs, VK_IMAGE_ASPECT_DEPTH_BIT, 1, mips_count - 1, 0, 1);
+      in.normal = builder.sample_image(normals, cs);
+      in.material = builder.sample_image(gbuff.material, cs);
+      in.out = builder.use_storage_image(rays, cs, 0, 0);
+      builder.use_indirect_buffer(reflective_indirect);
+      builder.use_indirect_buffer(glossy_indirect);
+      builder.use_storage_buffer(reflective_tiles, cs);
+      builder.use_storage_buffer(glossy_tiles, cs);
+    },
+    [=](Input &in, rendergraph::RenderResources &resources, gpu::CmdContext &cmd) {
+      auto blk = cmd.allocate_ubo<TraceParams>();
+      *blk.ptr = config;
+      cmd.bind_pipeline(trace_indirect_pass);
+
+      const rendergraph::BufferResourceId lists[2] {reflective_tiles, glossy_tiles};
+      const rendergraph::BufferResourceId arguments[2] {reflective_indirect, glossy_indirect};
+      for (uint32_t kind = 0; kind < 2; kind++) {  // 0 - mirror, 1 - glossy
+        auto set = resources.allocate_set(trace_indirect_pass, 0);
+        gpu::write_set(set,
+          gpu::TextureBinding {0, resources.get_view(in.depth), sampler},
+          gpu::TextureBinding {1, resources.get_view(in.normal), sampler},
+          gpu::TextureBinding {2, resources.get_view(in.material), sampler},
+          gpu::UBOBinding {3, cmd.get_ubo_pool(), blk},
+          gpu::UBOBinding {4, halton_buffer},
+          gpu::StorageTextureBinding {5, resources.get_view(in.out)},
+          gpu::SSBOBinding {6, resources.get_buffer(lists[kind])});
+
+        const vkr_trace_indirect_push pc {kind, max_roughness};
+        cmd.bind_descriptors_compute(0, {set}, {blk.offset, 0});
+        cmd.push_constants_compute(0, sizeof(pc), &pc);
+        cmd.dispatch_indirect(resources.get_buffer(arguments[kind])->api_buffer());
+      }
+    });
+}
+
 void AdvancedSSR::run(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const DrawTAAParams &taa_params,
   const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion)
 {
-  run_trace_pass(graph, params, gbuff, ssr_occlusion);
+  if (settings.use_tile_classification) {  // the path advanced_ssr.cpp:547-550 keeps commented out
+    clear_indirect_params(graph);
+    run_classification_pass(graph, params, gbuff);
+    run_trace_indirect_pass(graph, params, gbuff);
+  } else {
+    run_trace_pass(graph, params, gbuff, ssr_occlusion);
+  }
   run_filter_pass(graph, params, gbuff);
   run_blur_pass(graph, params, taa_params, gbuff);
 }

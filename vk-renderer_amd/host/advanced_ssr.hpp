@@ -1,8 +1,10 @@
 // advanced_ssr.hpp — stochastic Hi-Z screen-space reflections, public interface of
 // src/advanced_ssr.hpp:7-113.  Implemented: run() = trace -> filter -> blur (advanced_ssr.cpp:551-553),
-// preintegrate_pdf / preintegrate_brdf, remap_images, the getters.  The reference's disabled experiments
-// (tile classification, indirect trace, tile regression; advanced_ssr.cpp:547-550) are outside the
-// hot path.
+// preintegrate_pdf / preintegrate_brdf, remap_images, the getters, and the tile-classified trace the
+// reference leaves commented out of run() (advanced_ssr.cpp:547-550):
+// clear_indirect_params -> run_classification_pass -> run_trace_indirect_pass, selected with
+// Settings::use_tile_classification (default off = the reference's behaviour).  The tile-regression
+// experiment (advanced_ssr.cpp:497-538) stays out of scope.
 #ifndef ADVANCED_SSR_HPP_INCLUDED
 #define ADVANCED_SSR_HPP_INCLUDED
 
@@ -52,9 +54,19 @@ struct AdvancedSSR {
     bool update_random = true;
     bool use_blur = true;
     int max_accumulated_rays = 16;
+    bool use_tile_classification = false;  // run(): classification + indirect trace instead of run_trace_pass
   };
   Settings &get_settings() { return settings; }
   void set_counter(uint32_t c) { counter = c; }
+
+  // advanced_ssr.cpp:440-495,216-302 (private in the reference; public here so drivers can record them one by one)
+  void clear_indirect_params(rendergraph::RenderGraph &graph);
+  void run_classification_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff);
+  void run_trace_indirect_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff);
+  rendergraph::BufferResourceId get_reflective_tiles() const { return reflective_tiles; }
+  rendergraph::BufferResourceId get_glossy_tiles() const { return glossy_tiles; }
+  rendergraph::BufferResourceId get_reflective_indirect() const { return reflective_indirect; }
+  rendergraph::BufferResourceId get_glossy_indirect() const { return glossy_indirect; }
 
 private:
   gpu::BufferPtr halton_buffer;
@@ -64,6 +76,13 @@ private:
   gpu::ComputePipeline blur_pass;
   gpu::ComputePipeline preintegrate_pass;
   gpu::ComputePipeline preintegrate_brdf_pass;
+  gpu::ComputePipeline classification_pass;
+  gpu::ComputePipeline trace_indirect_pass;
+
+  rendergraph::BufferResourceId reflective_indirect;
+  rendergraph::BufferResourceId glossy_indirect;
+  rendergraph::BufferResourceId reflective_tiles;
+  rendergraph::BufferResourceId glossy_tiles;
 
   VkSampler sampler;
 

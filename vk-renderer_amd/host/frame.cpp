@@ -2,6 +2,8 @@
 // only error channel, gpu/common.cpp:6-12) are turned into status codes at this C boundary.
 #include "frame.hpp"
 
+#include <hip/hip_runtime_api.h>
+
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -14,6 +16,7 @@
 #include "defered_shading.hpp"
 #include "downsample_pass.hpp"
 #include "gtao.hpp"
+#include "image_readback.hpp"
 #include "scene_renderer.hpp"
 #include "screen_trace.hpp"
 #include "synthetic_gbuffer.hpp"
@@ -42,6 +45,7 @@ struct PostFxFrame {
   rendergraph::ImageResourceId color_out_tex;
   SyntheticGbuffer synth;
   ScreenSpaceTrace screen_trace;
+  ReadBackSystem readback;
 
   DrawTAAParams draw_params{};
   glm::mat4 projection, view, prev_view;
@@ -99,7 +103,10 @@ struct PostFxFrame {
     const glm::mat4 normal_mat = glm::transpose(glm::inverse(view));
     const GTAOParams gtao_params{normal_mat, fazz.x, fazz.y, fazz.z, fazz.w};
     const AdvancedSSRParams assr_params{normal_mat, fazz.x, fazz.y, fazz.z, fazz.w};
-    if (mask & VKRH_STAGE_SSR) ssr.run(graph, assr_params, draw_params, gbuffer, gtao.raw);  // main.cpp:375
+    if (mask & (VKRH_STAGE_SSR | VKRH_STAGE_SSR_CLASSIFIED)) {                               // main.cpp:375
+      ssr.get_settings().use_tile_classification = (mask & VKRH_STAGE_SSR_CLASSIFIED) != 0;
+      ssr.run(graph, assr_params, draw_params, gbuffer, gtao.raw);
+    }
     if (mask & VKRH_STAGE_GTAO_MAIN_ONLY)
       gtao.add_main_pass(graph, gtao_params, gbuffer.depth, gbuffer.normal, gbuffer.material, ssr.get_preintegrated_pdf());
     if (mask & VKRH_STAGE_GTAO) {                                                           // main.cpp:384-388
@@ -229,11 +236,83 @@ int vkrh_image(void* frame, const char* name, uint32_t base_mip, uint32_t mip_co
     *out = img->describe(base_mip, mip_count);
   });
 }
+int vkrh_read_buffer(void* frame, const char* name, void* dst, uint64_t capacity, uint64_t* bytes) {
+  return guarded([&] {
+    auto* f = (PostFxFrame*)frame;
+    if (!f || !name || !dst) throw std::runtime_error{"NULL argument"};
+    const std::string n{name};
+    rendergraph::BufferResourceId id;
+    if (n == "reflective_tiles") id = f->ssr.get_reflective_tiles();
+    else if (n == "glossy_tiles") id = f->ssr.get_glossy_tiles();
+    else if (n == "reflective_indirect") id = f->ssr.get_reflective_indirect();
+    else if (n == "glossy_indirect") id = f->ssr.get_glossy_indirect();
+    else throw std::runtime_error{"vkrh_read_buffer: unknown buffer '" + n + "'"};
+    auto& buf = f->graph.get_buffer(id);
+    const uint64_t size = buf->get_size();
+    if (bytes) *bytes = size;
+    if (capacity < size) throw std::runtime_error{"vkrh_read_buffer: destination too small"};
+    void* stream = f->graph.get_stream();
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
+        hipMemcpy(dst, buf->device_ptr(stream), size, hipMemcpyDeviceToHost) != hipSuccess)
+      throw std::runtime_error{"vkrh_read_buffer: copy failed"};
+  });
+}
 int vkrh_image_layer(void* frame, const char* name, uint32_t layer, vkr_img* out) {
   return guarded([&] {
     auto* f = (PostFxFrame*)frame;
     if (!f || !name || !out) throw std::runtime_error{"NULL argument"};
     *out = f->graph.get_image(f->lookup(name))->describe_layer(layer);
+  });
+}
+int vkrh_capture(void* frame, const char* name, uint32_t mip, uint32_t kind, const char* path) {
+  return guarded([&] {
+    auto* f = (PostFxFrame*)frame;
+    if (!f || !name || !path) throw std::runtime_error{"NULL argument"};
+    const ReadBackID id = f->readback.read_image(f->graph, f->lookup(name), 0, mip, 0);
+    // the request matures frames_count + 1 submits later, like the reference's fenced frames
+    for (uint32_t i = 0; i <= f->graph.get_frames_count() + 1 && !f->readback.is_data_available(id); i++) {
+      f->graph.submit();
+      f->readback.after_submit(f->graph);
+    }
+    if (!f->readback.is_data_available(id)) throw std::runtime_error{"readback did not mature"};
+    ReadBackData data = f->readback.get_data(id);
+    bool ok = true;
+    if (kind == 0) {
+      if (data.texel_fmt != VK_FORMAT_D24_UNORM_S8_UINT) throw std::runtime_error{"depth CSV capture needs a D24S8 image"};
+      write_depth_csv(data, path);
+    } else if (kind == 1) {
+      if (data.texel_size != 4) throw std::runtime_error{"depth PNG capture needs 4-byte texels"};
+      ok = write_depth_png(data, path);
+    } else if (kind == 2) {
+      if (data.texel_size != 4) throw std::runtime_error{"RGBA PNG capture needs 4-byte texels"};
+      ok = write_rgba_png(data, path);
+    } else {
+      throw std::runtime_error{"unknown capture kind"};
+    }
+    if (!ok) throw std::runtime_error{std::string{"cannot write "} + path};
+  });
+}
+int vkrh_selftest_writers(const char* dir, uint32_t width, uint32_t height) {
+  return guarded([&] {
+    if (!dir || !width || !height) throw std::runtime_error{"bad arguments"};
+    auto make = [&](VkFormat fmt) {
+      ReadBackData d;
+      d.width = width; d.height = height; d.texel_fmt = fmt; d.texel_size = 4;
+      d.bytes.reset(new uint8_t[size_t(width) * height * 4]);
+      return d;
+    };
+    ReadBackData depth = make(VK_FORMAT_D24_UNORM_S8_UINT), color = make(VK_FORMAT_R8G8B8A8_SRGB);
+    for (uint32_t y = 0; y < height; y++)
+      for (uint32_t x = 0; x < width; x++) {
+        const size_t i = size_t(y) * width + x;
+        reinterpret_cast<uint32_t*>(depth.bytes.get())[i] = x * 65537u + y * 257u + 0xAB000000u;
+        uint8_t* c = color.bytes.get() + 4 * i;
+        c[0] = uint8_t(x); c[1] = uint8_t(y); c[2] = uint8_t(x ^ y); c[3] = 7;
+      }
+    const std::string base{dir};
+    write_depth_csv(depth, base + "/depth.csv");
+    if (!write_depth_png(depth, base + "/depth.png") || !write_rgba_png(color, base + "/color.png"))
+      throw std::runtime_error{"cannot write PNG files under " + base};
   });
 }
 int vkrh_enable_task_timing(void* frame, uint32_t on) { return guarded([&] { ((PostFxFrame*)frame)->graph.enable_task_timing(on != 0); }); }

@@ -41,6 +41,7 @@ enum {
   VKRH_STAGE_GTAO_GRAPHICS      = 1u << 11, /* gtao.add_main_pass_graphics, add_filter_pass, add_reprojection_pass */
   VKRH_STAGE_GTAO_DEINTERLEAVED = 1u << 12, /* gtao.deinterleave_depth, add_main_pass_deinterleaved                */
   VKRH_STAGE_SCREEN_TRACE       = 1u << 13, /* ScreenSpaceTrace main, filter, accumulate                           */
+  VKRH_STAGE_SSR_CLASSIFIED     = 1u << 14, /* ssr.run with tile classification + indirect trace (advanced_ssr.cpp:547-550) */
   VKRH_STAGE_CHAIN      = (1u << 3) | (1u << 5) | (1u << 6) | (1u << 7)
 };
 
@@ -66,8 +67,18 @@ int vkrh_run(void* frame, uint32_t stage_mask);
 int vkrh_end_frame(void* frame, uint32_t swap_depth);
 /* current descriptor of a named image ("depth", "taa_target", ...) */
 int vkrh_image(void* frame, const char* name, uint32_t base_mip, uint32_t mip_count, vkr_img* out);
+/* copies a named device buffer ("reflective_tiles", "glossy_tiles", "reflective_indirect",
+ * "glossy_indirect") to host memory after synchronising the stream; returns its size in *bytes */
+int vkrh_read_buffer(void* frame, const char* name, void* dst, uint64_t capacity, uint64_t* bytes);
 /* one layer of a named array image ("deinterleaved_depth") */
 int vkrh_image_layer(void* frame, const char* name, uint32_t layer, vkr_img* out);
+/* Reads `name` (mip) back through ReadBackSystem and writes it with the reference's capture writers
+ * (main.cpp:118-176): kind 0 = depth CSV (24-bit hex), 1 = depth PNG, 2 = RGBA8 PNG (alpha 255). */
+int vkrh_capture(void* frame, const char* name, uint32_t mip, uint32_t kind, const char* path);
+/* CPU-only check of the capture writers: writes <dir>/depth.csv, depth.png, color.png from a
+ * width x height pattern depth = (x * 65537 + y * 257 + 0xAB000000) (top byte = stencil, must be
+ * masked), rgba = (x, y, x ^ y, 7).  No GPU is touched. */
+int vkrh_selftest_writers(const char* dir, uint32_t width, uint32_t height);
 /* per-task device timing with HIP events on the frame's stream */
 int vkrh_enable_task_timing(void* frame, uint32_t on);
 /* synchronises and returns "name total_ms launches\n" lines accumulated since the last call */

@@ -308,6 +308,30 @@ void register_hot_path_programs() {
       return vkr_defered_shading(&albedo, &normal, &material, &depth, ubo<vkr_shading_params>(st, 4, P), &occlusion, &brdf, &refl, &out,
                                  push<vkr_shading_push>(st, P), st.stream);
     });
+    // ---- tile-classified trace ----
+    auto ssbo = [](const LaunchState& st, uint32_t slot, const char* prog) -> Buffer* {
+      const SetSlot& s = st.set ? st.set->slots[slot] : SetSlot{};
+      if (!st.set || s.kind != SetSlot::Ssbo || !s.buffer) throw std::runtime_error{std::string{prog} + ": storage buffer " + std::to_string(slot) + " is not bound"};
+      return s.buffer.get();
+    };
+    create_program("sssr_classification", [=](LaunchState& st) {
+      const char* P = "sssr_classification";
+      vkr_img material = tex(st, 0, T, P);
+      return vkr_sssr_classification(&material, (int32_t*)ssbo(st, 1, P)->device_ptr(st.stream), (int32_t*)ssbo(st, 2, P)->device_ptr(st.stream),
+                                     (uint32_t*)ssbo(st, 3, P)->device_ptr(st.stream), (uint32_t*)ssbo(st, 4, P)->device_ptr(st.stream),
+                                     push<vkr_classification_push>(st, P), st.stream);
+    });
+    create_program("sssr_trace_indirect", [=](LaunchState& st) {
+      const char* P = "sssr_trace_indirect";
+      if (!st.indirect) throw std::runtime_error{"sssr_trace_indirect: must be launched with dispatch_indirect"};
+      vkr_img depth = tex(st, 0, T, P), normal = tex(st, 1, T, P), material = tex(st, 2, T, P), rays = tex(st, 5, S, P);
+      const SetSlot& h = st.set->slots[4];
+      if (h.kind != SetSlot::Ubo || !h.buffer) throw std::runtime_error{"sssr_trace_indirect: Halton buffer (binding 4) is not bound"};
+      Buffer* tiles = ssbo(st, 6, P);
+      return vkr_sssr_trace_indirect(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), (const float*)h.buffer->device_ptr(st.stream), &rays,
+                                     (const int32_t*)tiles->device_ptr(st.stream), (const uint32_t*)st.indirect->device_ptr(st.stream),
+                                     (uint32_t)(tiles->get_size() / sizeof(int32_t)), push<vkr_trace_indirect_push>(st, P), st.stream);
+    });
     // ---- dormant GTAO variants ----
     // gtao/main.frag: set {0 depth, 1 GTAOParams, 2 normal}; colour attachment raw
     create_program("gtao_main", [=](LaunchState& st) {
@@ -384,6 +408,14 @@ ComputePipeline create_compute_pipeline(const char* name) { ComputePipeline p; p
 GraphicsPipeline create_graphics_pipeline() { return GraphicsPipeline{}; }
 
 // ---- command context ---------------------------------------------------------------------------------------
+void CmdContext::begin() {
+  if (!staged_updates.empty()) {  // their async copies must have drained before the storage goes away
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    staged_updates.clear();
+  }
+  ubo_pool.reset();
+  sets.clear();
+}
 VkDescriptorSet CmdContext::allocate_set() {
   sets.emplace_back(new DescriptorSetObject{});
   return (VkDescriptorSet)sets.back().get();
@@ -427,6 +459,21 @@ void CmdContext::launch() {
 void CmdContext::dispatch(uint32_t x, uint32_t y, uint32_t z) {
   state.groups[0] = x; state.groups[1] = y; state.groups[2] = z;
   launch();
+}
+void CmdContext::dispatch_indirect(VkBuffer arguments) {
+  if (!arguments) throw std::runtime_error{"dispatch_indirect: null argument buffer"};
+  state.groups[0] = state.groups[1] = state.groups[2] = 0;
+  state.indirect = (Buffer*)arguments;
+  launch();
+  state.indirect = nullptr;
+}
+void CmdContext::update_buffer_bytes(VkBuffer dst, uint64_t offset, const void* data, uint64_t size) {
+  auto* b = (Buffer*)dst;
+  if (!b || offset + size > b->get_size() || size > 65536) throw std::runtime_error{"update_buffer: range outside the buffer"};
+  // like vkCmdUpdateBuffer the value is captured at record time: stage it in memory that outlives the copy
+  staged_updates.emplace_back((const uint8_t*)data, (const uint8_t*)data + size);
+  hipError_t e = hipMemcpyAsync((uint8_t*)b->device_ptr(stream) + offset, staged_updates.back().data(), size, hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) throw std::runtime_error{std::string{"update_buffer failed: "} + hipGetErrorString(e)};
 }
 void CmdContext::draw(uint32_t vertex_count, uint32_t, uint32_t, uint32_t) {
   if (vertex_count != 3) throw std::runtime_error{"Only the full-screen triangle draw is implemented on this path"};

@@ -97,6 +97,8 @@ struct Buffer {
   void* get_mapped_ptr() { dirty = true; return shadow.data(); }
   const void* host_data() const { return shadow.empty() ? nullptr : shadow.data(); }
   void* device_ptr(void* stream);
+  // the handle cmd.dispatch_indirect / cmd.update_buffer take (gpu/resources.hpp api_buffer())
+  VkBuffer api_buffer() { return (VkBuffer)this; }
 
  private:
   uint64_t size;
@@ -179,6 +181,7 @@ struct LaunchState {
   uint32_t groups[3] = {0, 0, 0};
   uint32_t fb_width = 0, fb_height = 0;
   std::vector<ImageViewObject> attachments;  // graphics programs: colour..., depth last
+  Buffer* indirect = nullptr;                // dispatch_indirect: VkDispatchIndirectCommand on the device
   void* stream = nullptr;
 };
 using ProgramFn = std::function<int(LaunchState&)>;
@@ -218,7 +221,7 @@ GraphicsPipeline create_graphics_pipeline();
 // ---- command context (gpu/cmd_buffers.hpp:162-247) --------------------------------------------------------
 struct CmdContext {
   explicit CmdContext(void* hip_stream = nullptr) : stream{hip_stream} {}
-  void begin() { ubo_pool.reset(); sets.clear(); }
+  void begin();
   void set_stream(void* s) { stream = s; }
   void* get_stream() const { return stream; }
 
@@ -236,6 +239,11 @@ struct CmdContext {
   void end_renderpass() { state.attachments.clear(); }
   void dispatch(uint32_t groups_x, uint32_t groups_y, uint32_t groups_z);
   void draw(uint32_t vertex_count, uint32_t instance_count, uint32_t first_vertex, uint32_t first_instance);
+  // group counts come from a device buffer; the program bounds its launch itself (no host read-back)
+  void dispatch_indirect(VkBuffer arguments);
+  // vkCmdUpdateBuffer of a small POD value, ordered on the stream
+  void update_buffer_bytes(VkBuffer dst, uint64_t offset, const void* data, uint64_t size);
+  template <typename T> void update_buffer(VkBuffer dst, uint64_t offset, const T& value) { update_buffer_bytes(dst, offset, &value, sizeof(T)); }
   void push_label(const char*) {}
   void pop_label() {}
 
@@ -250,6 +258,7 @@ struct CmdContext {
   std::vector<std::unique_ptr<DescriptorSetObject>> sets;
   std::optional<std::string> bound_program;
   std::vector<uint8_t> push_data;
+  std::vector<std::vector<uint8_t>> staged_updates;  // update_buffer payloads, released by begin()
   LaunchState state;
 };
 

@@ -86,6 +86,8 @@ struct RenderGraphBuilder {  // rendergraph.hpp:17-55
   void use_uniform_buffer(BufferResourceId, VkShaderStageFlags) {}
   void use_storage_buffer(BufferResourceId, VkShaderStageFlags, bool = true) {}
   void use_indirect_buffer(BufferResourceId) {}
+  void transfer_write(BufferResourceId) {}
+  void transfer_read(BufferResourceId) {}
   void transfer_read(ImageResourceId id, uint32_t base_mip, uint32_t mip_count, uint32_t base_layer, uint32_t layer_count);
   void transfer_write(ImageResourceId id, uint32_t base_mip, uint32_t mip_count, uint32_t base_layer, uint32_t layer_count);
   gpu::ImageInfo get_image_info(ImageResourceId id);

@@ -48,6 +48,8 @@ struct VkSamplerCreateInfo {
   VkSamplerAddressMode addressModeU, addressModeV, addressModeW;
   float minLod, maxLod;
 };
+struct VkDispatchIndirectCommand { uint32_t x, y, z; };
+typedef struct VkBuffer_T* VkBuffer;
 typedef struct VkSampler_T* VkSampler;
 typedef struct VkImageView_T* VkImageView;
 typedef struct VkDescriptorSet_T* VkDescriptorSet;
