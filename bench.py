@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rehearse-tiled", action="store_true",
+                    help="N=1 only: run the multi-GPU code path (RCCL gathers, staged frame) on a one-rank group")
     ap.add_argument("--tile", type=str, default=f"{TILE_W}x{TILE_H}", help="per-GPU tile, WxH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c5"],
@@ -110,6 +112,13 @@ def main():
     elif args.config == "c3":
         args.tile = "7680x4320"
 
+    # Exactly ONE line may reach stdout (the JSON result): libraries print there too (RCCL writes its
+    # version banner to stdout on rank 0), so fd 1 is pointed at stderr for the whole run and the
+    # result is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,15 +128,20 @@ def main():
     torch.cuda.set_device(device)
     import torch.distributed as dist
 
-    if world > 1:
+    if world > 1 or args.rehearse_tiled:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if world == 1:  # rehearsal: a one-rank RCCL group, rendezvous on the loopback address
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     tw, th = (int(v) for v in args.tile.lower().split("x"))
     cols, rows = grid_for(world)
     W, H = tw * cols, th * rows
     setup = FrameSetup(W, H, use_mis=0 if args.config == "c1" else 1)
-    tiled = TiledFrame(setup, rank, world, cols, rows, device)
+    tiled = TiledFrame(setup, rank, world, cols, rows, device, force_tiled=args.rehearse_tiled)
     frame = tiled.frame
     if args.config == "c1":      # GTAO main pass only (BASELINE configs[0]); non-MIS: 1+4 read, 2 written = 7 B/px
         tiled.stage_plan = [host.STAGE_GTAO_MAIN_ONLY]
@@ -223,9 +237,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "c2" and not args.shading:
             out["cpu_baseline"] = cpu_baseline(frame, setup)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

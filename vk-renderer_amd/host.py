@@ -12,7 +12,7 @@ STAGE_LUT, STAGE_GBUFFER, STAGE_PREV_DEPTH, STAGE_DOWNSAMPLE = 1, 2, 4, 8
 STAGE_HIZ_TAIL, STAGE_SSR, STAGE_GTAO, STAGE_TAA = 16, 32, 64, 128
 STAGE_SHADING, STAGE_BRDF_LUT, STAGE_GTAO_MAIN_ONLY = 256, 512, 1024
 STAGE_GTAO_GRAPHICS, STAGE_GTAO_DEINTERLEAVED, STAGE_SCREEN_TRACE = 2048, 4096, 8192
-STAGE_SSR_CLASSIFIED = 16384
+STAGE_SSR_CLASSIFIED, STAGE_SSR_TRACE, STAGE_SSR_RESOLVE = 16384, 32768, 65536
 STAGE_CHAIN = STAGE_DOWNSAMPLE | STAGE_SSR | STAGE_GTAO | STAGE_TAA
 
 

@@ -377,9 +377,7 @@ void AdvancedSSR::run_trace_indirect_pass(rendergraph::RenderGraph &graph, const
     });
 }
 
-void AdvancedSSR::run(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const DrawTAAParams &taa_params,
-  const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion)
-{
+void AdvancedSSR::run_trace(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion) {
   if (settings.use_tile_classification) {  // the path advanced_ssr.cpp:547-550 keeps commented out
     clear_indirect_params(graph);
     run_classification_pass(graph, params, gbuff);
@@ -387,6 +385,16 @@ void AdvancedSSR::run(rendergraph::RenderGraph &graph, const AdvancedSSRParams &
   } else {
     run_trace_pass(graph, params, gbuff, ssr_occlusion);
   }
+}
+
+void AdvancedSSR::run_resolve(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const DrawTAAParams &taa_params, const Gbuffer &gbuff) {
   run_filter_pass(graph, params, gbuff);
   run_blur_pass(graph, params, taa_params, gbuff);
+}
+
+void AdvancedSSR::run(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const DrawTAAParams &taa_params,
+  const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion)
+{
+  run_trace(graph, params, gbuff, ssr_occlusion);
+  run_resolve(graph, params, taa_params, gbuff);
 }

@@ -59,6 +59,11 @@ struct AdvancedSSR {
   Settings &get_settings() { return settings; }
   void set_counter(uint32_t c) { counter = c; }
 
+  // the two halves of run(), for drivers that interleave an exchange between them (multi-GPU: the
+  // trace needs the gathered Hi-Z pyramid, the filter the gathered albedo)
+  void run_trace(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion);
+  void run_resolve(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const DrawTAAParams &taa_params, const Gbuffer &gbuff);
+
   // advanced_ssr.cpp:440-495,216-302 (private in the reference; public here so drivers can record them one by one)
   void clear_indirect_params(rendergraph::RenderGraph &graph);
   void run_classification_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff);

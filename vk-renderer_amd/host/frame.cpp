@@ -107,6 +107,8 @@ struct PostFxFrame {
       ssr.get_settings().use_tile_classification = (mask & VKRH_STAGE_SSR_CLASSIFIED) != 0;
       ssr.run(graph, assr_params, draw_params, gbuffer, gtao.raw);
     }
+    if (mask & VKRH_STAGE_SSR_TRACE) ssr.run_trace(graph, assr_params, gbuffer, gtao.raw);
+    if (mask & VKRH_STAGE_SSR_RESOLVE) ssr.run_resolve(graph, assr_params, draw_params, gbuffer);
     if (mask & VKRH_STAGE_GTAO_MAIN_ONLY)
       gtao.add_main_pass(graph, gtao_params, gbuffer.depth, gbuffer.normal, gbuffer.material, ssr.get_preintegrated_pdf());
     if (mask & VKRH_STAGE_GTAO) {                                                           // main.cpp:384-388

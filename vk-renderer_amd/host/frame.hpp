@@ -42,6 +42,8 @@ enum {
   VKRH_STAGE_GTAO_DEINTERLEAVED = 1u << 12, /* gtao.deinterleave_depth, add_main_pass_deinterleaved                */
   VKRH_STAGE_SCREEN_TRACE       = 1u << 13, /* ScreenSpaceTrace main, filter, accumulate                           */
   VKRH_STAGE_SSR_CLASSIFIED     = 1u << 14, /* ssr.run with tile classification + indirect trace (advanced_ssr.cpp:547-550) */
+  VKRH_STAGE_SSR_TRACE          = 1u << 15, /* first half of ssr.run: the trace (needs the Hi-Z pyramid)                    */
+  VKRH_STAGE_SSR_RESOLVE        = 1u << 16, /* second half of ssr.run: filter + blur (needs albedo at the hit positions)      */
   VKRH_STAGE_CHAIN      = (1u << 3) | (1u << 5) | (1u << 6) | (1u << 7)
 };
 

@@ -6,9 +6,12 @@ that whole window; results are exact on the tile interior as long as a pass's re
 the halo (fixed-radius stencils: <= 19 half-res px).  Reads with unbounded reach
 are served from whole-frame copies:
 
-  exchange A (every frame, after the Hi-Z downsample):  all-gather of each tile's
-      depth image-mips 1..4, downsampled normals and albedo  ->  frame_hiz / frame_normals /
-      frame_albedo on every rank; the coarser Hi-Z mips are then rebuilt locally.
+  exchange A (every frame, after the Hi-Z downsample):  two all-gathers — each tile's depth
+      image-mips 1..4 + downsampled normals (what the trace marches through), then its albedo
+      (what the filter reads at the hit positions)  ->  frame_hiz / frame_normals / frame_albedo
+      on every rank; the coarser Hi-Z mips are then rebuilt locally.  Both are issued
+      asynchronously right after the downsample: TAA (independent of them) runs while the first
+      is in flight, the trace while the second is.
   exchange B (every frame, after the history remaps):  the halo ring of the three history
       surfaces (TAA, accumulated AO, blurred reflections) is refreshed from the neighbours'
       interiors with point-to-point sends (up to 8 neighbours).
@@ -54,23 +57,29 @@ class HostBackend:
         self.host = host
         self.frame = host.HostFrame(setup, device=device, window=window, tiled=tiled)
         self.device = device
+        self._views = {}
 
     def rows(self, name, mip=0):
+        """(uint8 view [height, pitch] of one mip, bytes per texel, window rect).  Views are cached per device
+        address: history remaps only permute which address a name resolves to."""
         d = self.frame.image(name, mip, 1)
-        t, off = self.frame.allocator.tensor_at(d.base)
         h, pitch = d.height, d.pitch_bytes[0]
-        return t[off: off + h * pitch].view(h, pitch), abi.FORMAT_BYTES[d.format], (d.origin_x, d.origin_y, d.width, d.height)
+        key = (d.base, h, pitch)
+        view = self._views.get(key)
+        if view is None:
+            t, off = self.frame.allocator.tensor_at(d.base)
+            view = self._views[key] = t[off: off + h * pitch].view(h, pitch)
+        return view, abi.FORMAT_BYTES[d.format], (d.origin_x, d.origin_y, d.width, d.height)
 
     def prepare(self):
         h = self.host
         self.frame.run(h.STAGE_LUT | h.STAGE_GBUFFER | h.STAGE_PREV_DEPTH)
 
-    def run_pre(self):
-        self.frame.run(self.host.STAGE_DOWNSAMPLE)
-
-    def run_main(self):
+    def run_stage(self, stage):
+        """stage: 'downsample' | 'taa' | 'trace' (Hi-Z tail + trace) | 'resolve' (filter, blur, GTAO)"""
         h = self.host
-        self.frame.run(h.STAGE_HIZ_TAIL | h.STAGE_SSR | h.STAGE_GTAO | h.STAGE_TAA)
+        self.frame.run({"downsample": h.STAGE_DOWNSAMPLE, "taa": h.STAGE_TAA, "trace": h.STAGE_HIZ_TAIL | h.STAGE_SSR_TRACE,
+                        "resolve": h.STAGE_SSR_RESOLVE | h.STAGE_GTAO}[stage])
 
     def run_all(self):
         self.frame.run(self.host.STAGE_CHAIN)
@@ -107,21 +116,25 @@ class OracleBackend:
         c.init_histories()
         c.preintegrate_pdf()
 
-    def run_pre(self):
-        self.chain.downsample()
-
-    def run_main(self):
+    def run_stage(self, stage):
         c = self.chain
-        if c.tiled:
-            c.hiz_tail(GATHER_MIPS)
-        c.ssr_trace(frame_random=c.frame_index % 16)
-        c.ssr_filter()
-        c.ssr_blur()
-        c.gtao_main()
-        c.gtao_filter()
-        c.gtao_accumulate()
-        c.taa()
-        c.frame_index += 1
+        if stage == "downsample":
+            c.downsample()
+        elif stage == "taa":
+            c.taa()
+        elif stage == "trace":
+            if c.tiled:
+                c.hiz_tail(GATHER_MIPS)
+            c.ssr_trace(frame_random=c.frame_index % 16)
+        elif stage == "resolve":
+            c.ssr_filter()
+            c.ssr_blur()
+            c.gtao_main()
+            c.gtao_filter()
+            c.gtao_accumulate()
+            c.frame_index += 1
+        else:
+            raise ValueError(stage)
 
     def run_all(self):
         self.chain.frame()
@@ -134,7 +147,7 @@ class OracleBackend:
 
 
 class TiledFrame:
-    def __init__(self, setup, rank, world, cols, rows, device, backend="host", halo=HALO):
+    def __init__(self, setup, rank, world, cols, rows, device, backend="host", halo=HALO, force_tiled=False):
         assert cols * rows == world
         self.setup, self.rank, self.world, self.cols, self.rows_n = setup, rank, world, cols, rows
         W, H = setup.width, setup.height
@@ -146,13 +159,15 @@ class TiledFrame:
             assert self.halo % 2 == 0 and self.halo <= min(self.tw, self.th)
         self.tile = tile_rect(rank, cols, rows, self.tw, self.th)
         self.window = window_rect(rank, cols, rows, self.tw, self.th, self.halo)
-        self.tiled = world > 1
+        # force_tiled: run the multi-GPU code path (gathers, whole-frame Hi-Z, staged frame) on one rank
+        self.tiled = world > 1 or force_tiled
         cls = HostBackend if backend == "host" else OracleBackend
         self.backend = cls(setup, self.window, self.tiled, device)
         self.frame = self.backend.frame
         self.device = self.backend.device
         self._xchg_s = 0.0
-        self._gather_buf = None
+        self._gather_buf = {}
+        self._halo_cache = None
         self.stage_plan = None  # single-GPU only: list of stage masks run per step instead of STAGE_CHAIN
 
     # ---- set-up ---------------------------------------------------------------------------------
@@ -192,11 +207,23 @@ class TiledFrame:
                 self.backend.run_all()
             self.backend.end_frame()
             return
-        self.backend.run_pre()
+        # downsample -> [gather Hi-Z + normals || TAA] -> trace -> [gather albedo, in flight since the
+        # downsample] -> filter, blur, GTAO.  The collectives run on the communicator's own stream;
+        # wait() only orders the compute stream behind them.
+        self.backend.run_stage("downsample")
         t0 = time.perf_counter()
-        self.exchange_gather()
+        pending_hiz = self.gather_start("hiz")
+        pending_albedo = self.gather_start("albedo")
         self._xchg_s += time.perf_counter() - t0
-        self.backend.run_main()
+        self.backend.run_stage("taa")
+        t0 = time.perf_counter()
+        self.gather_finish(pending_hiz)
+        self._xchg_s += time.perf_counter() - t0
+        self.backend.run_stage("trace")
+        t0 = time.perf_counter()
+        self.gather_finish(pending_albedo)
+        self._xchg_s += time.perf_counter() - t0
+        self.backend.run_stage("resolve")
         self.backend.end_frame()
         t0 = time.perf_counter()
         self.exchange_history_halos()
@@ -207,39 +234,55 @@ class TiledFrame:
         return self._xchg_s / max(steps, 1) * 1e3
 
     # ---- exchange A: all-gather of the unbounded-reach surfaces -------------------------------------
-    def _gather_plan(self):
+    def _gather_plan(self, group):
         """[(src image, src mip, dst image, dst mip, divisor)]: tile interior at full-res >> divisor"""
-        plan = [("depth", m, "frame_hiz", m - 1, m) for m in range(1, GATHER_MIPS + 1)]
-        plan += [("dn", 0, "frame_normals", 0, 1), ("albedo", 0, "frame_albedo", 0, 0)]
-        return plan
+        if group == "hiz":
+            return [("depth", m, "frame_hiz", m - 1, m) for m in range(1, GATHER_MIPS + 1)] + [("dn", 0, "frame_normals", 0, 1)]
+        return [("albedo", 0, "frame_albedo", 0, 0)]
 
-    def exchange_gather(self):
-        plan = self._gather_plan()
+    def gather_start(self, group):
+        """Packs this tile's share of `group` and issues the all-gather asynchronously."""
+        plan = self._gather_plan(group)
         x0, y0, tw, th = self.tile
         sizes = []
         for src, mip, _, _, dv in plan:
             _, bpp, _ = self.backend.rows(src, mip)
             sizes.append((th >> dv) * (tw >> dv) * bpp)
         chunk = sum(sizes)
-        if self._gather_buf is None:
-            self._gather_buf = (torch.empty(chunk, dtype=torch.uint8, device=self.device),
-                                torch.empty(chunk * self.world, dtype=torch.uint8, device=self.device))
-        send, recv = self._gather_buf
+        if group not in self._gather_buf:
+            self._gather_buf[group] = (torch.empty(chunk, dtype=torch.uint8, device=self.device),
+                                       torch.empty(chunk * self.world, dtype=torch.uint8, device=self.device))
+        send, recv = self._gather_buf[group]
         off = 0
         for (src, mip, _, _, dv), n in zip(plan, sizes):
             rows, bpp, (ox, oy, _, _) = self.backend.rows(src, mip)
             lx, ly, w, h = (x0 >> dv) - ox, (y0 >> dv) - oy, tw >> dv, th >> dv
             send[off: off + n].view(h, w * bpp).copy_(rows[ly: ly + h, lx * bpp: (lx + w) * bpp])
             off += n
-        dist.all_gather_into_tensor(recv, send)
-        for r in range(self.world):
-            rx0, ry0, _, _ = tile_rect(r, self.cols, self.rows_n, self.tw, self.th)
-            off = r * chunk
-            for (_, _, dst, dmip, dv), n in zip(plan, sizes):
-                rows, bpp, (ox, oy, _, _) = self.backend.rows(dst, dmip)
-                lx, ly, w, h = (rx0 >> dv) - ox, (ry0 >> dv) - oy, tw >> dv, th >> dv
-                rows[ly: ly + h, lx * bpp: (lx + w) * bpp].copy_(recv[off: off + n].view(h, w * bpp))
-                off += n
+        work = dist.all_gather_into_tensor(recv, send, async_op=True)
+        return work, plan, sizes, chunk, recv
+
+    def gather_finish(self, pending):
+        """Orders the compute stream behind the collective and scatters the tiles into the frame images."""
+        work, plan, sizes, chunk, recv = pending
+        work.wait()
+        # one strided copy per surface: recv is [rank = (row, col)][surface bytes]; the frame image is
+        # [row][y][col][x bytes] (rank r sits at column r % cols, row r // cols of the grid)
+        per_rank = recv.view(self.world, chunk)
+        off = 0
+        for (_, _, dst, dmip, dv), n in zip(plan, sizes):
+            rows, bpp, (ox, oy, _, _) = self.backend.rows(dst, dmip)
+            assert ox == 0 and oy == 0, "whole-frame images start at the frame origin"
+            w, h = self.tw >> dv, self.th >> dv
+            src = per_rank[:, off: off + n].view(self.rows_n, self.cols, h, w * bpp)
+            out = rows[: self.rows_n * h, : self.cols * w * bpp].unflatten(0, (self.rows_n, h)).unflatten(2, (self.cols, w * bpp))
+            out.copy_(src.permute(0, 2, 1, 3))
+            off += n
+
+    def exchange_gather(self):
+        """Both groups back to back (kept for callers that do not overlap)."""
+        for group in ("hiz", "albedo"):
+            self.gather_finish(self.gather_start(group))
 
     # ---- exchange B: history halos -------------------------------------------------------------------
     def _neighbours(self):
@@ -257,28 +300,47 @@ class TiledFrame:
         x1, y1 = min(a[0] + a[2], b[0] + b[2]), min(a[1] + a[3], b[1] + b[3])
         return (x0, y0, x1 - x0, y1 - y0) if x1 > x0 and y1 > y0 else None
 
-    def exchange_history_halos(self):
-        ops, unpack = [], []
-        for name, dv in (("taa_hist", 0), ("acc_hist", 1), ("blurred_hist", 1)):
-            rows, bpp, (ox, oy, ww, wh) = self.backend.rows(name)
-            mine = tuple(v >> dv for v in self.tile)
-            my_win = (ox, oy, ww, wh)
-            for dx, dy, nb in self._neighbours():
+    def _halo_plan(self):
+        """Static geometry of exchange B: per neighbour, the slices of each history surface to send (my
+        interior inside its window) and to receive (its interior inside my window), packed back to back
+        in one persistent buffer per direction."""
+        if self._halo_cache is not None:
+            return self._halo_cache
+        plan = []
+        for dx, dy, nb in self._neighbours():
+            send, recv, sbytes, rbytes = [], [], 0, 0
+            for name, dv in (("taa_hist", 0), ("acc_hist", 1), ("blurred_hist", 1)):
+                _, bpp, (ox, oy, ww, wh) = self.backend.rows(name)
+                mine = tuple(v >> dv for v in self.tile)
                 nb_tile = tuple(v >> dv for v in tile_rect(nb, self.cols, self.rows_n, self.tw, self.th))
                 nb_win = tuple(v >> dv for v in window_rect(nb, self.cols, self.rows_n, self.tw, self.th, self.halo))
-                # what the neighbour needs from me: my interior inside its window
                 s = self._overlap(mine, nb_win)
                 if s:
-                    buf = rows[s[1] - oy: s[1] - oy + s[3], (s[0] - ox) * bpp: (s[0] - ox + s[2]) * bpp].contiguous()
-                    ops.append(dist.P2POp(dist.isend, buf, nb))
-                # what I need from it: its interior inside my window
-                r = self._overlap(nb_tile, my_win)
+                    send.append((name, s[1] - oy, s[3], (s[0] - ox) * bpp, s[2] * bpp, sbytes))
+                    sbytes += s[3] * s[2] * bpp
+                r = self._overlap(nb_tile, (ox, oy, ww, wh))
                 if r:
-                    buf = torch.empty((r[3], r[2] * bpp), dtype=torch.uint8, device=self.device)
-                    ops.append(dist.P2POp(dist.irecv, buf, nb))
-                    unpack.append((rows, (r[0] - ox) * bpp, r[1] - oy, buf))
+                    recv.append((name, r[1] - oy, r[3], (r[0] - ox) * bpp, r[2] * bpp, rbytes))
+                    rbytes += r[3] * r[2] * bpp
+            plan.append((nb, send, torch.empty(max(sbytes, 1), dtype=torch.uint8, device=self.device),
+                         recv, torch.empty(max(rbytes, 1), dtype=torch.uint8, device=self.device)))
+        self._halo_cache = plan
+        return plan
+
+    def exchange_history_halos(self):
+        plan = self._halo_plan()
+        rows = {name: self.backend.rows(name)[0] for name in ("taa_hist", "acc_hist", "blurred_hist")}
+        ops = []
+        for nb, send, sbuf, recv, rbuf in plan:
+            for name, y, h, xb, wb, off in send:
+                sbuf[off: off + h * wb].view(h, wb).copy_(rows[name][y: y + h, xb: xb + wb])
+            if send:
+                ops.append(dist.P2POp(dist.isend, sbuf, nb))
+            if recv:
+                ops.append(dist.P2POp(dist.irecv, rbuf, nb))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        for rows, bx, ly, buf in unpack:
-            rows[ly: ly + buf.shape[0], bx: bx + buf.shape[1]].copy_(buf)
+        for nb, send, sbuf, recv, rbuf in plan:
+            for name, y, h, xb, wb, off in recv:
+                rows[name][y: y + h, xb: xb + wb].copy_(rbuf[off: off + h * wb].view(h, wb))
