@@ -67,20 +67,21 @@ VKR_DEV float find_horizon(const DepthTile& depth, const Proj& pr, f2 start, f3 
 // (main.comp:276-278), so its 16 (cos,sin) pairs are kernel arguments evaluated once on the host
 // instead of per pixel.
 __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
+  const i2 blk = xcd_block<2, 4>();  // chunks of 128 x 64 output pixels
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   __shared__ float s_depth[GT_TW * GT_TH];
   const int tid = threadIdx.y * GT_BX + threadIdx.x;
   srgb_lut_stage(s_lut, tid, GT_BX * GT_BY);
   DepthTile tile;
   tile.d = s_depth;
-  tile.x0 = a.out.ox + blockIdx.x * GT_BX - GT_R;
-  tile.y0 = a.out.oy + blockIdx.y * GT_BY - GT_R;
+  tile.x0 = a.out.ox + blk.x * GT_BX - GT_R;
+  tile.y0 = a.out.oy + blk.y * GT_BY - GT_R;
   tile.fw = (float)a.depth.fw; tile.fh = (float)a.depth.fh;
   for (int t = tid; t < GT_TW * GT_TH; t += GT_BX * GT_BY)
     s_depth[t] = fetch_clamped<FmtD24>(a.depth, tile.x0 + t % GT_TW, tile.y0 + t / GT_TW);
   __syncthreads();
-  const int lx = blockIdx.x * GT_BX + threadIdx.x;
-  const int ly = blockIdx.y * GT_BY + threadIdx.y;
+  const int lx = blk.x * GT_BX + threadIdx.x;
+  const int ly = blk.y * GT_BY + threadIdx.y;
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   if (gx >= a.tex_w || gy >= a.tex_h) return;
@@ -165,16 +166,17 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
 #define GF_TW (GF_BX + 3)
 #define GF_TH (GF_BY + 3)
 __global__ __launch_bounds__(GF_BX * GF_BY) void k_gtao_filter(Tex depth, Tex raw, Tex out, int tex_w, int tex_h, float znear, float zfar) {
+  const i2 blk = xcd_block<2, 16>();  // chunks of 128 x 64 output pixels
   __shared__ float2 s_t[GF_TW * GF_TH];
   const int tid = threadIdx.y * GF_BX + threadIdx.x;
-  const int bx0 = out.ox + blockIdx.x * GF_BX - 2, by0 = out.oy + blockIdx.y * GF_BY - 2;
+  const int bx0 = out.ox + blk.x * GF_BX - 2, by0 = out.oy + blk.y * GF_BY - 2;
   for (int t = tid; t < GF_TW * GF_TH; t += GF_BX * GF_BY) {
     const int px = bx0 + t % GF_TW, py = by0 + t / GF_TW;
     s_t[t] = make_float2(linearize_depth2_unorm(fetch<FmtD24>(depth, px, py), znear, zfar), fetch<FmtRGBA16F>(raw, px, py).x);
   }
   __syncthreads();
-  const int lx = blockIdx.x * GF_BX + threadIdx.x;
-  const int ly = blockIdx.y * GF_BY + threadIdx.y;
+  const int lx = blk.x * GF_BX + threadIdx.x;
+  const int ly = blk.y * GF_BY + threadIdx.y;
   if (lx >= out.w || ly >= out.h) return;
   const int gx = out.ox + lx, gy = out.oy + ly;
   if (gx >= tex_w || gy >= tex_h) return;
@@ -204,8 +206,9 @@ struct AccumArgs {
 
 // accum.comp:29-88
 __global__ __launch_bounds__(256) void k_gtao_accumulate(AccumArgs a) {
-  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+  const i2 blk = xcd_block<2, 16>();  // chunks of 128 x 64 output pixels
+  const int lx = blk.x * blockDim.x + threadIdx.x;
+  const int ly = blk.y * blockDim.y + threadIdx.y;
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);

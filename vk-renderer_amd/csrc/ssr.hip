@@ -56,6 +56,7 @@ struct TraceArgs {
 #define TRACE_THREADS 256
 #define TRACE_ROUND 16
 __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
+  const i2 blk = xcd_block<4, 8>();  // chunks of 128 x 64 output pixels
   __shared__ uint4 s_mip[16];
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   __shared__ float s_rc[17][TRACE_THREADS];     // RayConst (15) + t + h of unfinished rays
@@ -67,10 +68,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   if (tid < 16) s_mip[tid] = mip_descriptor(a.depth.mip[tid < a.depth.count ? tid : 0]);
   if (tid < 2) s_count[tid] = 0;
   __syncthreads();
-  // 256 threads = 4 waves; wave w owns the 8x8 tile (blockIdx.x*4 + w, blockIdx.y)
+  // 256 threads = 4 waves; wave w owns the 8x8 tile (blk.x*4 + w, blk.y)
   const int wave = tid >> 6, lane = tid & 63;
-  const int lx = (blockIdx.x * 4 + wave) * 8 + (lane & 7);
-  const int ly = blockIdx.y * 8 + (lane >> 3);
+  const int lx = (blk.x * 4 + wave) * 8 + (lane & 7);
+  const int ly = blk.y * 8 + (lane >> 3);
   const bool active = lx < a.out_ray.w && ly < a.out_ray.h;
   const int gx = a.out_ray.ox + lx, gy = a.out_ray.oy + ly;
   const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
@@ -253,6 +254,7 @@ struct FilterArgs {
 #define FILT_TH (FILT_BY + 2)
 
 __global__ __launch_bounds__(FILT_BX * FILT_BY) void k_sssr_filter(FilterArgs a) {
+  const i2 blk = xcd_block<4, 8>();  // chunks of 128 x 64 output pixels
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   __shared__ float4 s_geo[FILT_TW * FILT_TH];  // {fresnel power term, NdotL, NdotV, depth}
   __shared__ float4 s_rad[FILT_TW * FILT_TH];  // radiance rgb
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(FILT_BX * FILT_BY) void k_sssr_filter(FilterArgs a)
   __syncthreads();
 
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
-  const int bx0 = a.out.ox + blockIdx.x * FILT_BX - 1, by0 = a.out.oy + blockIdx.y * FILT_BY - 1;
+  const int bx0 = a.out.ox + blk.x * FILT_BX - 1, by0 = a.out.oy + blk.y * FILT_BY - 1;
   for (int t = tid; t < FILT_TW * FILT_TH; t += FILT_BX * FILT_BY) {
     const int px = bx0 + t % FILT_TW, py = by0 + t / FILT_TW;
     const f4 trace_result = fetch<FmtRGBA16U>(a.rays, px, py);
@@ -284,8 +286,8 @@ __global__ __launch_bounds__(FILT_BX * FILT_BY) void k_sssr_filter(FilterArgs a)
   }
   __syncthreads();
 
-  const int lx = blockIdx.x * FILT_BX + threadIdx.x;
-  const int ly = blockIdx.y * FILT_BY + threadIdx.y;
+  const int lx = blk.x * FILT_BX + threadIdx.x;
+  const int ly = blk.y * FILT_BY + threadIdx.y;
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   const f2 screen_uv = mk2((float)gx / tex_size.x, (float)gy / tex_size.y);  // no +0.5 (filter.comp:39)
@@ -407,6 +409,7 @@ VKR_DEV f4 blur_single(const float4* s_nd, const uint32_t* s_refl, const BlurCen
 }
 
 __global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
+  const i2 blk = xcd_block<4, 4>();  // chunks of 128 x 64 output pixels
   // staged tile, one float4 {normal.xyz, depth} + one packed RGBA8 reflection texel per pixel
   __shared__ float4 s_nd[BLUR_TH * BLUR_TW];
   __shared__ uint32_t s_refl[BLUR_TH * BLUR_TW];
@@ -414,8 +417,8 @@ __global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
   const int tid = threadIdx.y * BLUR_BX + threadIdx.x;
   srgb_lut_stage(s_lut, tid, BLUR_THREADS);
 
-  const int bx0 = a.out.ox + blockIdx.x * BLUR_BX - BLUR_R;  // frame coordinates of the tile origin
-  const int by0 = a.out.oy + blockIdx.y * BLUR_BY - BLUR_R;
+  const int bx0 = a.out.ox + blk.x * BLUR_BX - BLUR_R;  // frame coordinates of the tile origin
+  const int by0 = a.out.oy + blk.y * BLUR_BY - BLUR_R;
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
   for (int t = tid; t < BLUR_TW * BLUR_TH; t += BLUR_THREADS) {
     const int tx = t % BLUR_TW, ty = t / BLUR_TW;
@@ -429,8 +432,8 @@ __global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
   }
   __syncthreads();
 
-  const int lx = blockIdx.x * BLUR_BX + threadIdx.x;
-  const int lyA = blockIdx.y * BLUR_BY + 2 * threadIdx.y;
+  const int lx = blk.x * BLUR_BX + threadIdx.x;
+  const int lyA = blk.y * BLUR_BY + 2 * threadIdx.y;
   if (lx >= a.out.w || lyA >= a.out.h) return;
   const bool has_b = lyA + 1 < a.out.h;
 

@@ -16,11 +16,12 @@ struct TaaArgs {
 VKR_DEV f3 rgb(f4 v) { return mk3(v.x, v.y, v.z); }
 
 __global__ __launch_bounds__(256) void k_taa_resolve(TaaArgs a) {
+  const i2 blk = xcd_block<2, 16>();  // chunks of 128 x 64 output pixels
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   srgb_lut_stage(s_lut, threadIdx.y * blockDim.x + threadIdx.x, 256);
   __syncthreads();
-  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+  const int lx = blk.x * blockDim.x + threadIdx.x;
+  const int ly = blk.y * blockDim.y + threadIdx.y;
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   const f2 screen_uv = mk2(((float)gx + 0.5f) / (float)a.out.fw, ((float)gy + 0.5f) / (float)a.out.fh);
