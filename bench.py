@@ -194,6 +194,11 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get(dominant)
+        valu_busy = None
+        vpath = os.path.join(ROOT, "profiles", "valu_busy.json")
+        if os.path.exists(vpath):
+            with open(vpath) as f:
+                valu_busy = json.load(f).get(dominant)
         out = {
             "metric": METRIC,
             "value": px * args.steps / elapsed / 1e6,
@@ -226,6 +231,9 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
+                # fraction of the SIMD issue slots the kernel keeps busy with VALU work (profiles/valu_busy.json,
+                # from SQ_ACTIVE_INST_VALU): why the HBM fraction is low — the pass is issue-bound, not memory-bound
+                "valu_busy": valu_busy,
                 "avg_launch_ms": avg_launch_ms,
                 "algorithmic_bytes_per_launch": algo_bytes_launch,
             },

@@ -130,6 +130,14 @@ def main():
                     ratio = f"{4.0 * cs['SQ_ACTIVE_INST_VALU'] / 1024.0 / (cs['_duration_ns'] * 2.4):.2f}"
                 g.write(f"| {k} | " + " | ".join(f"{cs.get(c, float('nan')):.4g}" for c in names) + f" | {ratio} |\n")
         print("wrote", f"profiles/{a.tag}_sq_counters.md")
+        busy = {}
+        for k, (task, _) in TASK_OF.items():
+            cs = merged.get(k, {})
+            if "SQ_ACTIVE_INST_VALU" in cs and cs.get("_duration_ns"):
+                busy[task] = 4.0 * cs["SQ_ACTIVE_INST_VALU"] / 1024.0 / (cs["_duration_ns"] * 2.4)
+        with open("profiles/valu_busy.json", "w") as g:
+            json.dump(busy, g, indent=1)
+        print("wrote profiles/valu_busy.json")
 
 
 if __name__ == "__main__":
