@@ -356,7 +356,7 @@ struct BlurArgs {
 // rho(k)*exp(-2/e)), the bilateral term uses a reciprocal-multiply, colour is accumulated in
 // UNORM8 code units and scaled by 1/255 once.
 #define BLUR_BX 32
-#define BLUR_BY 16
+#define BLUR_BY 32
 #define BLUR_R 11
 #define BLUR_TW (BLUR_BX + 2 * BLUR_R)
 #define BLUR_TH (BLUR_BY + 2 * BLUR_R)
@@ -409,7 +409,7 @@ VKR_DEV f4 blur_single(const float4* s_nd, const uint32_t* s_refl, const BlurCen
 }
 
 __global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
-  const i2 blk = xcd_block<4, 4>();  // chunks of 128 x 64 output pixels
+  const i2 blk = xcd_block<4, 2>();  // chunks of 128 x 64 output pixels
   // staged tile, one float4 {normal.xyz, depth} + one packed RGBA8 reflection texel per pixel
   __shared__ float4 s_nd[BLUR_TH * BLUR_TW];
   __shared__ uint32_t s_refl[BLUR_TH * BLUR_TW];
