@@ -38,6 +38,53 @@ def run_chain(backend="oracle", device=None):
     return c
 
 
+# second fixture: the rows added around the chain (8(f) #1, #4)
+EXTRA_IMAGES = ("ssr_out", "color_out", "brdf_crop", "raw_graphics", "ao_output", "raw_deinterleaved", "st_raw", "st_filtered",
+                "st_accumulated", "rays_indirect")
+
+
+def run_extras(backend="oracle", device=None):
+    """{name: ImageBuf} after running each widened pass once on the frozen 256x144 scene."""
+    from vk_renderer_amd.images import ImageBuf
+
+    c = run_chain(backend, device)
+    out = {}
+
+    def snap(name, img):
+        b = ImageBuf(img.format, img.width, img.height, img.mips)
+        b.upload(img.to_host())
+        out[name] = b
+
+    c.ssr_simple()
+    snap("ssr_out", c.ssr_out)
+    c.preintegrate_brdf()
+    c.shading()
+    snap("color_out", c.color_out)
+    crop_src = c.brdf.raw(0)[::64, ::64].copy()  # 16 x 16 spot grid of the 1024^2 split-sum LUT
+    lut = ImageBuf(c.brdf.format, crop_src.shape[1], crop_src.shape[0])
+    lut.set_raw(crop_src)
+    out["brdf_crop"] = lut
+    c.gtao_main_graphics()
+    snap("raw_graphics", c.raw)
+    c.gtao_filter()
+    c.gtao_reproject()
+    snap("ao_output", c.ao_output)
+    c.deinterleave_depth(2)
+    c.gtao_main_deinterleaved(layer=5)
+    snap("raw_deinterleaved", c.raw)
+    c.screen_trace()
+    snap("st_raw", c.st_raw)
+    c.screen_trace_filter()
+    snap("st_filtered", c.st_filtered)
+    c.screen_trace_accumulate()
+    snap("st_accumulated", c.st_accumulated)
+    c.ssr_classify()
+    c.ssr_trace_indirect(frame_random=3)
+    snap("rays_indirect", c.rays)
+    c.sync()
+    return out
+
+
 def digest(img):
     host = img.to_host()
     out = []
@@ -64,6 +111,15 @@ def main():
         data[name + "__crop"] = crop(img)
     data["pdf__spot"] = c.pdf.decode()[[100, 512, 900], :, 0][:, [100, 512, 900]]
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "chain_256x144.npz")
+    np.savez_compressed(out, **data)
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+    extras = run_extras()
+    data = {}
+    for name in EXTRA_IMAGES:
+        data[name + "__sha256"] = np.array(digest(extras[name]))
+        data[name + "__crop"] = crop(extras[name]) if extras[name].height >= 16 and extras[name].width >= 24 else extras[name].raw(0)
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "extras_256x144.npz")
     np.savez_compressed(out, **data)
     print("wrote", out, os.path.getsize(out), "bytes")
 
