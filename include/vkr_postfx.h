@@ -173,6 +173,33 @@ typedef struct vkr_screen_trace_filter_push { float znear, zfar; } vkr_screen_tr
 /* screen_trace/accumulate.comp:7-12 (screen_trace.cpp:148-153)                                     */
 typedef struct vkr_screen_trace_accum_push { float fovy, aspect, znear, zfar; } vkr_screen_trace_accum_push;
 
+/* ---- G-buffer raster stage --------------------------------------------------- */
+/* scene::Vertex, scene/scene.hpp:15-19                                                              */
+typedef struct vkr_raster_vertex { float pos[3], norm[3], uv[2]; } vkr_raster_vertex;
+/* Transform, gbuf/opaque_taa.vert:15-18                                                             */
+typedef struct vkr_raster_transform { vkr_mat4 model, normal; } vkr_raster_transform;
+/* one draw_indexed of scene_renderer.cpp:196-214 with its push constants (:132-137)                 */
+typedef struct vkr_raster_draw {
+  uint32_t transform_index, albedo_index, mr_index, flags;   /* PushData; 0xFFFFFFFF = no texture    */
+  uint32_t index_offset, index_count, vertex_offset, reserved;
+} vkr_raster_draw;
+/* GbufConst, scene_renderer.cpp:148-153 / opaque_taa.vert:7-12                                      */
+typedef struct vkr_gbuf_const {
+  vkr_mat4 view_projection, prev_view_projection;
+  float    jitter[4];
+  float    fovy_aspect_znear_zfar[4];
+} vkr_gbuf_const;
+/* vertices / indices / transforms: device memory; draws and textures: host arrays (launch params).
+ * Textures are RGBA8_SRGB images with full mip chains (scene/images.cpp:32-49), sampled with the
+ * scene sampler (scene_renderer.cpp:77-81: bilinear, linear mip, REPEAT).                          */
+typedef struct vkr_raster_scene {
+  const vkr_raster_vertex*    vertices;   uint32_t vertex_count;
+  const uint32_t*             indices;    uint32_t index_count;
+  const vkr_raster_transform* transforms; uint32_t transform_count;
+  const vkr_raster_draw*      draws;      uint32_t draw_count;
+  const vkr_img*              textures;   uint32_t texture_count;
+} vkr_raster_scene;
+
 /* Parameters of the synthetic G-buffer generator (replaces the raster stage
  * scene_renderer.cpp:140-220 + gbuf/opaque_taa.{vert,frag}). */
 typedef struct vkr_synth_params {
@@ -330,6 +357,18 @@ int vkr_screen_trace_filter(const vkr_img* raw, const vkr_img* depth, const vkr_
  * (accum is read and written in place).                                                            */
 int vkr_screen_trace_accumulate(const vkr_img* depth, const vkr_img* prev_depth, const vkr_img* current,
                                 const vkr_img* accum_inout, const vkr_screen_trace_accum_push* push, void* stream);
+
+/* program "gbuf_opaque_taa": SceneRenderer::draw_taa (scene_renderer.cpp:140-220) + gbuf/opaque_taa.{vert,frag}
+ * as a compute rasterizer: attachments cleared (colour 0, depth 1), every triangle of every draw
+ * rasterised into a 64-bit visibility buffer (depth | triangle) with atomics, then resolved per pixel
+ * (perspective-correct attributes, trilinear sRGB textures, octahedral normal, velocity).  Frozen
+ * raster rules: pixel centres, top-left fill rule, 8 sub-pixel bits, cull none, depth LESS_OR_EQUAL
+ * in D24 (gpu/pipelines.hpp:113-128), near-plane clipping in clip space, implicit LOD from forward
+ * differences of the interpolated uv.  `scratch`: vkr_raster_scratch_bytes() of device memory.      */
+uint64_t vkr_raster_scratch_bytes(uint32_t width, uint32_t height);
+int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_const* consts, const vkr_img* albedo,
+                       const vkr_img* normal, const vkr_img* material, const vkr_img* velocity, const vkr_img* depth,
+                       void* scratch, uint64_t scratch_bytes, void* stream);
 
 /* synthetic G-buffer generator (no reference program).  Any of the
  * colour outputs may be NULL when VKR_SYNTH_DEPTH_ONLY is set.                          */

@@ -158,6 +158,26 @@ class ScreenTraceAccumPush(C.Structure):
     _fields_ = [("fovy", C.c_float), ("aspect", C.c_float), ("znear", C.c_float), ("zfar", C.c_float)]
 
 
+class RasterTransform(C.Structure):
+    _fields_ = [("model", Mat4), ("normal", Mat4)]
+
+
+class RasterDraw(C.Structure):
+    _fields_ = [("transform_index", C.c_uint32), ("albedo_index", C.c_uint32), ("mr_index", C.c_uint32), ("flags", C.c_uint32),
+                ("index_offset", C.c_uint32), ("index_count", C.c_uint32), ("vertex_offset", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class GbufConst(C.Structure):
+    _fields_ = [("view_projection", Mat4), ("prev_view_projection", Mat4), ("jitter", C.c_float * 4),
+                ("fovy_aspect_znear_zfar", C.c_float * 4)]
+
+
+class RasterScene(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("vertex_count", C.c_uint32), ("indices", C.c_void_p), ("index_count", C.c_uint32),
+                ("transforms", C.c_void_p), ("transform_count", C.c_uint32), ("draws", C.c_void_p), ("draw_count", C.c_uint32),
+                ("textures", C.c_void_p), ("texture_count", C.c_uint32)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("camera_to_world", Mat4), ("prev_mvp", Mat4), ("mvp", Mat4), ("fovy", C.c_float), ("aspect", C.c_float),
                 ("znear", C.c_float), ("zfar", C.c_float), ("seed", C.c_uint32), ("flags", C.c_uint32)]
@@ -183,6 +203,8 @@ ENTRY_ARGS = {
     "ssr": [_IMG, _IMG, _IMG, P(SsrParams), _IMG, _IMG],
     "brdf_preintegrate": [C.c_void_p, _IMG],
     "defered_shading": [_IMG, _IMG, _IMG, _IMG, P(ShadingParams), _IMG, _IMG, _IMG, _IMG, P(ShadingPush)],
+    # G-buffer raster stage; trailing (scratch pointer, scratch bytes)
+    "raster_gbuffer": [P(RasterScene), P(GbufConst), _IMG, _IMG, _IMG, _IMG, _IMG, C.c_void_p, C.c_uint64],
     # tile-classified trace: tile lists / indirect args are raw device (oracle: host) pointers
     "sssr_clear_indirect": [C.c_void_p, C.c_void_p],
     "sssr_classification": [_IMG, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(ClassificationPush)],
@@ -230,6 +252,8 @@ def product():
             fn.restype = C.c_int
         lib.vkr_stream_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.vkr_stream_read.restype = C.c_int
+        lib.vkr_raster_scratch_bytes.argtypes = [C.c_uint32, C.c_uint32]
+        lib.vkr_raster_scratch_bytes.restype = C.c_uint64
         lib.vkr_halton23_fill.argtypes = [C.c_void_p, C.c_uint32]
         lib.vkr_halton23_fill.restype = None
         lib.vkr_version.restype = C.c_char_p

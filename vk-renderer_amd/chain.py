@@ -147,6 +147,43 @@ class PostFxChain:
         pp = s.synth(prev=True, depth_only=True)
         self.call("synth_gbuffer", C.byref(self.prev_depth.desc(0, 1)), None, None, None, None, C.byref(pp))
 
+    def raster(self, scene, target="current"):
+        """SceneRenderer::draw_taa (scene_renderer.cpp:140-220) on `scene` (scene.Scene) instead of the synthetic
+        generator: fills albedo / normal / material / velocity / depth mip 0 for the current camera.  target="prev":
+        only the depth of the previous camera is kept (into prev_depth), like build_prev_hiz does for the generator."""
+        key = "_scene_dev" if self.device is not None else "_scene_host"
+        cached = getattr(scene, key, None)
+        if cached is None:
+            cached = scene.upload(self.device)
+            setattr(scene, key, cached)
+        rs, _ = cached
+        c = abi.GbufConst()
+        st = self.setup
+        if target == "current":
+            c.view_projection, c.prev_view_projection = abi.Mat4.from_np(st.mvp), abi.Mat4.from_np(st.prev_mvp)
+        else:
+            c.view_projection, c.prev_view_projection = abi.Mat4.from_np(st.prev_mvp), abi.Mat4.from_np(st.prev_mvp)
+        c.fovy_aspect_znear_zfar = (C.c_float * 4)(*[float(v) for v in st.fazz])
+        depth = self.depth if target == "current" else self.prev_depth
+        if target == "current":
+            outs = (self.albedo, self.normal, self.material, self.velocity)
+        else:
+            if not hasattr(self, "_raster_dummy"):
+                self._raster_dummy = [ImageBuf(f, self.albedo.width, self.albedo.height, device=self.device, full=self.albedo.full, origin=self.albedo.origin)
+                                      for f in (abi.FMT_RGBA8_SRGB, abi.FMT_RG16_UNORM, abi.FMT_RGBA8_SRGB, abi.FMT_RG16_SFLOAT)]
+            outs = self._raster_dummy
+        scratch_ptr, nbytes = C.c_void_p(0), 0
+        if self.backend == "product":
+            import torch
+
+            W, H = self.albedo.full
+            nbytes = int(self.lib.vkr_raster_scratch_bytes(W, H))
+            if getattr(self, "_raster_scratch", None) is None or self._raster_scratch.numel() < nbytes:
+                self._raster_scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            scratch_ptr = C.c_void_p(self._raster_scratch.data_ptr())
+        self.call("raster_gbuffer", C.byref(rs), C.byref(c), C.byref(outs[0].desc()), C.byref(outs[1].desc()), C.byref(outs[2].desc()),
+                  C.byref(outs[3].desc()), C.byref(depth.desc(0, 1)), scratch_ptr, nbytes)
+
     def build_prev_hiz(self):
         """prev_depth's mips: what last frame's DownsamplePass left in the image that is now prev_depth (main.cpp:416)."""
         scratch_n = ImageBuf(abi.FMT_RG16_UNORM, self.dn.width, self.dn.height, device=self.device)

@@ -1,0 +1,386 @@
+// raster.hip — program "gbuf_opaque_taa": the G-buffer raster stage of the reference
+// (SceneRenderer::draw_taa, scene_renderer.cpp:140-220 + shaders/gbuf/opaque_taa.{vert,frag}) as a
+// compute rasterizer.
+//
+//   k_raster_clear    visibility buffer := empty
+//   k_raster_tris     one wave per triangle: vertex shader on its three corners, near-plane clip, 8-bit
+//                     sub-pixel snap, bounding box walked in 8x8 pixel blocks (one pixel per lane), fill
+//                     rule on exact 64-bit edge functions, D24 depth, atomicMin of (depth << 32 | ~triangle)
+//                     — LESS_OR_EQUAL with later triangles winning ties (gpu/pipelines.hpp:128)
+//   k_raster_resolve  one thread per pixel: re-derives the winning triangle, perspective-correct
+//                     attributes, implicit LOD from forward differences, trilinear sRGB fetches, stores
+//
+// Coverage and depth are integer-exact functions of the snapped vertices, so they are bit-equal to
+// the oracle's immediate-mode rasterizer; colour / normal / velocity follow the frozen fp32 contract.
+#include <vector>
+
+#include "vkr_host.hpp"
+
+namespace vkr {
+
+#define RASTER_MAX_TEXTURES 32
+#define RASTER_GUARD_PX 1048576.0f  // |screen coordinate| beyond this: the triangle is dropped (documented limit)
+
+struct DrawDev {  // one draw call, matrices premultiplied on the host exactly as the vertex shader does
+  Mat4 mvp, prev_mvp, normal_mat;
+  uint32_t albedo_index, mr_index, index_offset, vertex_offset;
+  uint32_t tri_base, tri_count, pad0, pad1;
+};
+
+struct RasterArgs {
+  const vkr_raster_vertex* vertices;
+  const uint32_t* indices;
+  const DrawDev* draws;
+  uint32_t draw_count;
+  unsigned long long* vis;
+  int width, height;  // framebuffer = whole frame
+  float jitter_x, jitter_y;
+};
+
+struct VsOut { f4 position, pos_after, pos_before; f3 normal; f2 uv; };
+
+// opaque_taa.vert:35-45
+VKR_DEV VsOut vertex_shader(const RasterArgs& a, const DrawDev& d, uint32_t index) {
+  const vkr_raster_vertex v = a.vertices[d.vertex_offset + a.indices[d.index_offset + index]];
+  VsOut o;
+  o.normal = normalize(xyz(mul(d.normal_mat, mk4(v.norm[0], v.norm[1], v.norm[2], 0.0f))));
+  o.uv = mk2(v.uv[0], v.uv[1]);
+  const f4 out_vector = mul(d.mvp, mk4(v.pos[0], v.pos[1], v.pos[2], 1.0f));
+  o.position = mk4(out_vector.x + out_vector.w * a.jitter_x, out_vector.y + out_vector.w * a.jitter_y, out_vector.z, out_vector.w);
+  o.pos_after = out_vector;
+  o.pos_before = mul(d.prev_mvp, mk4(v.pos[0], v.pos[1], v.pos[2], 1.0f));
+  return o;
+}
+
+VKR_DEV VsOut vs_lerp(const VsOut& p, const VsOut& q, float t) {  // p + t (q - p), every output
+  VsOut o;
+#define L1(F) o.F = p.F + t * (q.F - p.F)
+  L1(position.x); L1(position.y); L1(position.z); L1(position.w);
+  L1(pos_after.x); L1(pos_after.y); L1(pos_after.z); L1(pos_after.w);
+  L1(pos_before.x); L1(pos_before.y); L1(pos_before.z); L1(pos_before.w);
+  L1(normal.x); L1(normal.y); L1(normal.z);
+  L1(uv.x); L1(uv.y);
+#undef L1
+  return o;
+}
+
+// A triangle ready for rasterisation: snapped screen positions (8 sub-pixel bits), 1/w-space data
+struct ScreenTri {
+  long long x[3], y[3];
+  float w[3], z[3];  // clip w and z / w
+  long long area2;
+  VsOut v[3];
+  bool valid;
+};
+
+VKR_DEV long long edge_fn(long long ax, long long ay, long long bx, long long by, long long px, long long py) {
+  return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+}
+// top-left rule for an edge a->b of a triangle with positive area2 under edge_fn (y down)
+VKR_DEV bool is_top_left(long long ax, long long ay, long long bx, long long by) {
+  const long long dx = bx - ax, dy = by - ay;
+  return dy < 0 || (dy == 0 && dx > 0);
+}
+
+// Vertex shader on the three corners + near-plane clip (z_clip >= 0) -> sub-triangle `sub` (0 or 1).
+// Returns the number of sub-triangles the clipped polygon has (0, 1 or 2) in *count.
+VKR_DEV ScreenTri setup_triangle(const RasterArgs& a, const DrawDev& d, uint32_t tri, int sub, int* count) {
+  ScreenTri t;
+  t.valid = false;
+  VsOut in[3], poly[4];
+  for (int k = 0; k < 3; k++) in[k] = vertex_shader(a, d, 3u * tri + (uint32_t)k);
+  int n = 0;
+  for (int k = 0; k < 3; k++) {  // Sutherland-Hodgman against z >= 0
+    const VsOut& p = in[k];
+    const VsOut& q = in[(k + 1) % 3];
+    const bool pin = p.position.z >= 0.0f, qin = q.position.z >= 0.0f;
+    if (pin) poly[n++] = p;
+    if (pin != qin) {
+      // always interpolate from the inside vertex so both orientations of a shared edge agree
+      const VsOut& s = pin ? p : q;
+      const VsOut& e = pin ? q : p;
+      poly[n++] = vs_lerp(s, e, s.position.z / (s.position.z - e.position.z));
+    }
+  }
+  *count = n < 3 ? 0 : n - 2;
+  if (sub >= *count) return t;
+  t.v[0] = poly[0]; t.v[1] = poly[1 + sub]; t.v[2] = poly[2 + sub];
+  for (int k = 0; k < 3; k++) {
+    const f4 p = t.v[k].position;
+    if (!(p.w > 0.0f)) return t;
+    const float xs = ((p.x / p.w) * 0.5f + 0.5f) * (float)a.width;
+    const float ys = ((p.y / p.w) * 0.5f + 0.5f) * (float)a.height;
+    if (!(fabsf(xs) <= RASTER_GUARD_PX && fabsf(ys) <= RASTER_GUARD_PX)) return t;
+    t.x[k] = (long long)rintf(xs * 256.0f);
+    t.y[k] = (long long)rintf(ys * 256.0f);
+    t.w[k] = p.w;
+    t.z[k] = p.z / p.w;
+  }
+  t.area2 = edge_fn(t.x[0], t.y[0], t.x[1], t.y[1], t.x[2], t.y[2]);
+  if (t.area2 == 0) return t;
+  if (t.area2 < 0) {  // cull none: both windings are drawn; normalise the orientation
+    const VsOut tv = t.v[1]; t.v[1] = t.v[2]; t.v[2] = tv;
+    long long tl = t.x[1]; t.x[1] = t.x[2]; t.x[2] = tl;
+    tl = t.y[1]; t.y[1] = t.y[2]; t.y[2] = tl;
+    float tf = t.w[1]; t.w[1] = t.w[2]; t.w[2] = tf;
+    tf = t.z[1]; t.z[1] = t.z[2]; t.z[2] = tf;
+    t.area2 = -t.area2;
+  }
+  t.valid = true;
+  return t;
+}
+
+// coverage + depth of pixel (px, py); lambda: screen-space barycentrics
+VKR_DEV bool cover(const ScreenTri& t, int px, int py, float lambda[3], uint32_t* d24) {
+  const long long X = ((long long)px << 8) + 128, Y = ((long long)py << 8) + 128;
+  const long long e0 = edge_fn(t.x[1], t.y[1], t.x[2], t.y[2], X, Y);
+  const long long e1 = edge_fn(t.x[2], t.y[2], t.x[0], t.y[0], X, Y);
+  const long long e2 = edge_fn(t.x[0], t.y[0], t.x[1], t.y[1], X, Y);
+  if (e0 < 0 || e1 < 0 || e2 < 0) return false;
+  if (e0 == 0 && !is_top_left(t.x[1], t.y[1], t.x[2], t.y[2])) return false;
+  if (e1 == 0 && !is_top_left(t.x[2], t.y[2], t.x[0], t.y[0])) return false;
+  if (e2 == 0 && !is_top_left(t.x[0], t.y[0], t.x[1], t.y[1])) return false;
+  const double inv = 1.0 / (double)t.area2;
+  lambda[0] = (float)((double)e0 * inv);
+  lambda[1] = (float)((double)e1 * inv);
+  lambda[2] = (float)((double)e2 * inv);
+  const float depth = (lambda[0] * t.z[0] + lambda[1] * t.z[1]) + lambda[2] * t.z[2];
+  if (!(depth >= 0.0f && depth <= 1.0f)) return false;  // depth clipping (far plane; near was clipped)
+  *d24 = (uint32_t)rintf(depth * 16777215.0f);
+  return true;
+}
+// barycentrics at an arbitrary (possibly uncovered) pixel, for the forward differences of uv
+VKR_DEV void lambda_at(const ScreenTri& t, int px, int py, float lambda[3]) {
+  const long long X = ((long long)px << 8) + 128, Y = ((long long)py << 8) + 128;
+  const double inv = 1.0 / (double)t.area2;
+  lambda[0] = (float)((double)edge_fn(t.x[1], t.y[1], t.x[2], t.y[2], X, Y) * inv);
+  lambda[1] = (float)((double)edge_fn(t.x[2], t.y[2], t.x[0], t.y[0], X, Y) * inv);
+  lambda[2] = (float)((double)edge_fn(t.x[0], t.y[0], t.x[1], t.y[1], X, Y) * inv);
+}
+VKR_DEV void perspective(const ScreenTri& t, const float lambda[3], float b[3]) {
+  const float q0 = lambda[0] / t.w[0], q1 = lambda[1] / t.w[1], q2 = lambda[2] / t.w[2];
+  const float s = (q0 + q1) + q2;
+  b[0] = q0 / s; b[1] = q1 / s; b[2] = q2 / s;
+}
+#define BARY(F) ((b[0] * t.v[0].F + b[1] * t.v[1].F) + b[2] * t.v[2].F)
+
+__global__ void k_raster_clear(unsigned long long* vis, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) vis[i] = ~0ull;
+}
+
+// one wave per triangle
+__global__ __launch_bounds__(256) void k_raster_tris(RasterArgs a, uint32_t draw_index) {
+  const DrawDev d = a.draws[draw_index];
+  const uint32_t tri = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (tri >= d.tri_count) return;
+  for (int sub = 0; sub < 2; sub++) {
+    int count;
+    const ScreenTri t = setup_triangle(a, d, tri, sub, &count);
+    if (sub >= count) break;
+    if (!t.valid) continue;
+    // bounding box in pixels whose centres can be covered
+    long long minx = min(t.x[0], min(t.x[1], t.x[2])), maxx = max(t.x[0], max(t.x[1], t.x[2]));
+    long long miny = min(t.y[0], min(t.y[1], t.y[2])), maxy = max(t.y[0], max(t.y[1], t.y[2]));
+    int x0 = (int)max((minx - 128) >> 8, 0ll), x1 = (int)min((maxx - 128) >> 8, (long long)a.width - 1);
+    int y0 = (int)max((miny - 128) >> 8, 0ll), y1 = (int)min((maxy - 128) >> 8, (long long)a.height - 1);
+    if (x0 > x1 || y0 > y1) continue;
+    const unsigned long long id = 0xFFFFFFFFull - (unsigned long long)((d.tri_base + tri) * 2u + (uint32_t)sub);
+    for (int by = y0 & ~7; by <= y1; by += 8) {
+      for (int bx = x0 & ~7; bx <= x1; bx += 8) {
+        const int px = bx + (lane & 7), py = by + (lane >> 3);
+        if (px < x0 || px > x1 || py < y0 || py > y1) continue;
+        float lambda[3];
+        uint32_t d24;
+        if (!cover(t, px, py, lambda, &d24)) continue;
+        atomicMin(&a.vis[(size_t)py * a.width + px], ((unsigned long long)d24 << 32) | id);
+      }
+    }
+  }
+}
+
+struct ResolveArgs {
+  RasterArgs r;
+  Tex albedo, normal, material, velocity, depth;
+  Pyramid tex[RASTER_MAX_TEXTURES];
+};
+
+VKR_DEV int wrap_repeat(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+// texture(sampler2D, uv) of an RGBA8_SRGB mip chain: REPEAT, bilinear, linear between the two mips of `lod`
+VKR_DEV f4 sample_level_repeat(const Tex& t, f2 uv) {
+  const float x = uv.x * (float)t.fw - 0.5f, y = uv.y * (float)t.fh - 0.5f;
+  const float x0f = floorf(x), y0f = floorf(y);
+  const float fx = x - x0f, fy = y - y0f;
+  const int x0 = wrap_repeat(f2i(x0f), t.fw), y0 = wrap_repeat(f2i(y0f), t.fh);
+  const int x1 = wrap_repeat(x0 + 1, t.fw), y1 = wrap_repeat(y0 + 1, t.fh);
+  auto dec = [&](int tx, int ty) {
+    const uint32_t v = *texel_ptr<const uint32_t>(t, tx, ty);
+    return mk4(srgb8_to_float(v & 0xFFu), srgb8_to_float((v >> 8) & 0xFFu), srgb8_to_float((v >> 16) & 0xFFu), unorm8_to_float(v >> 24));
+  };
+  return mix4(mix4(dec(x0, y0), dec(x1, y0), fx), mix4(dec(x0, y1), dec(x1, y1), fx), fy);
+}
+VKR_DEV f4 sample_trilinear(const Pyramid& p, f2 uv, f2 duvdx, f2 duvdy) {
+  const float w = (float)p.mip[0].fw, h = (float)p.mip[0].fh;
+  // rho^2 = max squared footprint; lod = log2(rho).  The level pair comes from the exponent of rho^2
+  // (exact), only the blend factor from log2f (smooth) — a libm ulp must not flip the pair.
+  const float rx2 = (duvdx.x * w) * (duvdx.x * w) + (duvdx.y * h) * (duvdx.y * h);
+  const float ry2 = (duvdy.x * w) * (duvdy.x * w) + (duvdy.y * h) * (duvdy.y * h);
+  const float r2 = vmax(rx2, ry2);
+  int l0 = 0;
+  float f = 0.0f;
+  if (r2 > 1.0f && r2 < 3.0e38f) {
+    l0 = ilogbf(r2) >> 1;  // floor(log2(rho))
+    f = vclamp(0.5f * log2f(r2) - (float)l0, 0.0f, 1.0f);
+  }
+  if (l0 >= p.count - 1) { l0 = p.count - 1; f = 0.0f; }  // sampler LOD range [0, 10] and the chain length
+  const int l1 = min(l0 + 1, p.count - 1);
+  const f4 a = sample_level_repeat(p.mip[l0], uv);
+  if (f == 0.0f || l1 == l0) return a;
+  return mix4(a, sample_level_repeat(p.mip[l1], uv), f);
+}
+
+__global__ __launch_bounds__(256) void k_raster_resolve(ResolveArgs a) {
+  const int lx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ly = blockIdx.y * blockDim.y + threadIdx.y;
+  if (lx >= a.albedo.w || ly >= a.albedo.h) return;
+  const int px = a.albedo.ox + lx, py = a.albedo.oy + ly;
+  const unsigned long long key = a.r.vis[(size_t)py * a.r.width + px];
+  uint32_t o_albedo = 0u, o_normal = 0u, o_material = 0u, o_velocity = 0u, o_depth = 0x00FFFFFFu;  // cleared attachments
+  if (key != ~0ull) {
+    const uint32_t gid2 = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+    const uint32_t gid = gid2 >> 1;
+    const int sub = (int)(gid2 & 1u);
+    uint32_t di = 0;
+    while (di + 1 < a.r.draw_count && gid >= a.r.draws[di + 1].tri_base) di++;
+    const DrawDev d = a.r.draws[di];
+    int count;
+    const ScreenTri t = setup_triangle(a.r, d, gid - d.tri_base, sub, &count);
+    float lambda[3], b[3];
+    uint32_t d24 = 0;
+    cover(t, px, py, lambda, &d24);
+    perspective(t, lambda, b);
+    const f3 in_normal = mk3(BARY(normal.x), BARY(normal.y), BARY(normal.z));
+    const f2 in_uv = mk2(BARY(uv.x), BARY(uv.y));
+    const f4 pa = mk4(BARY(pos_after.x), BARY(pos_after.y), BARY(pos_after.z), BARY(pos_after.w));
+    const f4 pb = mk4(BARY(pos_before.x), BARY(pos_before.y), BARY(pos_before.z), BARY(pos_before.w));
+    // implicit derivatives: forward differences of the interpolated uv
+    float lx1[3], ly1[3], bx1[3], by1[3];
+    lambda_at(t, px + 1, py, lx1);
+    lambda_at(t, px, py + 1, ly1);
+    perspective(t, lx1, bx1);
+    perspective(t, ly1, by1);
+    const f2 uvx = mk2((bx1[0] * t.v[0].uv.x + bx1[1] * t.v[1].uv.x) + bx1[2] * t.v[2].uv.x, (bx1[0] * t.v[0].uv.y + bx1[1] * t.v[1].uv.y) + bx1[2] * t.v[2].uv.y);
+    const f2 uvy = mk2((by1[0] * t.v[0].uv.x + by1[1] * t.v[1].uv.x) + by1[2] * t.v[2].uv.x, (by1[0] * t.v[0].uv.y + by1[1] * t.v[1].uv.y) + by1[2] * t.v[2].uv.y);
+    const f2 ddx = uvx - in_uv, ddy = uvy - in_uv;
+    // opaque_taa.frag:26-46
+    f4 out_albedo = mk4(0.5f, 0.5f, 0.5f, 1.0f);
+    if (d.albedo_index != 0xFFFFFFFFu) out_albedo = sample_trilinear(a.tex[d.albedo_index], in_uv, ddx, ddy);
+    f4 out_material = mk4(0.5f, 0.9f, 0.5f, 0.5f);
+    if (d.mr_index != 0xFFFFFFFFu) out_material = sample_trilinear(a.tex[d.mr_index], in_uv, ddx, ddy);
+    const f2 en = encode_normal(in_normal);
+    const f2 vel = mk2(0.5f * (pb.x / pb.w - pa.x / pa.w), 0.5f * (pb.y / pb.w - pa.y / pa.w));
+    o_albedo = float_to_srgb8(out_albedo.x) | (float_to_srgb8(out_albedo.y) << 8) | (float_to_srgb8(out_albedo.z) << 16) | (float_to_unorm8(out_albedo.w) << 24);
+    o_material = float_to_srgb8(out_material.x) | (float_to_srgb8(out_material.y) << 8) | (float_to_srgb8(out_material.z) << 16) | (float_to_unorm8(out_material.w) << 24);
+    o_normal = float_to_unorm16(en.x) | (float_to_unorm16(en.y) << 16);
+    o_velocity = float_to_half_bits(vel.x) | (float_to_half_bits(vel.y) << 16);
+    o_depth = (uint32_t)(key >> 32);
+  }
+  *texel_ptr<uint32_t>(a.albedo, lx, ly) = o_albedo;
+  *texel_ptr<uint32_t>(a.normal, lx, ly) = o_normal;
+  *texel_ptr<uint32_t>(a.material, lx, ly) = o_material;
+  *texel_ptr<uint32_t>(a.velocity, lx, ly) = o_velocity;
+  *texel_ptr<uint32_t>(a.depth, lx, ly) = o_depth;
+}
+
+// c = a * b with GLSL's mat4 * mat4 (column-major, each element a dot product accumulated left to right)
+static void mat_mul(Mat4& c, const vkr_mat4& a, const vkr_mat4& b) {
+  for (int col = 0; col < 4; col++)
+    for (int row = 0; row < 4; row++) {
+      float s = a.m[0 * 4 + row] * b.m[col * 4 + 0];
+      for (int k = 1; k < 4; k++) s = s + a.m[k * 4 + row] * b.m[col * 4 + k];
+      c.m[col * 4 + row] = s;
+    }
+}
+
+}  // namespace vkr
+
+using namespace vkr;
+
+static uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+extern "C" uint64_t vkr_raster_scratch_bytes(uint32_t width, uint32_t height) {
+  return align_up((uint64_t)width * height * 8u, 256) + align_up(sizeof(DrawDev) * 1024u, 256);
+}
+
+extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_const* consts, const vkr_img* albedo,
+                                  const vkr_img* normal, const vkr_img* material, const vkr_img* velocity, const vkr_img* depth,
+                                  void* scratch, uint64_t scratch_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!scene || !consts || !scratch) { set_error("gbuf_opaque_taa: NULL argument"); return VKR_ERR_NULL; }
+  if (scene->draw_count > 1024 || scene->texture_count > RASTER_MAX_TEXTURES) {
+    set_error("gbuf_opaque_taa: at most 1024 draws and %d textures", RASTER_MAX_TEXTURES);
+    return VKR_ERR_EXTENT;
+  }
+  ResolveArgs ra;
+  VKR_TRY(make_tex(albedo, 0, VKR_FMT_RGBA8_SRGB, "gbuf_opaque_taa.albedo", &ra.albedo));
+  VKR_TRY(make_tex(normal, 0, VKR_FMT_RG16_UNORM, "gbuf_opaque_taa.normal", &ra.normal));
+  VKR_TRY(make_tex(material, 0, VKR_FMT_RGBA8_SRGB, "gbuf_opaque_taa.material", &ra.material));
+  VKR_TRY(make_tex(velocity, 0, VKR_FMT_RG16_SFLOAT, "gbuf_opaque_taa.velocity", &ra.velocity));
+  VKR_TRY(make_tex(depth, 0, VKR_FMT_D24_UNORM_S8, "gbuf_opaque_taa.depth", &ra.depth));
+  if (!same_window(ra.albedo, ra.normal) || !same_window(ra.albedo, ra.material) || !same_window(ra.albedo, ra.velocity) ||
+      !same_window(ra.albedo, ra.depth)) {
+    set_error("gbuf_opaque_taa: attachments differ in extent");
+    return VKR_ERR_EXTENT;
+  }
+  const int W = ra.albedo.fw, H = ra.albedo.fh;
+  if (scratch_bytes < vkr_raster_scratch_bytes((uint32_t)W, (uint32_t)H)) { set_error("gbuf_opaque_taa: scratch too small"); return VKR_ERR_EXTENT; }
+  for (uint32_t i = 0; i < scene->texture_count; i++) {
+    const vkr_img& t = scene->textures[i];
+    if (t.mip_count < 1 || t.mip_count > VKR_MAX_MIPS) { set_error("gbuf_opaque_taa: texture %u: bad mip count", i); return VKR_ERR_MIPS; }
+    ra.tex[i].count = (int)t.mip_count;
+    for (int m = 0; m < (int)t.mip_count; m++) VKR_TRY(make_tex(&t, m, VKR_FMT_RGBA8_SRGB, "gbuf_opaque_taa.texture", &ra.tex[i].mip[m]));
+    for (int m = (int)t.mip_count; m < 16; m++) ra.tex[i].mip[m] = ra.tex[i].mip[0];
+  }
+  // per-draw constants: view_projection * model exactly as opaque_taa.vert:39,44 multiplies them
+  std::vector<DrawDev> draws(scene->draw_count);
+  uint32_t tri_base = 0;
+  for (uint32_t i = 0; i < scene->draw_count; i++) {
+    const vkr_raster_draw& s = scene->draws[i];
+    if (s.transform_index >= scene->transform_count || (s.albedo_index != 0xFFFFFFFFu && s.albedo_index >= scene->texture_count) ||
+        (s.mr_index != 0xFFFFFFFFu && s.mr_index >= scene->texture_count) || s.index_offset + s.index_count > scene->index_count) {
+      set_error("gbuf_opaque_taa: draw %u references data outside the scene", i);
+      return VKR_ERR_EXTENT;
+    }
+    DrawDev& d = draws[i];
+    mat_mul(d.mvp, consts->view_projection, scene->transforms[s.transform_index].model);
+    mat_mul(d.prev_mvp, consts->prev_view_projection, scene->transforms[s.transform_index].model);
+    load_mat(d.normal_mat, scene->transforms[s.transform_index].normal);
+    d.albedo_index = s.albedo_index; d.mr_index = s.mr_index;
+    d.index_offset = s.index_offset; d.vertex_offset = s.vertex_offset;
+    d.tri_base = tri_base; d.tri_count = s.index_count / 3u;
+    d.pad0 = d.pad1 = 0;
+    tri_base += d.tri_count;
+  }
+  if (tri_base >= 0x7FFFFFFFu) { set_error("gbuf_opaque_taa: too many triangles"); return VKR_ERR_EXTENT; }
+  RasterArgs r;
+  r.vertices = scene->vertices; r.indices = scene->indices;
+  r.vis = (unsigned long long*)scratch;
+  r.draws = (const DrawDev*)((uint8_t*)scratch + align_up((uint64_t)W * H * 8u, 256));
+  r.draw_count = scene->draw_count;
+  r.width = W; r.height = H;
+  r.jitter_x = consts->jitter[0]; r.jitter_y = consts->jitter[1];
+  if (!draws.empty()) {
+    hipError_t e = hipMemcpyAsync((void*)r.draws, draws.data(), sizeof(DrawDev) * draws.size(), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // `draws` is a local: the copy must have left the host
+    if (e != hipSuccess) { set_error("gbuf_opaque_taa: draw table upload failed: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  const size_t npx = (size_t)W * H;
+  hipLaunchKernelGGL(k_raster_clear, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, r.vis, npx);
+  for (uint32_t i = 0; i < scene->draw_count; i++)
+    if (draws[i].tri_count) hipLaunchKernelGGL(k_raster_tris, dim3((draws[i].tri_count + 3) / 4), dim3(256), 0, stream, r, i);
+  ra.r = r;
+  dim3 block(64, 4);
+  hipLaunchKernelGGL(k_raster_resolve, grid2d(ra.albedo.w, ra.albedo.h, block), block, 0, stream, ra);
+  return launch_status("gbuf_opaque_taa");
+}

@@ -13,6 +13,7 @@ STAGE_HIZ_TAIL, STAGE_SSR, STAGE_GTAO, STAGE_TAA = 16, 32, 64, 128
 STAGE_SHADING, STAGE_BRDF_LUT, STAGE_GTAO_MAIN_ONLY = 256, 512, 1024
 STAGE_GTAO_GRAPHICS, STAGE_GTAO_DEINTERLEAVED, STAGE_SCREEN_TRACE = 2048, 4096, 8192
 STAGE_SSR_CLASSIFIED, STAGE_SSR_TRACE, STAGE_SSR_RESOLVE = 16384, 32768, 65536
+STAGE_RASTER = 131072
 STAGE_CHAIN = STAGE_DOWNSAMPLE | STAGE_SSR | STAGE_GTAO | STAGE_TAA
 
 
@@ -24,6 +25,16 @@ class HostConfig(C.Structure):
 class HostCamera(C.Structure):
     _fields_ = [("view", C.c_float * 16), ("prev_view", C.c_float * 16), ("projection", C.c_float * 16),
                 ("fovy", C.c_float), ("aspect", C.c_float), ("znear", C.c_float), ("zfar", C.c_float)]
+
+
+class SceneDraw(C.Structure):
+    _fields_ = [("transform", C.c_float * 16), ("vertex_offset", C.c_uint32), ("index_offset", C.c_uint32), ("index_count", C.c_uint32),
+                ("albedo_tex_index", C.c_uint32), ("metalic_roughness_index", C.c_uint32), ("clip_alpha", C.c_uint32)]
+
+
+class SceneTexture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("mip_levels", C.c_uint32), ("reserved", C.c_uint32),
+                ("levels", C.c_void_p * 16)]
 
 
 _ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_uint64, C.c_void_p)
@@ -49,6 +60,8 @@ def lib():
         l.vkrh_pin_screen_trace.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint32]
         l.vkrh_capture.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p]
         l.vkrh_read_buffer.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        l.vkrh_load_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(SceneDraw), C.c_uint32,
+                                      C.POINTER(SceneTexture), C.c_uint32]
         l.vkrh_last_tasks.argtypes = [C.c_void_p]
         l.vkrh_last_tasks.restype = C.c_char_p
         l.vkrh_enable_task_timing.argtypes = [C.c_void_p, C.c_uint32]
@@ -127,6 +140,32 @@ class HostFrame:
     def pin_randoms(self, angle_jitter=0.0, gtao_frame_count=0, ssr_counter=0):
         """angle_offset = table[frame_count % 12]/360 + jitter (gtao.cpp:109-111); SURVEY 8(d) pins 60/360 + 0."""
         self._check(lib().vkrh_pin_randoms(self.h, angle_jitter, gtao_frame_count, ssr_counter))
+
+    def set_camera(self, view, prev_view, proj, fazz):
+        cam = HostCamera()
+        cam.view, cam.prev_view, cam.projection = _mat16(view), _mat16(prev_view), _mat16(proj)
+        cam.fovy, cam.aspect, cam.znear, cam.zfar = [float(v) for v in fazz]
+        self._check(lib().vkrh_set_camera(self.h, C.byref(cam)))
+
+    def load_scene(self, sc):
+        """scene.Scene -> scene::CompiledScene + SceneRenderer inside the frame (main.cpp:250-259)."""
+        verts = np.ascontiguousarray(sc.vertices, dtype=np.float32)
+        idx = np.ascontiguousarray(sc.indices, dtype=np.uint32)
+        draws = (SceneDraw * max(1, len(sc.draws)))()
+        for i, d in enumerate(sc.draws):
+            m = sc.transforms[d["transform"]][0]
+            draws[i] = SceneDraw(_mat16(m), d["vertex_offset"], d["index_offset"], d["index_count"], d["albedo"], d["mr"], 1 if d["flags"] else 0)
+        tex = (SceneTexture * max(1, len(sc.textures)))()
+        keep = []
+        for i, levels in enumerate(sc.textures):
+            h, w = levels[0].shape[:2]
+            tex[i].width, tex[i].height, tex[i].mip_levels = w, h, len(levels)
+            for m, lv in enumerate(levels):
+                a = np.ascontiguousarray(lv)
+                keep.append(a)
+                tex[i].levels[m] = a.ctypes.data
+        self._check(lib().vkrh_load_scene(self.h, C.c_void_p(verts.ctypes.data), len(verts), C.c_void_p(idx.ctypes.data), len(idx),
+                                          draws, len(sc.draws), tex, len(sc.textures)))
 
     def pin_screen_trace(self, angle_jitter=0.0, random_offset=0.25, frame_count=0):
         self._check(lib().vkrh_pin_screen_trace(self.h, angle_jitter, random_offset, frame_count))

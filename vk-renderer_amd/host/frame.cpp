@@ -11,6 +11,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "advanced_ssr.hpp"
 #include "defered_shading.hpp"
@@ -46,6 +47,8 @@ struct PostFxFrame {
   SyntheticGbuffer synth;
   ScreenSpaceTrace screen_trace;
   ReadBackSystem readback;
+  std::unique_ptr<scene::CompiledScene> loaded_scene;
+  std::unique_ptr<SceneRenderer> scene_renderer;
 
   DrawTAAParams draw_params{};
   glm::mat4 projection, view, prev_view;
@@ -92,6 +95,10 @@ struct PostFxFrame {
                           gbuffer.downsampled_velocity_vectors);
     }
     if (mask & VKRH_STAGE_GBUFFER) synth.draw_taa(graph, gbuffer, draw_params);
+    if (mask & VKRH_STAGE_RASTER) {  // main.cpp:345
+      if (!scene_renderer) throw std::runtime_error{"vkrh_run: VKRH_STAGE_RASTER without a loaded scene"};
+      scene_renderer->draw_taa(graph, gbuffer, draw_params);
+    }
     if (mask & VKRH_STAGE_DOWNSAMPLE)  // main.cpp:347
       downsample_pass.run(graph, gbuffer.normal, gbuffer.velocity_vectors, gbuffer.depth, gbuffer.downsampled_normals,
                           gbuffer.downsampled_velocity_vectors);
@@ -215,6 +222,32 @@ int vkrh_pin_randoms(void* frame, float jitter, uint32_t gtao_frame_count, uint3
     f->gtao.pin_angle_jitter(jitter);
     f->gtao.set_frame_count(gtao_frame_count);
     f->ssr.set_counter(ssr_counter);
+  });
+}
+int vkrh_load_scene(void* frame, const vkr_raster_vertex* vertices, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
+                    const vkrh_scene_draw* draws, uint32_t draw_count, const vkrh_scene_texture* textures, uint32_t texture_count) {
+  return guarded([&] {
+    auto* f = (PostFxFrame*)frame;
+    if (!f || !vertices || !indices || (!draws && draw_count) || (!textures && texture_count)) throw std::runtime_error{"NULL argument"};
+    std::vector<scene::FlatDraw> flat(draw_count);
+    for (uint32_t i = 0; i < draw_count; i++) {
+      std::memcpy(&flat[i].transform, draws[i].transform, 64);
+      flat[i].vertex_offset = draws[i].vertex_offset; flat[i].index_offset = draws[i].index_offset; flat[i].index_count = draws[i].index_count;
+      flat[i].albedo_tex_index = draws[i].albedo_tex_index; flat[i].metalic_roughness_index = draws[i].metalic_roughness_index;
+      flat[i].clip_alpha = draws[i].clip_alpha != 0;
+    }
+    std::vector<scene::TextureData> tex(texture_count);
+    for (uint32_t i = 0; i < texture_count; i++) {
+      if (textures[i].mip_levels == 0 || textures[i].mip_levels > VKR_MAX_MIPS) throw std::runtime_error{"vkrh_load_scene: bad mip count"};
+      tex[i].width = textures[i].width; tex[i].height = textures[i].height; tex[i].mip_levels = textures[i].mip_levels;
+      for (uint32_t m = 0; m < textures[i].mip_levels; m++) tex[i].levels[m] = textures[i].levels[m];
+    }
+    f->scene_renderer.reset();
+    f->loaded_scene.reset(new scene::CompiledScene(scene::make_scene((const scene::Vertex*)vertices, vertex_count, indices, index_count,
+                                                                     flat.data(), draw_count, tex.data(), texture_count)));
+    f->scene_renderer.reset(new SceneRenderer(*f->loaded_scene));
+    f->scene_renderer->init_pipeline(f->graph, f->gbuffer);  // main.cpp:256-259
+    f->scene_renderer->update_scene();
   });
 }
 int vkrh_pin_screen_trace(void* frame, float angle_jitter, float random_offset, uint32_t frame_count) {

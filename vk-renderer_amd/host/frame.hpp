@@ -44,6 +44,7 @@ enum {
   VKRH_STAGE_SSR_CLASSIFIED     = 1u << 14, /* ssr.run with tile classification + indirect trace (advanced_ssr.cpp:547-550) */
   VKRH_STAGE_SSR_TRACE          = 1u << 15, /* first half of ssr.run: the trace (needs the Hi-Z pyramid)                    */
   VKRH_STAGE_SSR_RESOLVE        = 1u << 16, /* second half of ssr.run: filter + blur (needs albedo at the hit positions)      */
+  VKRH_STAGE_RASTER             = 1u << 17, /* scene_renderer.draw_taa on the loaded scene (main.cpp:345) instead of the generator */
   VKRH_STAGE_CHAIN      = (1u << 3) | (1u << 5) | (1u << 6) | (1u << 7)
 };
 
@@ -60,6 +61,20 @@ const char* vkrh_last_error(void);
 int vkrh_set_camera(void* frame, const vkrh_camera* cam);
 /* pin the host-side randoms of the reference (gtao.cpp:109-111 rand(), advanced_ssr.cpp:168-171 counter) */
 int vkrh_pin_randoms(void* frame, float gtao_angle_jitter, uint32_t gtao_frame_count, uint32_t ssr_counter);
+/* Scene for VKRH_STAGE_RASTER (replaces scene::load_tinygltf_scene, main.cpp:250): draw i renders
+ * indices [index_offset, +index_count) with base vertex vertex_offset under `transform` (16 floats,
+ * glm layout); texture index 0xFFFFFFFF = none.  Textures: RGBA8 mip chains, level 0 first. */
+typedef struct vkrh_scene_draw {
+  float    transform[16];
+  uint32_t vertex_offset, index_offset, index_count;
+  uint32_t albedo_tex_index, metalic_roughness_index, clip_alpha;
+} vkrh_scene_draw;
+typedef struct vkrh_scene_texture {
+  uint32_t width, height, mip_levels, reserved;
+  const uint8_t* levels[16];
+} vkrh_scene_texture;
+int vkrh_load_scene(void* frame, const vkr_raster_vertex* vertices, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
+                    const vkrh_scene_draw* draws, uint32_t draw_count, const vkrh_scene_texture* textures, uint32_t texture_count);
 /* pin ScreenSpaceTrace's per-frame randoms (screen_trace.cpp:49-53) */
 int vkrh_pin_screen_trace(void* frame, float angle_jitter, float random_offset, uint32_t frame_count);
 int vkrh_set_gtao_mode(void* frame, uint32_t use_mis, uint32_t two_directions);

@@ -101,6 +101,14 @@ vkr_img Image::describe_layer(uint32_t layer) const {
   return d;
 }
 
+void Image::upload_mip(uint32_t mip, const void* rows) {
+  if (mip >= info.mip_levels) throw std::runtime_error{"Image upload outside the mip chain"};
+  const uint32_t bpp = vkr_format_bytes(to_vkr_format(info.format));
+  const uint32_t w = mip_dim(info.width, mip), h = mip_dim(info.height, mip);
+  hipError_t e = hipMemcpy2D((uint8_t*)base + offset[mip], pitch[mip], rows, size_t(w) * bpp, size_t(w) * bpp, h, hipMemcpyHostToDevice);
+  if (e != hipSuccess) throw std::runtime_error{std::string{"image upload failed: "} + hipGetErrorString(e)};
+}
+
 Buffer::Buffer(VmaMemoryUsage memory, uint64_t sz, VkBufferUsageFlags usage) : size{sz} {
   dev = device_alloc((sz + 255) & ~uint64_t(255));
   // host shadow: mapped (CPU_TO_GPU) buffers, and uniform buffers — their contents become kernel
@@ -161,6 +169,19 @@ void write_binding(VkDescriptorSet set, const SSBOBinding& b) {
   auto& s = slot_of(set, b.binding);
   s = SetSlot{};
   s.kind = SetSlot::Ssbo; s.buffer = b.buffer;
+}
+
+namespace { std::vector<std::unique_ptr<DescriptorSetObject>> g_long_lived_sets; std::mutex g_set_lock; }
+VkDescriptorSet allocate_descriptor_set(VkDescriptorSetLayout, const std::initializer_list<uint32_t>&) {
+  std::lock_guard<std::mutex> lock{g_set_lock};
+  g_long_lived_sets.emplace_back(new DescriptorSetObject{});
+  return (VkDescriptorSet)g_long_lived_sets.back().get();
+}
+void write_binding(VkDescriptorSet set, const ArrayOfImagesBinding& b) {
+  if (!set) throw std::runtime_error{"write_set: null descriptor set"};
+  auto* obj = (DescriptorSetObject*)set;
+  obj->image_array.clear();
+  for (const auto& it : b.images) obj->image_array.push_back(view_of(it.first));
 }
 
 // ---- program table ----------------------------------------------------------------------------------------
@@ -332,6 +353,42 @@ void register_hot_path_programs() {
                                      (const int32_t*)tiles->device_ptr(st.stream), (const uint32_t*)st.indirect->device_ptr(st.stream),
                                      (uint32_t)(tiles->get_size() / sizeof(int32_t)), push<vkr_trace_indirect_push>(st, P), st.stream);
     });
+    // ---- G-buffer raster stage: gbuf/opaque_taa.{vert,frag} ----
+    // set 0 {0 GbufConst, 1 transforms (pairs of mat4: model, normal)}, set 1 {0 material textures[]}; vertex + index
+    // buffers; one recorded draw_indexed per primitive with PushData {transform, albedo, mr, flags}; attachments
+    // {albedo, normal, material, velocity, depth}, cleared.
+    create_program("gbuf_opaque_taa", [=](LaunchState& st) {
+      const char* P = "gbuf_opaque_taa";
+      if (st.attachments.size() != 5) throw std::runtime_error{"gbuf_opaque_taa: expects 4 colour attachments + depth"};
+      if (!st.cleared_color || !st.cleared_depth) throw std::runtime_error{"gbuf_opaque_taa: attachments must be cleared (colour 0, depth 1)"};
+      if (!st.vertex_buffer || !st.index_buffer) throw std::runtime_error{"gbuf_opaque_taa: vertex / index buffer not bound"};
+      Buffer* transforms = ssbo(st, 1, P);
+      if (!transforms->host_data()) throw std::runtime_error{"gbuf_opaque_taa: the transform buffer must be host-visible on this path"};
+      auto att = [&](size_t i) { return st.attachments[i].image->describe(st.attachments[i].range.base_mip, 1); };
+      vkr_img albedo = att(0), normal = att(1), material = att(2), velocity = att(3), depth = att(4);
+      std::vector<vkr_img> textures;
+      if (st.set1)
+        for (const auto& v : st.set1->image_array) textures.push_back(v.image->describe(v.range.base_mip, v.range.mips_count));
+      std::vector<vkr_raster_draw> draws;
+      for (const auto& d : st.indexed_draws) {
+        if (d.push.size() < 16) throw std::runtime_error{"gbuf_opaque_taa: push constants missing"};
+        vkr_raster_draw r{};
+        std::memcpy(&r, d.push.data(), 16);
+        r.index_offset = d.first_index; r.index_count = d.index_count; r.vertex_offset = (uint32_t)d.vertex_offset;
+        draws.push_back(r);
+      }
+      vkr_raster_scene scene{};
+      scene.vertices = (const vkr_raster_vertex*)st.vertex_buffer->device_ptr(st.stream);
+      scene.vertex_count = (uint32_t)(st.vertex_buffer->get_size() / sizeof(vkr_raster_vertex));
+      scene.indices = (const uint32_t*)st.index_buffer->device_ptr(st.stream);
+      scene.index_count = (uint32_t)(st.index_buffer->get_size() / sizeof(uint32_t));
+      scene.transforms = (const vkr_raster_transform*)transforms->host_data();
+      scene.transform_count = (uint32_t)(transforms->get_size() / sizeof(vkr_raster_transform));
+      scene.draws = draws.data(); scene.draw_count = (uint32_t)draws.size();
+      scene.textures = textures.data(); scene.texture_count = (uint32_t)textures.size();
+      return vkr_raster_gbuffer(&scene, ubo<vkr_gbuf_const>(st, 0, P), &albedo, &normal, &material, &velocity, &depth,
+                                st.scratch, st.scratch_bytes, st.stream);
+    });
     // ---- dormant GTAO variants ----
     // gtao/main.frag: set {0 depth, 1 GTAOParams, 2 normal}; colour attachment raw
     create_program("gtao_main", [=](LaunchState& st) {
@@ -429,8 +486,48 @@ void CmdContext::bind_pipeline(const GraphicsPipeline& p) {
   bound_program = p.program_name();
 }
 void CmdContext::bind_sets(uint32_t first_set, const std::initializer_list<VkDescriptorSet>& s) {
-  if (first_set != 0 || s.size() != 1) throw std::runtime_error{"Only descriptor set 0 is used on this path"};
-  state.set = (const DescriptorSetObject*)*s.begin();
+  if (first_set > 1 || s.size() != 1) throw std::runtime_error{"Only descriptor sets 0 and 1 are used on this path"};
+  (first_set == 0 ? state.set : state.set1) = (const DescriptorSetObject*)*s.begin();
+}
+CmdContext::~CmdContext() { device_free(state.scratch); }
+void* CmdContext::require_scratch(uint64_t bytes) {
+  if (bytes > state.scratch_bytes) {
+    if (state.scratch) { (void)hipStreamSynchronize((hipStream_t)stream); device_free(state.scratch); }
+    state.scratch = device_alloc(bytes);
+    state.scratch_bytes = bytes;
+  }
+  return state.scratch;
+}
+void CmdContext::clear_color_attachments(float r, float g, float b, float a) {
+  if (r != 0.f || g != 0.f || b != 0.f || a != 0.f) throw std::runtime_error{"Only a clear to 0 is implemented on this path"};
+  state.cleared_color = true;
+}
+void CmdContext::clear_depth_attachment(float depth) {
+  if (depth != 1.f) throw std::runtime_error{"Only a depth clear to 1 is implemented on this path"};
+  state.cleared_depth = true;
+}
+void CmdContext::bind_vertex_buffers(uint32_t first, const std::initializer_list<VkBuffer>& buffers, const std::initializer_list<uint64_t>& offsets) {
+  if (first != 0 || buffers.size() != 1 || (offsets.size() && *offsets.begin() != 0)) throw std::runtime_error{"One vertex buffer at offset 0 is implemented on this path"};
+  state.vertex_buffer = (Buffer*)*buffers.begin();
+}
+void CmdContext::bind_index_buffer(VkBuffer buffer, uint64_t offset, VkIndexType type) {
+  if (offset != 0 || type != VK_INDEX_TYPE_UINT32) throw std::runtime_error{"A uint32 index buffer at offset 0 is implemented on this path"};
+  state.index_buffer = (Buffer*)buffer;
+}
+void CmdContext::draw_indexed(uint32_t index_count, uint32_t instance_count, uint32_t first_index, int32_t vertex_offset, uint32_t) {
+  if (instance_count != 1) throw std::runtime_error{"Instanced draws are not implemented on this path"};
+  state.indexed_draws.push_back(LaunchState::IndexedDraw{push_data, index_count, first_index, vertex_offset});
+}
+void CmdContext::end_renderpass() {
+  if (!state.indexed_draws.empty()) {  // the recorded geometry is one pass of the bound raster program
+    require_scratch(vkr_raster_scratch_bytes(state.fb_width, state.fb_height));
+    launch();
+  }
+  state.indexed_draws.clear();
+  state.attachments.clear();
+  state.set1 = nullptr;
+  state.vertex_buffer = state.index_buffer = nullptr;
+  state.cleared_color = state.cleared_depth = false;
 }
 void CmdContext::push_constants_compute(uint32_t offset, uint32_t size, const void* constants) {
   if (push_data.size() < offset + size) push_data.resize(offset + size);

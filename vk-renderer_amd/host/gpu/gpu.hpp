@@ -75,6 +75,8 @@ struct Image {
   vkr_img describe(uint32_t base_mip, uint32_t count) const;
   // one layer of a (single-mip) array image
   vkr_img describe_layer(uint32_t layer) const;
+  // tightly packed rows of one mip -> device (asset upload; synchronous)
+  void upload_mip(uint32_t mip, const void* rows);
 
  private:
   ImageInfo info;
@@ -145,7 +147,17 @@ struct SetSlot {
   uint64_t host_size = 0;
   BufferPtr buffer;                 // UBO / SSBO living in a device buffer
 };
-struct DescriptorSetObject { std::array<SetSlot, 16> slots; };
+struct DescriptorSetObject {
+  std::array<SetSlot, 16> slots;
+  std::vector<ImageViewObject> image_array;  // ArrayOfImagesBinding (bindless material textures)
+};
+// gpu/descriptors.hpp: a long-lived set outside the per-frame pool (scene_renderer.cpp:98)
+VkDescriptorSet allocate_descriptor_set(VkDescriptorSetLayout layout, const std::initializer_list<uint32_t>& variable_counts);
+struct ArrayOfImagesBinding {
+  uint32_t binding;
+  const std::vector<std::pair<VkImageView, VkSampler>>& images;
+};
+void write_binding(VkDescriptorSet set, const ArrayOfImagesBinding& b);
 
 struct BaseBinding { uint32_t binding; };
 struct TextureBinding : BaseBinding {  // gpu/descriptors.hpp:89-101
@@ -182,6 +194,15 @@ struct LaunchState {
   uint32_t fb_width = 0, fb_height = 0;
   std::vector<ImageViewObject> attachments;  // graphics programs: colour..., depth last
   Buffer* indirect = nullptr;                // dispatch_indirect: VkDispatchIndirectCommand on the device
+  // indexed geometry recorded between set_framebuffer and end_renderpass (raster programs)
+  struct IndexedDraw { std::vector<uint8_t> push; uint32_t index_count, first_index; int32_t vertex_offset; };
+  std::vector<IndexedDraw> indexed_draws;
+  const DescriptorSetObject* set1 = nullptr;  // descriptor set 1 (bindless textures)
+  Buffer* vertex_buffer = nullptr;
+  Buffer* index_buffer = nullptr;
+  bool cleared_color = false, cleared_depth = false;
+  void* scratch = nullptr;                    // device scratch owned by the command context
+  uint64_t scratch_bytes = 0;
   void* stream = nullptr;
 };
 using ProgramFn = std::function<int(LaunchState&)>;
@@ -236,7 +257,16 @@ struct CmdContext {
   void set_framebuffer(uint32_t width, uint32_t height, const std::vector<ImageViewObject>& attachments);
   void bind_viewport(float, float, float, float, float, float) {}
   void bind_scissors(int32_t, int32_t, uint32_t, uint32_t) {}
-  void end_renderpass() { state.attachments.clear(); }
+  void end_renderpass();
+  void clear_color_attachments(float r, float g, float b, float a);
+  void clear_depth_attachment(float depth);
+  void bind_vertex_buffers(uint32_t first, const std::initializer_list<VkBuffer>& buffers, const std::initializer_list<uint64_t>& offsets);
+  void bind_index_buffer(VkBuffer buffer, uint64_t offset, VkIndexType type);
+  // recorded, executed as one pass by end_renderpass()
+  void draw_indexed(uint32_t index_count, uint32_t instance_count, uint32_t first_index, int32_t vertex_offset, uint32_t first_instance);
+  // grows the context's device scratch (raster visibility buffer)
+  void* require_scratch(uint64_t bytes);
+  ~CmdContext();
   void dispatch(uint32_t groups_x, uint32_t groups_y, uint32_t groups_z);
   void draw(uint32_t vertex_count, uint32_t instance_count, uint32_t first_vertex, uint32_t first_instance);
   // group counts come from a device buffer; the program bounds its launch itself (no host read-back)

@@ -1,13 +1,16 @@
 // scene_renderer.hpp — the G-buffer resource set and the per-frame camera block every hot-path
 // pass consumes.  Mirrors `Gbuffer` (src/scene_renderer.hpp:11-24, ctor scene_renderer.cpp:8-44)
-// and `DrawTAAParams` (scene_renderer.hpp:26-33).  The raster stage that fills the G-buffer in the
-// reference (SceneRenderer::draw_taa) is replaced by SyntheticGbuffer (synthetic_gbuffer.hpp).
+// and `DrawTAAParams` (scene_renderer.hpp:26-33), and `SceneRenderer` (scene_renderer.hpp:35-65): the raster
+// stage that fills the G-buffer (draw_taa, scene_renderer.cpp:140-220) over the compute rasterizer bound
+// as program "gbuf_opaque_taa".  SyntheticGbuffer (synthetic_gbuffer.hpp) fills the same attachments
+// without geometry for the benchmark.
 #ifndef SCENE_RENDERER_HPP_INCLUDED
 #define SCENE_RENDERER_HPP_INCLUDED
 
 #include "glm_compat.hpp"
 #include "gpu/gpu.hpp"
 #include "rendergraph/rendergraph.hpp"
+#include "scene.hpp"
 
 struct Gbuffer {
   Gbuffer(rendergraph::RenderGraph &graph, uint32_t width, uint32_t height);
@@ -41,6 +44,33 @@ struct DrawTAAParams {
   glm::mat4 prev_camera;
   glm::vec4 jitter;
   glm::vec4 fovy_aspect_znear_zfar;
+};
+
+struct SceneRenderer {
+  SceneRenderer(scene::CompiledScene &s) : target {s} {}
+
+  void init_pipeline(rendergraph::RenderGraph &graph, const Gbuffer &buffer);
+  void update_scene();
+  void draw_taa(rendergraph::RenderGraph &graph, const Gbuffer &gbuffer, const DrawTAAParams &params);
+
+  struct DrawCall {
+    uint32_t transform;
+    uint32_t mesh;
+  };
+
+  const std::vector<DrawCall> &get_drawcalls() const { return draw_calls; }
+  rendergraph::BufferResourceId get_scene_transforms() const { return transform_buffer; }
+
+private:
+  scene::CompiledScene &target;
+  rendergraph::RenderGraph *owner = nullptr;
+  gpu::GraphicsPipeline opaque_taa_pipeline;
+  VkSampler sampler;
+  rendergraph::BufferResourceId transform_buffer;
+  VkDescriptorSet bindless_textures {nullptr};
+  std::vector<std::unique_ptr<gpu::ImageViewObject>> texture_views;
+  std::vector<std::pair<VkImageView, VkSampler>> scene_textures;
+  std::vector<DrawCall> draw_calls;
 };
 
 #endif

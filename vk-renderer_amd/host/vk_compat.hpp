@@ -48,6 +48,7 @@ struct VkSamplerCreateInfo {
   VkSamplerAddressMode addressModeU, addressModeV, addressModeW;
   float minLod, maxLod;
 };
+enum VkIndexType { VK_INDEX_TYPE_UINT16 = 0, VK_INDEX_TYPE_UINT32 = 1 };
 struct VkDispatchIndirectCommand { uint32_t x, y, z; };
 typedef struct VkBuffer_T* VkBuffer;
 typedef struct VkSampler_T* VkSampler;
