@@ -35,6 +35,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # Algorithmic bytes per FULL-RES pixel of each task: surface-compulsory model of SURVEY.md 8(d)
 # (every input surface read once, every output written once, at storage-format size).
 BYTES_PER_PX = {
+    "GbufferPass": 20.0,  # --raster only: five 4-byte attachments written once (geometry / textures excluded)
     "DeferedShading": 23.0,
     "DownsampleGbuffer": 15.0,
     "DownsampleDepth": 1.667,  # the whole chain mips 2..L-1 (one task, two launches)
@@ -95,6 +96,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--raster", action="store_true",
+                    help="N=1 only: the G-buffer comes from the raster stage (procedural mesh scene, SceneRenderer::draw_taa) "
+                         "and GbufferPass is part of every timed step")
     ap.add_argument("--rehearse-tiled", action="store_true",
                     help="N=1 only: run the multi-GPU code path (RCCL gathers, staged frame) on a one-rank group")
     ap.add_argument("--tile", type=str, default=f"{TILE_W}x{TILE_H}", help="per-GPU tile, WxH")
@@ -153,6 +157,22 @@ def main():
     if args.shading or args.config == "c5":
         frame.run(host.STAGE_BRDF_LUT)
 
+    if args.raster:
+        if world != 1 or args.rehearse_tiled:
+            raise SystemExit("--raster is a single-GPU option")
+        from vk_renderer_amd import scene as scn
+
+        frame.load_scene(scn.procedural_scene(detail=96))  # 5 draws, 37k triangles
+        frame.run(host.STAGE_LUT)
+        frame.set_camera(setup.prev_view, setup.prev_view, setup.proj, setup.fazz)
+        frame.run(host.STAGE_RASTER | host.STAGE_DOWNSAMPLE)
+        frame.end_frame(swap_depth=True)  # the previous camera's depth + Hi-Z become prev_depth (main.cpp:416)
+        frame.set_camera(setup.view, setup.prev_view, setup.proj, setup.fazz)
+        frame.run(host.STAGE_RASTER)
+        tiled._seed_histories_gpu()
+        tiled.backend.sync()
+        tiled.stage_plan = [host.STAGE_RASTER | (tiled.stage_plan[0] if tiled.stage_plan else host.STAGE_CHAIN)]
+        tiled.prepare = lambda: None
     tiled.prepare()  # LUT, G-buffer (tile + halo), prev depth, histories
     if args.config == "c1":
         frame.run(host.STAGE_DOWNSAMPLE)  # GTAO reads depth mip 1; built once, outside the timed pass
@@ -222,6 +242,7 @@ def main():
                 "tile_per_gpu": [tw, th],
                 "grid": [cols, rows],
                 "halo_px": tiled.halo,
+                "gbuffer": "rasterised procedural mesh scene (GbufferPass timed)" if args.raster else "analytic generator (not timed)",
             },
             "roofline": {
                 "bound": "hbm",

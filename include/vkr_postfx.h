@@ -364,8 +364,9 @@ int vkr_screen_trace_accumulate(const vkr_img* depth, const vkr_img* prev_depth,
  * (perspective-correct attributes, trilinear sRGB textures, octahedral normal, velocity).  Frozen
  * raster rules: pixel centres, top-left fill rule, 8 sub-pixel bits, cull none, depth LESS_OR_EQUAL
  * in D24 (gpu/pipelines.hpp:113-128), near-plane clipping in clip space, implicit LOD from forward
- * differences of the interpolated uv.  `scratch`: vkr_raster_scratch_bytes() of device memory.      */
-uint64_t vkr_raster_scratch_bytes(uint32_t width, uint32_t height);
+ * differences of the interpolated uv.  `scratch`: vkr_raster_scratch_bytes() of device memory (the
+ * visibility buffer + two records per drawn triangle).                           */
+uint64_t vkr_raster_scratch_bytes(uint32_t width, uint32_t height, uint32_t triangle_count /* summed over all draws */);
 int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_const* consts, const vkr_img* albedo,
                        const vkr_img* normal, const vkr_img* material, const vkr_img* velocity, const vkr_img* depth,
                        void* scratch, uint64_t scratch_bytes, void* stream);

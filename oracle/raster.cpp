@@ -83,7 +83,7 @@ vec4 sample_trilinear(const Image& t, vec2 uv, vec2 duvdx, vec2 duvdy) {
 
 }  // namespace
 
-extern "C" uint64_t vkr_ref_raster_scratch_bytes(uint32_t, uint32_t) { return 0; }
+extern "C" uint64_t vkr_ref_raster_scratch_bytes(uint32_t, uint32_t, uint32_t) { return 0; }
 
 extern "C" int vkr_ref_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_const* consts, const vkr_img* albedo,
                                       const vkr_img* normal, const vkr_img* material, const vkr_img* velocity, const vkr_img* depth,

@@ -252,7 +252,7 @@ def product():
             fn.restype = C.c_int
         lib.vkr_stream_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.vkr_stream_read.restype = C.c_int
-        lib.vkr_raster_scratch_bytes.argtypes = [C.c_uint32, C.c_uint32]
+        lib.vkr_raster_scratch_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         lib.vkr_raster_scratch_bytes.restype = C.c_uint64
         lib.vkr_halton23_fill.argtypes = [C.c_void_p, C.c_uint32]
         lib.vkr_halton23_fill.restype = None

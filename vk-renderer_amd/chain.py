@@ -177,7 +177,7 @@ class PostFxChain:
             import torch
 
             W, H = self.albedo.full
-            nbytes = int(self.lib.vkr_raster_scratch_bytes(W, H))
+            nbytes = int(self.lib.vkr_raster_scratch_bytes(W, H, sum(d["index_count"] // 3 for d in scene.draws)))
             if getattr(self, "_raster_scratch", None) is None or self._raster_scratch.numel() < nbytes:
                 self._raster_scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             scratch_ptr = C.c_void_p(self._raster_scratch.data_ptr())

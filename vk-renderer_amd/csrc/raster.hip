@@ -3,12 +3,17 @@
 // compute rasterizer.
 //
 //   k_raster_clear    visibility buffer := empty
-//   k_raster_tris     one wave per triangle: vertex shader on its three corners, near-plane clip, 8-bit
-//                     sub-pixel snap, bounding box walked in 8x8 pixel blocks (one pixel per lane), fill
-//                     rule on exact 64-bit edge functions, D24 depth, atomicMin of (depth << 32 | ~triangle)
-//                     — LESS_OR_EQUAL with later triangles winning ties (gpu/pipelines.hpp:128)
-//   k_raster_resolve  one thread per pixel: re-derives the winning triangle, perspective-correct
-//                     attributes, implicit LOD from forward differences, trilinear sRGB fetches, stores
+//   k_raster_setup    one thread per triangle: vertex shader on its three corners, near-plane clip (up to
+//                     two sub-triangles), 8-bit sub-pixel snap, orientation -> ScreenTri records in scratch
+//                     in scratch; records whose bounding box exceeds 64 blocks of 8x8 pixels go to a work list
+//   k_raster_small    one wave per triangle walks the (<= 64) blocks of its bounding box, one pixel per lane
+//   k_raster_large    the listed triangles: 256 waves share the blocks of one triangle (a screen-filling quad
+//                     does not serialise on one wave)
+//                     both: fill rule on exact 64-bit edge functions of 24.8 coordinates, D24 depth, atomicMin
+//                     of (depth << 32 | ~record) — LESS_OR_EQUAL with later triangles winning ties
+//                     (gpu/pipelines.hpp:128)
+//   k_raster_resolve  one thread per pixel: the winning triangle's record, perspective-correct attributes,
+//                     implicit LOD from forward differences, trilinear sRGB fetches, stores
 //
 // Coverage and depth are integer-exact functions of the snapped vertices, so they are bit-equal to
 // the oracle's immediate-mode rasterizer; colour / normal / velocity follow the frozen fp32 contract.
@@ -33,6 +38,7 @@ struct RasterArgs {
   const DrawDev* draws;
   uint32_t draw_count;
   unsigned long long* vis;
+  struct ScreenTri* setup;  // [2 * total triangles]: sub-triangle records written by k_raster_setup
   int width, height;  // framebuffer = whole frame
   float jitter_x, jitter_y;
 };
@@ -66,19 +72,20 @@ VKR_DEV VsOut vs_lerp(const VsOut& p, const VsOut& q, float t) {  // p + t (q - 
 
 // A triangle ready for rasterisation: snapped screen positions (8 sub-pixel bits), 1/w-space data
 struct ScreenTri {
-  long long x[3], y[3];
+  int x[3], y[3];  // 24.8 fixed point, |v| <= 2^28 (guard band)
   float w[3], z[3];  // clip w and z / w
   long long area2;
   VsOut v[3];
   bool valid;
 };
 
-VKR_DEV long long edge_fn(long long ax, long long ay, long long bx, long long by, long long px, long long py) {
-  return (bx - ax) * (py - ay) - (by - ay) * (px - ax);
+// differences of 24.8 coordinates fit 32 bits, their products need 64 (v_mad_i64_i32)
+VKR_DEV long long edge_fn(int ax, int ay, int bx, int by, int px, int py) {
+  return (long long)(bx - ax) * (long long)(py - ay) - (long long)(by - ay) * (long long)(px - ax);
 }
 // top-left rule for an edge a->b of a triangle with positive area2 under edge_fn (y down)
-VKR_DEV bool is_top_left(long long ax, long long ay, long long bx, long long by) {
-  const long long dx = bx - ax, dy = by - ay;
+VKR_DEV bool is_top_left(int ax, int ay, int bx, int by) {
+  const int dx = bx - ax, dy = by - ay;
   return dy < 0 || (dy == 0 && dx > 0);
 }
 
@@ -111,8 +118,8 @@ VKR_DEV ScreenTri setup_triangle(const RasterArgs& a, const DrawDev& d, uint32_t
     const float xs = ((p.x / p.w) * 0.5f + 0.5f) * (float)a.width;
     const float ys = ((p.y / p.w) * 0.5f + 0.5f) * (float)a.height;
     if (!(fabsf(xs) <= RASTER_GUARD_PX && fabsf(ys) <= RASTER_GUARD_PX)) return t;
-    t.x[k] = (long long)rintf(xs * 256.0f);
-    t.y[k] = (long long)rintf(ys * 256.0f);
+    t.x[k] = (int)rintf(xs * 256.0f);
+    t.y[k] = (int)rintf(ys * 256.0f);
     t.w[k] = p.w;
     t.z[k] = p.z / p.w;
   }
@@ -120,7 +127,7 @@ VKR_DEV ScreenTri setup_triangle(const RasterArgs& a, const DrawDev& d, uint32_t
   if (t.area2 == 0) return t;
   if (t.area2 < 0) {  // cull none: both windings are drawn; normalise the orientation
     const VsOut tv = t.v[1]; t.v[1] = t.v[2]; t.v[2] = tv;
-    long long tl = t.x[1]; t.x[1] = t.x[2]; t.x[2] = tl;
+    int tl = t.x[1]; t.x[1] = t.x[2]; t.x[2] = tl;
     tl = t.y[1]; t.y[1] = t.y[2]; t.y[2] = tl;
     float tf = t.w[1]; t.w[1] = t.w[2]; t.w[2] = tf;
     tf = t.z[1]; t.z[1] = t.z[2]; t.z[2] = tf;
@@ -132,7 +139,7 @@ VKR_DEV ScreenTri setup_triangle(const RasterArgs& a, const DrawDev& d, uint32_t
 
 // coverage + depth of pixel (px, py); lambda: screen-space barycentrics
 VKR_DEV bool cover(const ScreenTri& t, int px, int py, float lambda[3], uint32_t* d24) {
-  const long long X = ((long long)px << 8) + 128, Y = ((long long)py << 8) + 128;
+  const int X = (px << 8) + 128, Y = (py << 8) + 128;
   const long long e0 = edge_fn(t.x[1], t.y[1], t.x[2], t.y[2], X, Y);
   const long long e1 = edge_fn(t.x[2], t.y[2], t.x[0], t.y[0], X, Y);
   const long long e2 = edge_fn(t.x[0], t.y[0], t.x[1], t.y[1], X, Y);
@@ -151,7 +158,7 @@ VKR_DEV bool cover(const ScreenTri& t, int px, int py, float lambda[3], uint32_t
 }
 // barycentrics at an arbitrary (possibly uncovered) pixel, for the forward differences of uv
 VKR_DEV void lambda_at(const ScreenTri& t, int px, int py, float lambda[3]) {
-  const long long X = ((long long)px << 8) + 128, Y = ((long long)py << 8) + 128;
+  const int X = (px << 8) + 128, Y = (py << 8) + 128;
   const double inv = 1.0 / (double)t.area2;
   lambda[0] = (float)((double)edge_fn(t.x[1], t.y[1], t.x[2], t.y[2], X, Y) * inv);
   lambda[1] = (float)((double)edge_fn(t.x[2], t.y[2], t.x[0], t.y[0], X, Y) * inv);
@@ -169,34 +176,77 @@ __global__ void k_raster_clear(unsigned long long* vis, size_t n) {
   if (i < n) vis[i] = ~0ull;
 }
 
-// one wave per triangle
-__global__ __launch_bounds__(256) void k_raster_tris(RasterArgs a, uint32_t draw_index) {
+// pixel bounding box (centres that can be covered), clipped to the viewport; false when empty
+VKR_DEV bool tri_bbox(const ScreenTri& t, int width, int height, int* x0, int* y0, int* x1, int* y1) {
+  const int minx = min(t.x[0], min(t.x[1], t.x[2])), maxx = max(t.x[0], max(t.x[1], t.x[2]));
+  const int miny = min(t.y[0], min(t.y[1], t.y[2])), maxy = max(t.y[0], max(t.y[1], t.y[2]));
+  *x0 = max((minx - 128) >> 8, 0); *x1 = min((maxx - 128) >> 8, width - 1);
+  *y0 = max((miny - 128) >> 8, 0); *y1 = min((maxy - 128) >> 8, height - 1);
+  return *x0 <= *x1 && *y0 <= *y1;
+}
+#define RASTER_SMALL_BLOCKS 64  // sub-triangles whose bounding box has more 8x8 blocks go to the shared-work kernel
+#define RASTER_LARGE_GRID_X 128
+#define RASTER_LARGE_GRID_Y 64
+
+// one thread per triangle; large sub-triangles are appended to `large_list` (record index), counted in large_count
+__global__ __launch_bounds__(256) void k_raster_setup(RasterArgs a, uint32_t draw_index, uint32_t* large_count, uint32_t* large_list) {
   const DrawDev d = a.draws[draw_index];
-  const uint32_t tri = blockIdx.x * 4u + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  const uint32_t tri = blockIdx.x * blockDim.x + threadIdx.x;
   if (tri >= d.tri_count) return;
   for (int sub = 0; sub < 2; sub++) {
     int count;
-    const ScreenTri t = setup_triangle(a, d, tri, sub, &count);
-    if (sub >= count) break;
-    if (!t.valid) continue;
-    // bounding box in pixels whose centres can be covered
-    long long minx = min(t.x[0], min(t.x[1], t.x[2])), maxx = max(t.x[0], max(t.x[1], t.x[2]));
-    long long miny = min(t.y[0], min(t.y[1], t.y[2])), maxy = max(t.y[0], max(t.y[1], t.y[2]));
-    int x0 = (int)max((minx - 128) >> 8, 0ll), x1 = (int)min((maxx - 128) >> 8, (long long)a.width - 1);
-    int y0 = (int)max((miny - 128) >> 8, 0ll), y1 = (int)min((maxy - 128) >> 8, (long long)a.height - 1);
-    if (x0 > x1 || y0 > y1) continue;
-    const unsigned long long id = 0xFFFFFFFFull - (unsigned long long)((d.tri_base + tri) * 2u + (uint32_t)sub);
-    for (int by = y0 & ~7; by <= y1; by += 8) {
-      for (int bx = x0 & ~7; bx <= x1; bx += 8) {
-        const int px = bx + (lane & 7), py = by + (lane >> 3);
-        if (px < x0 || px > x1 || py < y0 || py > y1) continue;
-        float lambda[3];
-        uint32_t d24;
-        if (!cover(t, px, py, lambda, &d24)) continue;
-        atomicMin(&a.vis[(size_t)py * a.width + px], ((unsigned long long)d24 << 32) | id);
-      }
+    ScreenTri t = setup_triangle(a, d, tri, sub, &count);
+    if (sub >= count) t.valid = false;
+    const uint32_t rec = (d.tri_base + tri) * 2u + (uint32_t)sub;
+    a.setup[rec] = t;
+    int x0, y0, x1, y1;
+    if (t.valid && tri_bbox(t, a.width, a.height, &x0, &y0, &x1, &y1)) {
+      const int nb = ((x1 >> 3) - (x0 >> 3) + 1) * ((y1 >> 3) - (y0 >> 3) + 1);
+      if (nb > RASTER_SMALL_BLOCKS) large_list[atomicAdd(large_count, 1u)] = rec;
     }
+  }
+}
+
+// 8x8 pixel block `b` (row-major inside the bounding box) of record `rec`, one pixel per lane
+VKR_DEV void raster_block(const RasterArgs& a, const ScreenTri& t, uint32_t rec, int x0, int y0, int x1, int y1, int b, int lane) {
+  const int bw = (x1 >> 3) - (x0 >> 3) + 1;
+  const int px = (((x0 >> 3) + b % bw) << 3) + (lane & 7), py = (((y0 >> 3) + b / bw) << 3) + (lane >> 3);
+  if (px < x0 || px > x1 || py < y0 || py > y1) return;
+  float lambda[3];
+  uint32_t d24;
+  if (!cover(t, px, py, lambda, &d24)) return;
+  atomicMin(&a.vis[(size_t)py * a.width + px], ((unsigned long long)d24 << 32) | (0xFFFFFFFFull - (unsigned long long)rec));
+}
+
+// small triangles: one wave per triangle walks its (at most 64) blocks
+__global__ __launch_bounds__(256) void k_raster_small(RasterArgs a, uint32_t draw_index) {
+  const DrawDev& d = a.draws[draw_index];
+  const uint32_t tri = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (tri >= d.tri_count) return;
+  for (uint32_t sub = 0; sub < 2; sub++) {
+    const uint32_t rec = (d.tri_base + tri) * 2u + sub;
+    const ScreenTri& t = a.setup[rec];
+    int x0, y0, x1, y1;
+    if (!t.valid || !tri_bbox(t, a.width, a.height, &x0, &y0, &x1, &y1)) continue;
+    const int nb = ((x1 >> 3) - (x0 >> 3) + 1) * ((y1 >> 3) - (y0 >> 3) + 1);
+    if (nb > RASTER_SMALL_BLOCKS) continue;
+    for (int b = 0; b < nb; b++) raster_block(a, t, rec, x0, y0, x1, y1, b, lane);
+  }
+}
+
+// large triangles: blockIdx.x strides the list, the 4 * gridDim.y waves of a column share one triangle's blocks
+__global__ __launch_bounds__(256) void k_raster_large(RasterArgs a, const uint32_t* large_count, const uint32_t* large_list) {
+  const uint32_t n = *large_count;
+  const int lane = threadIdx.x & 63;
+  const int slice = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6), slices = (int)gridDim.y * 4;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint32_t rec = large_list[i];
+    const ScreenTri& t = a.setup[rec];
+    int x0, y0, x1, y1;
+    if (!tri_bbox(t, a.width, a.height, &x0, &y0, &x1, &y1)) continue;
+    const int nb = ((x1 >> 3) - (x0 >> 3) + 1) * ((y1 >> 3) - (y0 >> 3) + 1);
+    for (int b = slice; b < nb; b += slices) raster_block(a, t, rec, x0, y0, x1, y1, b, lane);
   }
 }
 
@@ -250,12 +300,10 @@ __global__ __launch_bounds__(256) void k_raster_resolve(ResolveArgs a) {
   if (key != ~0ull) {
     const uint32_t gid2 = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
     const uint32_t gid = gid2 >> 1;
-    const int sub = (int)(gid2 & 1u);
     uint32_t di = 0;
     while (di + 1 < a.r.draw_count && gid >= a.r.draws[di + 1].tri_base) di++;
-    const DrawDev d = a.r.draws[di];
-    int count;
-    const ScreenTri t = setup_triangle(a.r, d, gid - d.tri_base, sub, &count);
+    const DrawDev& d = a.r.draws[di];
+    const ScreenTri& t = a.r.setup[gid2];
     float lambda[3], b[3];
     uint32_t d24 = 0;
     cover(t, px, py, lambda, &d24);
@@ -309,8 +357,9 @@ using namespace vkr;
 
 static uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
-extern "C" uint64_t vkr_raster_scratch_bytes(uint32_t width, uint32_t height) {
-  return align_up((uint64_t)width * height * 8u, 256) + align_up(sizeof(DrawDev) * 1024u, 256);
+extern "C" uint64_t vkr_raster_scratch_bytes(uint32_t width, uint32_t height, uint32_t triangle_count) {
+  return align_up((uint64_t)width * height * 8u, 256) + align_up(sizeof(DrawDev) * 1024u, 256) +
+         align_up(sizeof(ScreenTri) * 2u * (uint64_t)triangle_count, 256) + align_up(4u * (2u * (uint64_t)triangle_count + 64u), 256);
 }
 
 extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_const* consts, const vkr_img* albedo,
@@ -334,7 +383,10 @@ extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_
     return VKR_ERR_EXTENT;
   }
   const int W = ra.albedo.fw, H = ra.albedo.fh;
-  if (scratch_bytes < vkr_raster_scratch_bytes((uint32_t)W, (uint32_t)H)) { set_error("gbuf_opaque_taa: scratch too small"); return VKR_ERR_EXTENT; }
+  uint64_t total_tris = 0;
+  for (uint32_t i = 0; i < scene->draw_count; i++) total_tris += scene->draws[i].index_count / 3u;
+  if (total_tris >= 0x7FFFFFFFull) { set_error("gbuf_opaque_taa: too many triangles"); return VKR_ERR_EXTENT; }
+  if (scratch_bytes < vkr_raster_scratch_bytes((uint32_t)W, (uint32_t)H, (uint32_t)total_tris)) { set_error("gbuf_opaque_taa: scratch too small"); return VKR_ERR_EXTENT; }
   for (uint32_t i = 0; i < scene->texture_count; i++) {
     const vkr_img& t = scene->textures[i];
     if (t.mip_count < 1 || t.mip_count > VKR_MAX_MIPS) { set_error("gbuf_opaque_taa: texture %u: bad mip count", i); return VKR_ERR_MIPS; }
@@ -367,6 +419,9 @@ extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_
   r.vertices = scene->vertices; r.indices = scene->indices;
   r.vis = (unsigned long long*)scratch;
   r.draws = (const DrawDev*)((uint8_t*)scratch + align_up((uint64_t)W * H * 8u, 256));
+  r.setup = (ScreenTri*)((uint8_t*)r.draws + align_up(sizeof(DrawDev) * 1024u, 256));
+  uint32_t* large_count = (uint32_t*)((uint8_t*)r.setup + align_up(sizeof(ScreenTri) * 2u * total_tris, 256));
+  uint32_t* large_list = large_count + 64;
   r.draw_count = scene->draw_count;
   r.width = W; r.height = H;
   r.jitter_x = consts->jitter[0]; r.jitter_y = consts->jitter[1];
@@ -377,8 +432,17 @@ extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_
   }
   const size_t npx = (size_t)W * H;
   hipLaunchKernelGGL(k_raster_clear, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, r.vis, npx);
-  for (uint32_t i = 0; i < scene->draw_count; i++)
-    if (draws[i].tri_count) hipLaunchKernelGGL(k_raster_tris, dim3((draws[i].tri_count + 3) / 4), dim3(256), 0, stream, r, i);
+  {
+    hipError_t e = hipMemsetAsync(large_count, 0, 256, stream);
+    if (e != hipSuccess) { set_error("gbuf_opaque_taa: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  for (uint32_t i = 0; i < scene->draw_count; i++) {
+    if (!draws[i].tri_count) continue;
+    hipLaunchKernelGGL(k_raster_setup, dim3((draws[i].tri_count + 255) / 256), dim3(256), 0, stream, r, i, large_count, large_list);
+    hipLaunchKernelGGL(k_raster_small, dim3((draws[i].tri_count + 3) / 4), dim3(256), 0, stream, r, i);
+  }
+  // every draw's large triangles in one launch: submission order is carried by the record index in the key
+  hipLaunchKernelGGL(k_raster_large, dim3(RASTER_LARGE_GRID_X, RASTER_LARGE_GRID_Y), dim3(256), 0, stream, r, large_count, large_list);
   ra.r = r;
   dim3 block(64, 4);
   hipLaunchKernelGGL(k_raster_resolve, grid2d(ra.albedo.w, ra.albedo.h, block), block, 0, stream, ra);

@@ -520,7 +520,9 @@ void CmdContext::draw_indexed(uint32_t index_count, uint32_t instance_count, uin
 }
 void CmdContext::end_renderpass() {
   if (!state.indexed_draws.empty()) {  // the recorded geometry is one pass of the bound raster program
-    require_scratch(vkr_raster_scratch_bytes(state.fb_width, state.fb_height));
+    uint32_t triangles = 0;
+    for (const auto& d : state.indexed_draws) triangles += d.index_count / 3u;
+    require_scratch(vkr_raster_scratch_bytes(state.fb_width, state.fb_height, triangles));
     launch();
   }
   state.indexed_draws.clear();
