@@ -423,3 +423,119 @@ def test_tile_classification_partition(oracle_lib):
     assert prev_reflective == total
     c.ssr_classify(glossy_value=0.0)
     assert int(c.reflective_args[0]) == 0
+
+
+# ---- the SSR trace against analytic geometry -----------------------------------------------------------------------------
+def test_trace_mirror_floor_hits_wall_where_geometry_says(oracle_lib):
+    """A perfectly smooth floor (y = 0) in front of a wall (z = 9): for roughness 0 the VNDF sample is the surface normal
+    (brdf.glsl:135-155 degenerates), so the traced ray is the mirror reflection and must end on the wall where the law of
+    reflection puts it — computed here in float64 from the camera matrices alone.  Pins reconstruct/project conventions,
+    reflect(), the Hi-Z march and the validity tests of trace.comp:94-118 against geometry instead of against themselves."""
+    from vk_renderer_amd import scene as scn
+
+    W, H = 512, 288
+    setup = FrameSetup(W, H)
+    sc = scn.Scene()
+    smooth = sc.add_texture(np.tile(np.array([128, 0, 0, 255], np.uint8), (4, 4, 1)))  # material.g = 0 -> roughness 0
+    quad = sc.add_mesh(np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32), np.array([[0, 1, 0]] * 4, np.float32),
+                       np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32), np.array([0, 2, 1, 0, 3, 2], np.uint32))
+    floor = np.array([[30, 0, 0, 0], [0, 1, 0, 0], [0, 0, 30, 9], [0, 0, 0, 1]], np.float32)       # y = 0, huge
+    wall = np.array([[30, 0, 0, 0], [0, 0, -30, 0], [0, -1, 0, 9], [0, 0, 0, 1]], np.float32)       # z = 9, normal (0, 0, -1)
+    sc.add_draw(sc.add_transform(floor), quad, scn.INVALID, smooth)
+    sc.add_draw(sc.add_transform(wall), quad, scn.INVALID, smooth)
+    c = PostFxChain(W, H, backend="oracle", setup=setup)
+    c.raster(sc)
+    c.downsample()
+    c.preintegrate_pdf()
+    c.ssr_trace(frame_random=0)
+    rays = c.rays.decode()  # (uv.x, uv.y, depth, valid ? pixel_depth : 1)
+    w2, h2 = W // 2, H // 2
+
+    mvp = setup.mvp.astype(np.float64)
+    inv = np.linalg.inv(mvp)
+    checked = 0
+    worst = 0.0
+    for py in range(h2 // 2 + 8, h2 - 4, 7):
+        for px in range(8, w2 - 8, 13):
+            u, v = (px + 0.5) / w2, (py + 0.5) / h2
+            a = inv @ np.array([2 * u - 1, 2 * v - 1, 0.0, 1.0])
+            b = inv @ np.array([2 * u - 1, 2 * v - 1, 1.0, 1.0])
+            a, b = a[:3] / a[3], b[:3] / b[3]
+            d = (b - a) / np.linalg.norm(b - a)
+            if abs(d[1]) < 1e-6:
+                continue
+            t = -a[1] / d[1]
+            P = a + t * d                      # floor point seen through the pixel
+            if t <= 0 or P[2] >= 9.0:
+                continue                       # the pixel shows the wall (or nothing), not the floor
+            r = d * np.array([1.0, -1.0, 1.0])  # mirror about y = 0
+            s = (9.0 - P[2]) / r[2]
+            Q = P + s * r                      # where the reflection meets the wall
+            q = mvp @ np.append(Q, 1.0)
+            hit_uv = (q[:2] / q[3]) * 0.5 + 0.5
+            if not (0.02 < hit_uv[0] < 0.98 and 0.02 < hit_uv[1] < 0.98):
+                continue
+            got = rays[py, px]
+            assert got[3] != 1.0, f"ray of pixel ({px}, {py}) should be a valid hit"
+            err = max(abs(got[0] - hit_uv[0]) * w2, abs(got[1] - hit_uv[1]) * h2)
+            worst = max(worst, err)
+            assert err <= 2.0, f"pixel ({px}, {py}): hit {got[:2]} vs geometric {hit_uv} ({err:.2f} half-res px)"
+            assert abs(got[2] - q[2] / q[3]) < 2e-3  # depth of the hit point
+            checked += 1
+    assert checked > 40, f"only {checked} mirror pixels checked: the scene does not exercise the trace"
+    print(f"[known-answer] mirror trace: {checked} pixels, worst {worst:.2f} half-res px")
+
+
+def test_velocity_convention_reprojects_to_the_same_surface_point(oracle_lib):
+    """opaque_taa.frag:45 writes velocity = 0.5 (ndc_prev - ndc_cur) and resolve.comp:27-31 fetches the history at
+    uv + velocity.  For a static textured scene seen from two cameras, the history (= the previous camera's image)
+    fetched that way must show the same surface point as the current pixel; with the sign flipped it must not."""
+    from vk_renderer_amd import scene as scn
+    from vk_renderer_amd.images import ImageBuf
+
+    W, H = 384, 216
+    setup = FrameSetup(W, H)
+    sc = scn.procedural_scene(detail=16)
+    cur = PostFxChain(W, H, backend="oracle", setup=setup)
+    cur.raster(sc)
+    cur.raster(sc, target="prev")
+
+    class PrevSetup(FrameSetup):  # the previous camera as "current" camera of a second chain
+        def __init__(self):
+            super().__init__(W, H)
+            self.mvp, self.view, self.inv_view = setup.prev_mvp, setup.prev_view, setup.prev_inv_view
+
+    prev = PostFxChain(W, H, backend="oracle", setup=PrevSetup())
+    prev.raster(sc)
+
+    def run(sign):
+        # history = previous camera's albedo as RGBA16F, colour = current albedo
+        hist = np.zeros((H, W, 4), np.float16)
+        hist[..., :3] = prev.albedo.decode()[..., :3]
+        cur.taa_hist.set_raw(hist.view(np.uint16))
+        vel = cur.velocity.raw(0).view(np.float16).astype(np.float32) * sign
+        v = ImageBuf(abi.FMT_RG16_SFLOAT, W, H)
+        v.set_raw(vel.astype(np.float16).view(np.uint16))
+        keep = cur.velocity
+        cur.velocity = v
+        cur.taa()
+        cur.velocity = keep
+        out = cur.taa_target.decode()[..., :3]
+        col = cur.albedo.decode()[..., :3]
+        return float(np.abs(out - col).mean())
+
+    good, bad = run(+1.0), run(-1.0)
+    # the same statement without the resolve pass: previous image at uv + velocity vs the current image
+    vel = cur.velocity.raw(0).view(np.float16).astype(np.float64)
+    ys, xs = np.mgrid[0:H, 0:W]
+    col, pimg = cur.albedo.decode()[..., :3], prev.albedo.decode()[..., :3]
+
+    def direct(sign):
+        px = np.clip(np.rint((xs + 0.5) + sign * vel[..., 0] * W - 0.5), 0, W - 1).astype(int)
+        py = np.clip(np.rint((ys + 0.5) + sign * vel[..., 1] * H - 0.5), 0, H - 1).astype(int)
+        return float(np.abs(pimg[py, px] - col).mean())
+
+    dgood, dbad = direct(+1.0), direct(-1.0)
+    print(f"[known-answer] mean |history - current|: resolve {good:.4f} (flipped {bad:.4f}), direct fetch {dgood:.4f} (flipped {dbad:.4f})")
+    assert dgood < 0.5 * dbad, "raster velocity does not point at the previous position of the surface point"
+    assert good < 0.6 * bad, "resolve.comp does not fetch its history at uv + velocity"
