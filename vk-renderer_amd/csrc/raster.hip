@@ -171,6 +171,13 @@ VKR_DEV void perspective(const ScreenTri& t, const float lambda[3], float b[3]) 
 }
 #define BARY(F) ((b[0] * t.v[0].F + b[1] * t.v[1].F) + b[2] * t.v[2].F)
 
+// the per-draw constants travel as kernel arguments (8 per launch) into the draw table in scratch: no host
+// staging memory has to outlive the call and nothing synchronises
+struct DrawChunk { DrawDev d[8]; };
+__global__ void k_raster_store_draws(DrawChunk c, DrawDev* dst, uint32_t n) {
+  if (threadIdx.x < n) dst[threadIdx.x] = c.d[threadIdx.x];
+}
+
 __global__ void k_raster_clear(unsigned long long* vis, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) vis[i] = ~0ull;
@@ -425,10 +432,12 @@ extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_
   r.draw_count = scene->draw_count;
   r.width = W; r.height = H;
   r.jitter_x = consts->jitter[0]; r.jitter_y = consts->jitter[1];
-  if (!draws.empty()) {
-    hipError_t e = hipMemcpyAsync((void*)r.draws, draws.data(), sizeof(DrawDev) * draws.size(), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);  // `draws` is a local: the copy must have left the host
-    if (e != hipSuccess) { set_error("gbuf_opaque_taa: draw table upload failed: %s", hipGetErrorString(e)); return (int)e; }
+  for (uint32_t i = 0; i < scene->draw_count; i += 8) {
+    DrawChunk c;
+    const uint32_t n = scene->draw_count - i < 8u ? scene->draw_count - i : 8u;
+    for (uint32_t k = 0; k < n; k++) c.d[k] = draws[i + k];
+    for (uint32_t k = n; k < 8; k++) c.d[k] = draws[i];
+    hipLaunchKernelGGL(k_raster_store_draws, dim3(1), dim3(64), 0, stream, c, const_cast<DrawDev*>(r.draws) + i, n);
   }
   const size_t npx = (size_t)W * H;
   hipLaunchKernelGGL(k_raster_clear, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, r.vis, npx);
