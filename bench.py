@@ -73,8 +73,10 @@ def measured_read_bandwidth(device):
 def cpu_baseline(frame, setup, threads=None):
     """The oracle (CPU restatement of the reference shaders, "port") timed on this host on ONE full
     frame of the same 3840x2160 workload, from the same G-buffer bytes."""
+    from oracle import binding  # the checker, used here only as the timed CPU baseline
     from vk_renderer_amd.chain import PostFxChain
 
+    binding.install()
     ref = PostFxChain(setup.width, setup.height, backend="oracle", setup=setup)
     cores = ref.lib.vkr_ref_threads()
     for name in ("depth", "prev_depth", "normal", "albedo", "material", "velocity", "pdf", "taa_hist", "acc_hist", "blurred_hist"):

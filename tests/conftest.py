@@ -14,12 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _oracle():
+    """The checker: oracle/binding.py builds the library if needed and registers the "oracle" backend with the
+    flat chain driver.  The product package itself knows nothing about it."""
+    from oracle import binding
+
+    return binding.install(build_if_missing=True)
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
-    from vk_renderer_amd import abi
+    return _oracle()
 
-    if not os.path.exists(abi.ORACLE_LIB):
-        import subprocess
 
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-j8"])
-    return abi.oracle()
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_backend_registered():
+    _oracle()

@@ -25,7 +25,15 @@ IMAGES = ("depth", "prev_depth", "normal", "albedo", "material", "velocity", "dn
           "blurred_hist", "acc_hist", "taa_hist")
 
 
+def _ensure_backend(backend):
+    if backend == "oracle":
+        from oracle import binding
+
+        binding.install(build_if_missing=True)
+
+
 def run_chain(backend="oracle", device=None):
+    _ensure_backend(backend)
     c = PostFxChain(W, H, backend=backend, device=device)
     c.synth()
     c.build_prev_hiz()
@@ -47,6 +55,7 @@ def run_extras(backend="oracle", device=None):
     """{name: ImageBuf} after running each widened pass once on the frozen 256x144 scene."""
     from vk_renderer_amd.images import ImageBuf
 
+    _ensure_backend(backend)
     c = run_chain(backend, device)
     out = {}
 

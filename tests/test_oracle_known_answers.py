@@ -12,6 +12,12 @@ from vk_renderer_amd.camera import FOVY, ZFAR, ZNEAR, FrameSetup
 from vk_renderer_amd.chain import PostFxChain
 from vk_renderer_amd.images import ImageBuf
 
+def _olib():
+    from oracle import binding
+
+    return binding.load()
+
+
 F3 = C.c_float * 3
 F2 = C.c_float * 2
 
@@ -104,15 +110,15 @@ def _plane_chain(w=64, h=32, z_view=-4.0, use_mis=0, static_camera=False):
     kw = dict(prev_delta=(0.0, 0.0, 0.0), prev_yaw_delta=0.0) if static_camera else {}
     setup = FrameSetup(w, h, use_mis=use_mis, **kw)
     c = PostFxChain(w, h, backend="oracle", setup=setup)
-    _typed(abi.oracle())
-    d = float(abi.oracle().vkr_ref_encode_depth(z_view, ZNEAR, ZFAR))
+    _typed(_olib())
+    d = float(_olib().vkr_ref_encode_depth(z_view, ZNEAR, ZFAR))
     d24 = np.uint32(round(d * 16777215.0))
     c.depth.set_raw(np.full((h, w, 1), d24, dtype=np.uint32))
     c.prev_depth.set_raw(np.full((h, w, 1), d24, dtype=np.uint32))
     # world normal such that the view-space normal is (0,0,1): n_world = view^-1 rotation * (0,0,1)
     n_world = setup.inv_view[:3, :3] @ np.array([0.0, 0.0, 1.0])
     e = F2()
-    abi.oracle().vkr_ref_encode_normal(F3(*[float(v) for v in n_world]), e)
+    _olib().vkr_ref_encode_normal(F3(*[float(v) for v in n_world]), e)
     n16 = np.array([round(e[0] * 65535), round(e[1] * 65535)], dtype=np.uint16)
     c.normal.set_raw(np.broadcast_to(n16, (h, w, 2)).copy())
     mat = np.zeros((h, w, 4), dtype=np.uint8)
@@ -171,7 +177,7 @@ def test_hiz_every_mip_is_min_of_parents(size):
     v.set_raw(rng.integers(0, 0x7BFF, size=(h, w, 2), dtype=np.uint16).view(np.float16))
     dn = ImageBuf(abi.FMT_RG16_UNORM, max(1, w // 2), max(1, h // 2))
     dv = ImageBuf(abi.FMT_RG16_SFLOAT, max(1, w // 2), max(1, h // 2))
-    lib = abi.oracle()
+    lib = _olib()
     assert lib.vkr_ref_downsample_gbuffer(C.byref(depth.desc()), C.byref(n.desc()), C.byref(v.desc()), C.byref(dn.desc()), C.byref(dv.desc())) == 0
     assert lib.vkr_ref_depth_mips(C.byref(depth.desc()), 1) == 0
     for m in range(1, L):
@@ -195,7 +201,7 @@ def test_hiz_every_mip_is_min_of_parents(size):
 
 
 def test_hiz_rejects_single_mip_and_mismatched_outputs():
-    lib = abi.oracle()
+    lib = _olib()
     depth = ImageBuf(abi.FMT_D24_UNORM_S8, 16, 16, 1)
     n, v = ImageBuf(abi.FMT_RG16_UNORM, 16, 16), ImageBuf(abi.FMT_RG16_SFLOAT, 16, 16)
     dn, dv = ImageBuf(abi.FMT_RG16_UNORM, 8, 8), ImageBuf(abi.FMT_RG16_SFLOAT, 8, 8)

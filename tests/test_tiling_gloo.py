@@ -19,12 +19,14 @@ WORKER = textwrap.dedent("""
     from vk_renderer_amd.camera import FrameSetup
     from vk_renderer_amd.tiling import TiledFrame, grid_for
     from vk_renderer_amd.chain import PostFxChain
+    from oracle import binding
+    binding.install()
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     dist.init_process_group('gloo')
     cols, rows = grid_for(world)
     W, H = 128 * cols, 144 * rows
     setup = FrameSetup(W, H)
-    t = TiledFrame(setup, rank, world, cols, rows, None, backend='oracle', halo=32)
+    t = TiledFrame(setup, rank, world, cols, rows, None, backend=binding.OracleBackend, halo=32)
     t.prepare()
     for _ in range(2):
         t.step()

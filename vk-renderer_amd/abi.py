@@ -10,7 +10,6 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PRODUCT_LIB = os.path.join(ROOT, "vk-renderer_amd", "csrc", "libvkr_postfx.so")
 HOST_LIB = os.path.join(ROOT, "vk-renderer_amd", "host", "libvkr_host.so")
-ORACLE_LIB = os.path.join(ROOT, "oracle", "libvkr_oracle.so")
 
 VKR_MAX_MIPS = 16
 HALTON_SEQ_SIZE = 128
@@ -186,8 +185,7 @@ class SynthParams(C.Structure):
 P = C.POINTER
 _IMG = P(VkrImg)
 
-# name -> argument types *without* the trailing stream (the oracle's vkr_ref_* twins
-# take the same arguments minus the stream, on host memory).
+# name -> argument types *without* the trailing stream
 ENTRY_ARGS = {
     "downsample_gbuffer": [_IMG, _IMG, _IMG, _IMG, _IMG],
     "depth_mips": [_IMG, C.c_uint32],
@@ -205,7 +203,7 @@ ENTRY_ARGS = {
     "defered_shading": [_IMG, _IMG, _IMG, _IMG, P(ShadingParams), _IMG, _IMG, _IMG, _IMG, P(ShadingPush)],
     # G-buffer raster stage; trailing (scratch pointer, scratch bytes)
     "raster_gbuffer": [P(RasterScene), P(GbufConst), _IMG, _IMG, _IMG, _IMG, _IMG, C.c_void_p, C.c_uint64],
-    # tile-classified trace: tile lists / indirect args are raw device (oracle: host) pointers
+    # tile-classified trace: tile lists / indirect args are raw pointers
     "sssr_clear_indirect": [C.c_void_p, C.c_void_p],
     "sssr_classification": [_IMG, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(ClassificationPush)],
     "sssr_trace_indirect": [_IMG, _IMG, _IMG, P(TraceParams), C.c_void_p, _IMG, C.c_void_p, C.c_void_p, C.c_uint32, P(TraceIndirectPush)],
@@ -238,7 +236,6 @@ def _load(path, what, needs_hip=True):
 
 
 _product = None
-_oracle = None
 
 
 def product():
@@ -262,24 +259,6 @@ def product():
         lib.vkr_format_bytes.restype = C.c_uint32
         _product = lib
     return _product
-
-
-def oracle():
-    """CPU restatement of the reference shaders.  TEST INFRASTRUCTURE: only tests/,
-    __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this."""
-    global _oracle
-    if _oracle is None:
-        lib = _load(ORACLE_LIB, "oracle libvkr_oracle.so", needs_hip=False)
-        for name, args in ENTRY_ARGS.items():
-            fn = getattr(lib, "vkr_ref_" + name)
-            fn.argtypes = args
-            fn.restype = C.c_int
-        lib.vkr_ref_halton23.argtypes = [C.c_void_p, C.c_uint32]
-        lib.vkr_ref_halton23.restype = None
-        lib.vkr_ref_threads.restype = C.c_int
-        lib.vkr_ref_set_threads.argtypes = [C.c_int]
-        _oracle = lib
-    return _oracle
 
 
 def check(rc, lib=None):

@@ -3,8 +3,9 @@
 This is the thin Python driver used by the parity tests and `smoke()`: it allocates the
 resource set of Gbuffer / GTAO / AdvancedSSR / TAA (scene_renderer.cpp:8-44, gtao.cpp:17-47,
 advanced_ssr.cpp:62-92, taa.cpp:3-12) and issues the passes in the frame order of
-main.cpp:345-391.  `backend` is either the HIP library (abi.product(), device memory) or —
-in tests only — the oracle (abi.oracle(), host memory); both expose the same entry points.
+main.cpp:345-391.  `backend` names a registered C-ABI provider: the package registers only
+"product" (the HIP library, device memory); a checker exposing the same entry points on host memory
+can be registered from outside with register_backend() (the test suite does).
 The production host layer with the reference's pass structs lives in host/ (C++).
 """
 import ctypes as C
@@ -17,21 +18,30 @@ from .images import ImageBuf, depth_mip_count
 
 PDF_LUT_SIZE = 1024
 
+# name -> factory returning (ctypes library, entry-point prefix, runs on a device stream?)
+_BACKENDS = {"product": lambda: (abi.product(), "vkr_", True)}
+
+
+def register_backend(name, factory):
+    """factory() -> (lib, prefix, on_device).  on_device False: images live in host memory and calls take no stream."""
+    if name == "product":
+        raise ValueError("the product backend cannot be replaced")
+    _BACKENDS[name] = factory
+
 
 class PostFxChain:
     def __init__(self, width, height, backend="product", device=None, setup=None, window=None, force_tiled=None):
         """window: None (single GPU) or (ox, oy, w, h) full-res window of the frame held by this instance."""
         self.W, self.H = width, height
         self.backend = backend
-        if backend == "product":
-            self.lib = abi.product()
-            self.prefix = "vkr_"
+        if backend not in _BACKENDS:
+            raise RuntimeError(f"backend {backend!r} is not registered (this package ships only 'product')")
+        self.lib, self.prefix, on_device = _BACKENDS[backend]()
+        if on_device:
             if device is None:
                 device = "cuda"
             self.stream = self._stream_ptr(device)
         else:
-            self.lib = abi.oracle()
-            self.prefix = "vkr_ref_"
             device = None
             self.stream = None
         self.device = device
@@ -126,7 +136,7 @@ class PostFxChain:
 
     def call(self, name, *args):
         fn = getattr(self.lib, self.prefix + name)
-        if self.backend == "product":
+        if self.stream is not None:
             rc = fn(*args, self.stream)
         else:
             rc = fn(*args)

@@ -2,7 +2,7 @@
 
 An ImageBuf owns one allocation holding every mip of an image (rows 256-B aligned) and
 hands out `VkrImg` view descriptors for the C-ABI.  The backing store is either a numpy
-array (host: oracle, fixtures) or a torch uint8 tensor (device memory: torch is only the
+array (host memory: fixtures, checkers) or a torch uint8 tensor (device memory: torch is only the
 allocator here).  `decode()` turns storage into float arrays for comparisons in tests.
 """
 import ctypes as C

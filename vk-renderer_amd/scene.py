@@ -100,7 +100,7 @@ class Scene:
 
     # ---- C-ABI view -------------------------------------------------------------------------------------
     def upload(self, device=None):
-        """-> (abi.RasterScene, keep-alive list).  device None: host memory (oracle), else torch device."""
+        """-> (abi.RasterScene, keep-alive list).  device None: host memory, else torch device."""
         keep = []
 
         def dev(arr):

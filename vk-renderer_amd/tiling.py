@@ -17,7 +17,7 @@ are served from whole-frame copies:
       interiors with point-to-point sends (up to 8 neighbours).
 
 Collectives go through torch.distributed: backend "nccl" is RCCL over xGMI on the GPU box,
-"gloo" in the CPU tests (where the compute backend is the oracle).  No data-path collective is
+"gloo" in the CPU tests (which plug their own compute backend into TiledFrame).  No data-path collective is
 used when world == 1.
 """
 import time
@@ -91,61 +91,6 @@ class HostBackend:
         torch.cuda.synchronize(self.device)
 
 
-class OracleBackend:
-    """TESTS ONLY: the same driver over the CPU oracle (chain.PostFxChain, host memory)."""
-
-    def __init__(self, setup, window, tiled, device=None):
-        from .chain import PostFxChain
-
-        self.chain = PostFxChain(setup.width, setup.height, backend="oracle", setup=setup, window=window, force_tiled=tiled)
-        self.frame = None
-        self.device = torch.device("cpu")
-
-    def rows(self, name, mip=0):
-        img = getattr(self.chain, name)
-        from .images import mip_extent
-
-        h, w = mip_extent(img.height, mip), mip_extent(img.width, mip)
-        t = torch.from_numpy(img.host)[img.offset[mip]: img.offset[mip] + h * img.pitch[mip]].view(h, img.pitch[mip])
-        return t, img.bpp, (img.origin[0] >> mip, img.origin[1] >> mip, w, h)
-
-    def prepare(self):
-        c = self.chain
-        c.synth()
-        c.build_prev_hiz()
-        c.init_histories()
-        c.preintegrate_pdf()
-
-    def run_stage(self, stage):
-        c = self.chain
-        if stage == "downsample":
-            c.downsample()
-        elif stage == "taa":
-            c.taa()
-        elif stage == "trace":
-            if c.tiled:
-                c.hiz_tail(GATHER_MIPS)
-            c.ssr_trace(frame_random=c.frame_index % 16)
-        elif stage == "resolve":
-            c.ssr_filter()
-            c.ssr_blur()
-            c.gtao_main()
-            c.gtao_filter()
-            c.gtao_accumulate()
-            c.frame_index += 1
-        else:
-            raise ValueError(stage)
-
-    def run_all(self):
-        self.chain.frame()
-
-    def end_frame(self):
-        self.chain.swap_histories()
-
-    def sync(self):
-        pass
-
-
 class TiledFrame:
     def __init__(self, setup, rank, world, cols, rows, device, backend="host", halo=HALO, force_tiled=False):
         assert cols * rows == world
@@ -161,7 +106,8 @@ class TiledFrame:
         self.window = window_rect(rank, cols, rows, self.tw, self.th, self.halo)
         # force_tiled: run the multi-GPU code path (gathers, whole-frame Hi-Z, staged frame) on one rank
         self.tiled = world > 1 or force_tiled
-        cls = HostBackend if backend == "host" else OracleBackend
+        # "host": the C++ host mirror on the GPU; anything else: a class with HostBackend's interface
+        cls = HostBackend if backend == "host" else backend
         self.backend = cls(setup, self.window, self.tiled, device)
         self.frame = self.backend.frame
         self.device = self.backend.device
