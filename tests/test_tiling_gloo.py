@@ -26,7 +26,7 @@ WORKER = textwrap.dedent("""
     cols, rows = grid_for(world)
     W, H = 128 * cols, 144 * rows
     setup = FrameSetup(W, H)
-    t = TiledFrame(setup, rank, world, cols, rows, None, backend=binding.OracleBackend, halo=32)
+    t = TiledFrame(setup, rank, world, cols, rows, None, backend=binding.OracleBackend, halo=64)
     t.prepare()
     for _ in range(2):
         t.step()

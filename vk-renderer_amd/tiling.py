@@ -186,8 +186,9 @@ class TiledFrame:
             return [("depth", m, "frame_hiz", m - 1, m) for m in range(1, GATHER_MIPS + 1)] + [("dn", 0, "frame_normals", 0, 1)]
         return [("albedo", 0, "frame_albedo", 0, 0)]
 
-    def gather_start(self, group):
-        """Packs this tile's share of `group` and issues the all-gather asynchronously."""
+    def gather_pack(self, group):
+        """Packs this tile's share of `group` into the send buffer -> (send, recv, plan, sizes, chunk).  The collective
+        itself is separate so that a test harness can move the bytes between in-process ranks instead."""
         plan = self._gather_plan(group)
         x0, y0, tw, th = self.tile
         sizes = []
@@ -205,6 +206,11 @@ class TiledFrame:
             lx, ly, w, h = (x0 >> dv) - ox, (y0 >> dv) - oy, tw >> dv, th >> dv
             send[off: off + n].view(h, w * bpp).copy_(rows[ly: ly + h, lx * bpp: (lx + w) * bpp])
             off += n
+        return send, recv, plan, sizes, chunk
+
+    def gather_start(self, group):
+        """Packs and issues the all-gather asynchronously."""
+        send, recv, plan, sizes, chunk = self.gather_pack(group)
         work = dist.all_gather_into_tensor(recv, send, async_op=True)
         return work, plan, sizes, chunk, recv
 
@@ -212,6 +218,9 @@ class TiledFrame:
         """Orders the compute stream behind the collective and scatters the tiles into the frame images."""
         work, plan, sizes, chunk, recv = pending
         work.wait()
+        self.gather_unpack(plan, sizes, chunk, recv)
+
+    def gather_unpack(self, plan, sizes, chunk, recv):
         # one strided copy per surface: recv is [rank = (row, col)][surface bytes]; the frame image is
         # [row][y][col][x bytes] (rank r sits at column r % cols, row r // cols of the grid)
         per_rank = recv.view(self.world, chunk)
@@ -273,13 +282,25 @@ class TiledFrame:
         self._halo_cache = plan
         return plan
 
-    def exchange_history_halos(self):
+    def halo_pack(self):
+        """Fills every neighbour's send buffer -> the plan [(neighbour, send slices, send buffer, recv slices, recv buffer)]."""
         plan = self._halo_plan()
         rows = {name: self.backend.rows(name)[0] for name in ("taa_hist", "acc_hist", "blurred_hist")}
-        ops = []
         for nb, send, sbuf, recv, rbuf in plan:
             for name, y, h, xb, wb, off in send:
                 sbuf[off: off + h * wb].view(h, wb).copy_(rows[name][y: y + h, xb: xb + wb])
+        return plan
+
+    def halo_unpack(self, plan):
+        rows = {name: self.backend.rows(name)[0] for name in ("taa_hist", "acc_hist", "blurred_hist")}
+        for nb, send, sbuf, recv, rbuf in plan:
+            for name, y, h, xb, wb, off in recv:
+                rows[name][y: y + h, xb: xb + wb].copy_(rbuf[off: off + h * wb].view(h, wb))
+
+    def exchange_history_halos(self):
+        plan = self.halo_pack()
+        ops = []
+        for nb, send, sbuf, recv, rbuf in plan:
             if send:
                 ops.append(dist.P2POp(dist.isend, sbuf, nb))
             if recv:
@@ -287,6 +308,4 @@ class TiledFrame:
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        for nb, send, sbuf, recv, rbuf in plan:
-            for name, y, h, xb, wb, off in recv:
-                rows[name][y: y + h, xb: xb + wb].copy_(rbuf[off: off + h * wb].view(h, wb))
+        self.halo_unpack(plan)
