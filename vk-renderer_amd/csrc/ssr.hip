@@ -300,6 +300,7 @@ __global__ __launch_bounds__(FILT_BX * FILT_BY) void k_sssr_filter(FilterArgs a)
   f3 color_sum = mk3(0, 0, 0), weight_sum = mk3(0, 0, 0);
   const int tc = (threadIdx.y + 1) * FILT_TW + (threadIdx.x + 1);
   const float center_depth = s_geo[tc].w;
+  const float k_bilateral = 1000.0f * fast_rcp(center_depth);
   const int taps = (a.render_flags & VKR_NORMALIZE_REFLECTIONS) ? 5 : 1;
   const int offs[5] = {0, -1, FILT_TW, 1, -FILT_TW};  // (0,0) (-1,0) (0,1) (1,0) (0,-1): filter.comp:62-68
 #pragma unroll
@@ -318,15 +319,15 @@ __global__ __launch_bounds__(FILT_BX * FILT_BY) void k_sssr_filter(FilterArgs a)
       const float G1 = 2.0f * fast_rcp(1.0f + fast_sqrt(1.0f + geo.z * ((1.0f - a4) * fast_rcp(a4))));
       f3 weight = F * (G2 * fast_rcp(G1));
       float bilateral_weight = 1.0f;
-      if (a.render_flags & VKR_BILATERAL_FILTER)
-        bilateral_weight = vmax(1.0f - (1000.0f * fabsf(center_depth - geo.w)) / center_depth, 0.0f);
+      if (a.render_flags & VKR_BILATERAL_FILTER)  // continuous weight: one reciprocal of the centre depth for the five taps
+        bilateral_weight = vmax(__builtin_fmaf(-fabsf(center_depth - geo.w), k_bilateral, 1.0f), 0.0f);
       weight = weight * bilateral_weight;
       color_sum = color_sum + weight * mk3(rad.x, rad.y, rad.z);
       weight_sum = weight_sum + weight;
     }
   }
   if (vmax(weight_sum.x, vmax(weight_sum.y, weight_sum.z)) < 0.001f) weight_sum = mk3(1, 1, 1);
-  color_sum = color_sum / weight_sum;
+  color_sum = mk3(color_sum.x * fast_rcp(weight_sum.x), color_sum.y * fast_rcp(weight_sum.y), color_sum.z * fast_rcp(weight_sum.z));
   *texel_ptr<uint32_t>(a.out, lx, ly) =
       float_to_unorm8(color_sum.x) | (float_to_unorm8(color_sum.y) << 8) | (float_to_unorm8(color_sum.z) << 16);
 }
