@@ -81,12 +81,13 @@ class OracleBackend:
             if c.tiled:
                 c.hiz_tail(tiling.GATHER_MIPS)
             c.ssr_trace(frame_random=c.frame_index % 16)
-        elif stage == "resolve":
-            c.ssr_filter()
-            c.ssr_blur()
+        elif stage == "gtao":
             c.gtao_main()
             c.gtao_filter()
             c.gtao_accumulate()
+        elif stage == "ssr_resolve":
+            c.ssr_filter()
+            c.ssr_blur()
             c.frame_index += 1
         else:
             raise ValueError(stage)

@@ -17,7 +17,7 @@ def _lockstep_frame(ranks):
     world = len(ranks)
     for t in ranks:
         t.backend.run_stage("downsample")
-    for group, stages_before, stages_after in (("hiz", ("taa",), ("trace",)), ("albedo", (), ("resolve",))):
+    for group, stages_before, stages_after in (("hiz", ("taa",), ("trace", "gtao")), ("albedo", (), ("ssr_resolve",))):
         packed = [t.gather_pack(group) for t in ranks]
         for t in ranks:
             for st in stages_before:

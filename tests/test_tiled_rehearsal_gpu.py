@@ -37,7 +37,7 @@ def test_tiled_path_on_one_rank_matches_plain_frame():
             t.backend.sync()
             results.append({n: t.frame.download(n).to_host().copy() for n in OUTPUTS})
             if force:
-                assert t.frame.last_tasks()[-1] == "GTAO_accumulate", "staged frame: TAA runs early, the resolve stage last"
+                assert t.frame.last_tasks()[-1] == "SSSR_blur", "staged frame: TAA and GTAO run early, filter + blur last"
             t.frame.close()
         for n in OUTPUTS:
             assert np.array_equal(results[0][n], results[1][n]), f"{n}: tiled code path differs from the plain frame"

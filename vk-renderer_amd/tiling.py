@@ -11,7 +11,7 @@ are served from whole-frame copies:
       (what the filter reads at the hit positions)  ->  frame_hiz / frame_normals / frame_albedo
       on every rank; the coarser Hi-Z mips are then rebuilt locally.  Both are issued
       asynchronously right after the downsample: TAA (independent of them) runs while the first
-      is in flight, the trace while the second is.
+      is in flight, the trace and GTAO while the second is.
   exchange B (every frame, after the history remaps):  the halo ring of the three history
       surfaces (TAA, accumulated AO, blurred reflections) is refreshed from the neighbours'
       interiors with point-to-point sends (up to 8 neighbours).
@@ -76,10 +76,11 @@ class HostBackend:
         self.frame.run(h.STAGE_LUT | h.STAGE_GBUFFER | h.STAGE_PREV_DEPTH)
 
     def run_stage(self, stage):
-        """stage: 'downsample' | 'taa' | 'trace' (Hi-Z tail + trace) | 'resolve' (filter, blur, GTAO)"""
+        """stage: 'downsample' | 'taa' | 'trace' (Hi-Z tail + trace) | 'gtao' (main, filter, accumulate) |
+        'ssr_resolve' (filter, blur)"""
         h = self.host
         self.frame.run({"downsample": h.STAGE_DOWNSAMPLE, "taa": h.STAGE_TAA, "trace": h.STAGE_HIZ_TAIL | h.STAGE_SSR_TRACE,
-                        "resolve": h.STAGE_SSR_RESOLVE | h.STAGE_GTAO}[stage])
+                        "gtao": h.STAGE_GTAO, "ssr_resolve": h.STAGE_SSR_RESOLVE}[stage])
 
     def run_all(self):
         self.frame.run(self.host.STAGE_CHAIN)
@@ -153,9 +154,10 @@ class TiledFrame:
                 self.backend.run_all()
             self.backend.end_frame()
             return
-        # downsample -> [gather Hi-Z + normals || TAA] -> trace -> [gather albedo, in flight since the
-        # downsample] -> filter, blur, GTAO.  The collectives run on the communicator's own stream;
-        # wait() only orders the compute stream behind them.
+        # downsample -> [gather Hi-Z + normals || TAA] -> trace -> GTAO -> [gather albedo, in flight since
+        # the downsample] -> filter, blur.  GTAO only needs the trace's (occlusion, pdf), not the albedo,
+        # so it runs ahead of the reference's order to hide more of the second gather.  The collectives
+        # run on the communicator's own stream; wait() only orders the compute stream behind them.
         self.backend.run_stage("downsample")
         t0 = time.perf_counter()
         pending_hiz = self.gather_start("hiz")
@@ -166,10 +168,11 @@ class TiledFrame:
         self.gather_finish(pending_hiz)
         self._xchg_s += time.perf_counter() - t0
         self.backend.run_stage("trace")
+        self.backend.run_stage("gtao")
         t0 = time.perf_counter()
         self.gather_finish(pending_albedo)
         self._xchg_s += time.perf_counter() - t0
-        self.backend.run_stage("resolve")
+        self.backend.run_stage("ssr_resolve")
         self.backend.end_frame()
         t0 = time.perf_counter()
         self.exchange_history_halos()
