@@ -132,6 +132,13 @@ struct UniformBufferPool {
     top = at + sizeof(T);
     return UboBlock<T>{reinterpret_cast<T*>(storage.data() + at), (uint32_t)at};
   }
+  // untyped block (pass_recorder.hpp)
+  UboBlock<uint8_t> allocate_bytes(uint64_t bytes) {
+    uint64_t at = (top + 255) & ~uint64_t(255);
+    if (at + bytes > storage.size()) throw std::runtime_error{"Not enough space in uniform buffer"};
+    top = at + bytes;
+    return UboBlock<uint8_t>{storage.data() + at, (uint32_t)at};
+  }
   const uint8_t* data() const { return storage.data(); }
  private:
   std::vector<uint8_t> storage;
@@ -171,6 +178,7 @@ struct StorageTextureBinding : BaseBinding {  // gpu/descriptors.hpp:103-115
 struct UBOBinding : BaseBinding {  // gpu/descriptors.hpp:31-63
   template <typename T> UBOBinding(uint32_t b, const UniformBufferPool&, const UboBlock<T>& blk) : BaseBinding{b}, host{blk.ptr}, size{sizeof(T)} {}
   UBOBinding(uint32_t b, const BufferPtr& buf) : BaseBinding{b}, buffer{buf}, size{buf->get_size()} {}
+  UBOBinding(uint32_t b, const void* ring_memory, uint64_t bytes) : BaseBinding{b}, host{ring_memory}, size{bytes} {}
   const void* host = nullptr; BufferPtr buffer; uint64_t size;
 };
 struct SSBOBinding : BaseBinding {

@@ -1,0 +1,666 @@
+// passes.hpp — every pass struct of the path with the reference's public interface (constructor arguments,
+// method names and signatures, public image ids) so that its frame loop compiles against them unchanged:
+//   scene::CompiledScene, Gbuffer, DrawTAAParams, SceneRenderer   (src/scene/scene.hpp, src/scene_renderer.hpp)
+//   DownsamplePass                                                (src/downsample_pass.hpp)
+//   GTAOParams, GTAOReprojection, GTAO                            (src/gtao.hpp)
+//   AdvancedSSRParams, AdvancedSSR, halton23_seq                  (src/advanced_ssr.hpp)
+//   TAA                                                           (src/taa.hpp)
+//   SSRParams, add_ssr_pass, create_ssr_tex                       (src/ssr.hpp)
+//   ScreenTraceParams, ScreenSpaceTrace                           (src/screen_trace.hpp)
+//   DeferedShadingPass                                            (src/defered_shading.hpp)
+//   ReadBackData, ReadBackSystem + capture writers                (src/image_readback.hpp, main.cpp:118-176)
+//   SyntheticGbuffer                                              (no counterpart: analytic G-buffer)
+// The per-name headers (gtao.hpp, taa.hpp, ...) forward here.  Implementations: passes.cpp, written on
+// pass_recorder.hpp; everything executes through the C-ABI of include/vkr_postfx.h.
+#ifndef VKR_HOST_PASSES_HPP_INCLUDED
+#define VKR_HOST_PASSES_HPP_INCLUDED
+
+#include <limits>
+#include <memory>
+#include <random>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "glm_compat.hpp"
+#include "gpu/gpu.hpp"
+#include "rendergraph/rendergraph.hpp"
+
+
+// ======================================================================================================
+// scene.hpp — the compiled scene the raster stage draws: the subset of src/scene/scene.hpp:11-87 that
+// SceneRenderer reads (interleaved vertex / index buffers, primitives, materials, node tree, textures with
+// their mip chains).  The reference fills it from a glTF file through tinygltf + stb_image
+// (scene/scene.cpp:144-361, scene/images.cpp:20-60), neither of which is in this image; here it is
+// filled from plain arrays (`make_scene`), e.g. by vk-renderer_amd/scene.py, which follows the same
+// loading rules.
+
+
+
+namespace scene {
+
+constexpr uint32_t INVALID_TEXTURE = ~0u;
+
+struct Vertex {
+  glm::vec3 pos;
+  glm::vec3 norm;
+  glm::vec2 uv;
+};
+static_assert(sizeof(Vertex) == sizeof(vkr_raster_vertex), "Vertex must match the C-ABI");
+
+struct Primitive {
+  uint32_t vertex_offset;
+  uint32_t index_offset;
+  uint32_t index_count;
+  uint32_t material_index;
+};
+
+struct BaseMesh {
+  std::vector<Primitive> primitives;
+};
+
+struct BaseNode {
+  glm::mat4 transform;
+  std::vector<BaseNode> children;
+  int mesh_index;
+};
+
+struct Material {
+  uint32_t albedo_tex_index = INVALID_TEXTURE;
+  uint32_t metalic_roughness_index = INVALID_TEXTURE;
+  bool clip_alpha = false;
+  float alpha_cutoff = 0.f;
+};
+
+struct Texture {
+  uint32_t image_index;
+  uint32_t sampler_index;
+};
+
+struct CompiledScene {
+  gpu::BufferPtr vertex_buffer;
+  gpu::BufferPtr index_buffer;
+  std::vector<gpu::ImagePtr> images;
+  std::vector<VkSampler> samplers;
+  std::vector<Texture> textures;
+  std::vector<Material> materials;
+  std::vector<BaseMesh> root_meshes;
+  std::vector<BaseNode> base_nodes;
+};
+
+// one mip chain of RGBA8 texels, level 0 first, rows tightly packed
+struct TextureData {
+  uint32_t width, height, mip_levels;
+  const uint8_t *levels[VKR_MAX_MIPS];
+};
+
+// Flat description of a scene: node i draws mesh i (one primitive) with material i.
+struct FlatDraw {
+  glm::mat4 transform;
+  uint32_t vertex_offset, index_offset, index_count;
+  uint32_t albedo_tex_index, metalic_roughness_index;
+  bool clip_alpha;
+};
+
+CompiledScene make_scene(const Vertex *vertices, uint32_t vertex_count, const uint32_t *indices, uint32_t index_count,
+                         const FlatDraw *draws, uint32_t draw_count, const TextureData *textures, uint32_t texture_count);
+
+}
+
+
+// ======================================================================================================
+// scene_renderer.hpp — the G-buffer resource set and the per-frame camera block every hot-path
+// pass consumes.  Mirrors `Gbuffer` (src/scene_renderer.hpp:11-24, ctor scene_renderer.cpp:8-44)
+// and `DrawTAAParams` (scene_renderer.hpp:26-33), and `SceneRenderer` (scene_renderer.hpp:35-65): the raster
+// stage that fills the G-buffer (draw_taa, scene_renderer.cpp:140-220) over the compute rasterizer bound
+// as program "gbuf_opaque_taa".  SyntheticGbuffer (synthetic_gbuffer.hpp) fills the same attachments
+// without geometry for the benchmark.
+
+
+struct Gbuffer {
+  Gbuffer(rendergraph::RenderGraph &graph, uint32_t width, uint32_t height);
+
+  rendergraph::ImageResourceId albedo;
+  rendergraph::ImageResourceId normal;
+  rendergraph::ImageResourceId downsampled_normals;
+  rendergraph::ImageResourceId material;
+  rendergraph::ImageResourceId depth;
+  rendergraph::ImageResourceId prev_depth;
+  rendergraph::ImageResourceId velocity_vectors;
+  rendergraph::ImageResourceId downsampled_velocity_vectors;
+
+  uint32_t w, h;
+
+  // ---- multi-GPU tiling (not in the reference) ---------------------------------------------------
+  // When the frame is tiled, reads with unbounded reach (Hi-Z march, hit normal, hit colour) go
+  // to whole-frame copies assembled by the launcher over RCCL.  `frame_*` equal the window-local
+  // images on a single GPU.
+  bool tiled = false;
+  rendergraph::ImageResourceId frame_hiz;      // D24, mips = image mips 1..L-1 of the whole frame
+  rendergraph::ImageResourceId frame_normals;  // whole-frame downsampled_normals
+  rendergraph::ImageResourceId frame_albedo;   // whole-frame albedo
+  void enable_tiling(rendergraph::RenderGraph &graph, uint32_t full_width, uint32_t full_height);
+};
+
+struct DrawTAAParams {
+  glm::mat4 mvp;
+  glm::mat4 prev_mvp;
+  glm::mat4 camera;
+  glm::mat4 prev_camera;
+  glm::vec4 jitter;
+  glm::vec4 fovy_aspect_znear_zfar;
+};
+
+struct SceneRenderer {
+  SceneRenderer(scene::CompiledScene &s) : target {s} {}
+
+  void init_pipeline(rendergraph::RenderGraph &graph, const Gbuffer &buffer);
+  void update_scene();
+  void draw_taa(rendergraph::RenderGraph &graph, const Gbuffer &gbuffer, const DrawTAAParams &params);
+
+  struct DrawCall {
+    uint32_t transform;
+    uint32_t mesh;
+  };
+
+  const std::vector<DrawCall> &get_drawcalls() const { return draw_calls; }
+  rendergraph::BufferResourceId get_scene_transforms() const { return transform_buffer; }
+
+private:
+  scene::CompiledScene &target;
+  rendergraph::RenderGraph *owner = nullptr;
+  gpu::GraphicsPipeline opaque_taa_pipeline;
+  VkSampler sampler;
+  rendergraph::BufferResourceId transform_buffer;
+  VkDescriptorSet bindless_textures {nullptr};
+  std::vector<std::unique_ptr<gpu::ImageViewObject>> texture_views;
+  std::vector<std::pair<VkImageView, VkSampler>> scene_textures;
+  std::vector<DrawCall> draw_calls;
+};
+
+
+// ======================================================================================================
+// downsample_pass.hpp — Hi-Z build pass, public interface of src/downsample_pass.hpp:6-35.
+
+
+struct DownsamplePass {
+  DownsamplePass();
+
+  void run(
+    rendergraph::RenderGraph &graph,
+    rendergraph::ImageResourceId src_normals,
+    rendergraph::ImageResourceId src_velocity,
+    rendergraph::ImageResourceId depth,
+    rendergraph::ImageResourceId out_normals,
+    rendergraph::ImageResourceId out_velocity);
+
+  // Build mips src_mip+1.. of `depth` only (used for the whole-frame pyramid tail when tiled).
+  void run_downsample_depth(rendergraph::RenderGraph &graph, rendergraph::ImageResourceId depth, uint32_t src_mip);
+
+private:
+  gpu::GraphicsPipeline downsample_gbuffer;
+  gpu::GraphicsPipeline downsample_depth;
+  VkSampler sampler;
+
+  void run_downsample_gbuff(
+    rendergraph::RenderGraph &graph,
+    rendergraph::ImageResourceId src_normals,
+    rendergraph::ImageResourceId src_velocity,
+    rendergraph::ImageResourceId depth,
+    rendergraph::ImageResourceId out_normal,
+    rendergraph::ImageResourceId out_velocity);
+};
+
+
+// ======================================================================================================
+// gtao.hpp — ground-truth ambient occlusion pass, public interface of src/gtao.hpp:10-121.
+// The passes the reference's frame loop runs (main.cpp:384-388) — add_main_pass, add_filter_pass,
+// add_accumulate_pass, remap — over the C-ABI programs gtao_compute_main / gtao_filter /
+// gtao_accumulate, and the variants it ships but never records: graphics
+// main pass ("gtao_main"), static reprojection ("gtao_reproject"), deinterleaved depth + main pass
+// ("deinterleave_depth", "main_deinterleaved").  The ray-query pass (add_main_rt_pass,
+// gtao.cpp:150-196) needs a scene acceleration structure and is not part of this path: the
+// constructor throws when use_ray_query is set.
+
+
+rendergraph::ImageResourceId create_gtao_texture(rendergraph::RenderGraph &graph, uint32_t width, uint32_t height);
+
+struct GTAOParams {
+  glm::mat4 normal_mat;
+  float fovy;
+  float aspect;
+  float znear;
+  float zfar;
+};
+
+struct GTAOReprojection {
+  glm::mat4 camera_to_prev_frame;
+  float fovy;
+  float aspect;
+  float znear;
+  float zfar;
+};
+
+struct GTAO {
+  GTAO(rendergraph::RenderGraph &graph, uint32_t width, uint32_t height, bool use_ray_query, bool half_res = true, int pattern_n = 2);
+
+  void add_main_pass(
+    rendergraph::RenderGraph &graph,
+    const GTAOParams &params,
+    rendergraph::ImageResourceId depth,
+    rendergraph::ImageResourceId normal,
+    rendergraph::ImageResourceId material,
+    rendergraph::ImageResourceId preintegrated_pdf);
+
+  void add_main_pass_graphics(
+    rendergraph::RenderGraph &graph,
+    const GTAOParams &params,
+    rendergraph::ImageResourceId depth,
+    rendergraph::ImageResourceId normal);
+
+  void add_filter_pass(
+    rendergraph::RenderGraph &graph,
+    const GTAOParams &params,
+    rendergraph::ImageResourceId depth);
+
+  void add_reprojection_pass(
+    rendergraph::RenderGraph &graph,
+    const GTAOReprojection &params,
+    rendergraph::ImageResourceId depth,
+    rendergraph::ImageResourceId prev_depth);
+
+  void add_accumulate_pass(
+    rendergraph::RenderGraph &graph,
+    const DrawTAAParams &params,
+    const Gbuffer &gbuffer);
+
+  void deinterleave_depth(rendergraph::RenderGraph &graph, rendergraph::ImageResourceId depth);
+  void add_main_pass_deinterleaved(
+    rendergraph::RenderGraph &graph,
+    const GTAOParams &params,
+    rendergraph::ImageResourceId normal);
+
+  void remap(rendergraph::RenderGraph &graph) {
+    graph.remap(accumulated_history, accumulated_ao);
+  }
+
+  rendergraph::ImageResourceId raw; //output of main pass
+  rendergraph::ImageResourceId filtered; //output of filter pass
+  rendergraph::ImageResourceId prev_frame; //previous frame
+  rendergraph::ImageResourceId output; //final
+  rendergraph::ImageResourceId accumulated_ao;
+  rendergraph::ImageResourceId accumulated_history;
+  rendergraph::ImageResourceId deinterleaved_depth;
+
+  // ---- headless controls (ImGui toggles of gtao.cpp:528-536 in the reference) -------------------
+  // The reference adds rand()/RAND_MAX - 0.5 to the per-frame angle (gtao.cpp:111); parity runs
+  // pin it instead.  NaN = keep the reference behaviour.
+  void pin_angle_jitter(float jitter) { pinned_jitter = jitter; }
+  void set_mis(bool enabled) { mis_gtao = enabled; }
+  void set_two_directions(bool enabled) { two_directions = enabled; }
+  void set_only_reflections(bool enabled) { only_reflections = enabled; }
+  void set_weight_ratio(float ratio) { weight_ratio = ratio; }
+  void request_clear_history() { clear_history = true; }
+  void set_frame_count(uint32_t n) { frame_count = n; }
+
+private:
+  float next_base_angle();
+
+  gpu::GraphicsPipeline main_pipeline_gfx;
+  gpu::ComputePipeline reproject_pipeline;
+  gpu::ComputePipeline deinterleave_pipeline;
+  gpu::ComputePipeline main_deinterleaved_pipeline;
+  gpu::ComputePipeline main_pipeline;
+  gpu::ComputePipeline filter_pipeline;
+  gpu::ComputePipeline accumulate_pipeline;
+
+  int deinterleave_n = 2;
+  uint32_t depth_lod = 0;
+
+  bool mis_gtao = true;
+  bool two_directions = false;
+  bool only_reflections = false;
+  bool clear_history = false;
+  float weight_ratio = 1.0;
+  float pinned_jitter;
+
+  uint32_t frame_count = 0;
+
+  VkSampler sampler;
+};
+
+
+// ======================================================================================================
+// advanced_ssr.hpp — stochastic Hi-Z screen-space reflections, public interface of
+// src/advanced_ssr.hpp:7-113.  Implemented: run() = trace -> filter -> blur (advanced_ssr.cpp:551-553),
+// preintegrate_pdf / preintegrate_brdf, remap_images, the getters, and the tile-classified trace the
+// reference leaves commented out of run() (advanced_ssr.cpp:547-550):
+// clear_indirect_params -> run_classification_pass -> run_trace_indirect_pass, selected with
+// Settings::use_tile_classification (default off = the reference's behaviour).  The tile-regression
+// experiment (advanced_ssr.cpp:497-538) stays out of scope.
+
+
+
+struct AdvancedSSRParams {
+  glm::mat4 normal_mat;
+  float fovy;
+  float aspect;
+  float znear;
+  float zfar;
+};
+
+std::vector<glm::vec4> halton23_seq(uint32_t count);
+
+struct AdvancedSSR {
+  AdvancedSSR(rendergraph::RenderGraph &graph, uint32_t w, uint32_t h);
+  void run(
+    rendergraph::RenderGraph &graph,
+    const AdvancedSSRParams &params,
+    const DrawTAAParams &taa_params,
+    const Gbuffer &gbuff,
+    rendergraph::ImageResourceId ssr_occlusion);
+
+  void preintegrate_pdf(rendergraph::RenderGraph &graph);
+  void preintegrate_brdf(rendergraph::RenderGraph &graph);
+  void remap_images(rendergraph::RenderGraph &graph) { graph.remap(blurred_reflection, blurred_reflection_history); }
+
+  rendergraph::ImageResourceId get_ouput() const { return reflections; }
+  rendergraph::ImageResourceId get_rays() const { return rays; }
+  rendergraph::ImageResourceId get_blurred() const { return blurred_reflection; }
+  rendergraph::ImageResourceId get_blurred_history() const { return blurred_reflection_history; }
+  rendergraph::ImageResourceId get_occlusion() const { return rays_occlusion; }
+  rendergraph::ImageResourceId get_preintegrated_pdf() const { return preintegrated_pdf; }
+  rendergraph::ImageResourceId get_preintegrated_brdf() const { return preintegrated_brdf; }
+
+  // headless equivalents of the ImGui controls (advanced_ssr.cpp:556-567)
+  struct Settings {
+    float max_rougness = 1.f;
+    float glossy_roughness_value = 0.5f;
+    bool normalize_reflections = true;
+    bool accumulate_reflections = true;
+    bool bilateral_filter = true;
+    bool update_random = true;
+    bool use_blur = true;
+    int max_accumulated_rays = 16;
+    bool use_tile_classification = false;  // run(): classification + indirect trace instead of run_trace_pass
+  };
+  Settings &get_settings() { return settings; }
+  void set_counter(uint32_t c) { counter = c; }
+
+  // the two halves of run(), for drivers that interleave an exchange between them (multi-GPU: the
+  // trace needs the gathered Hi-Z pyramid, the filter the gathered albedo)
+  void run_trace(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion);
+  void run_resolve(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const DrawTAAParams &taa_params, const Gbuffer &gbuff);
+
+  // advanced_ssr.cpp:440-495,216-302 (private in the reference; public here so drivers can record them one by one)
+  void clear_indirect_params(rendergraph::RenderGraph &graph);
+  void run_classification_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff);
+  void run_trace_indirect_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff);
+  rendergraph::BufferResourceId get_reflective_tiles() const { return reflective_tiles; }
+  rendergraph::BufferResourceId get_glossy_tiles() const { return glossy_tiles; }
+  rendergraph::BufferResourceId get_reflective_indirect() const { return reflective_indirect; }
+  rendergraph::BufferResourceId get_glossy_indirect() const { return glossy_indirect; }
+
+private:
+  gpu::BufferPtr halton_buffer;
+
+  gpu::ComputePipeline trace_pass;
+  gpu::ComputePipeline filter_pass;
+  gpu::ComputePipeline blur_pass;
+  gpu::ComputePipeline preintegrate_pass;
+  gpu::ComputePipeline preintegrate_brdf_pass;
+  gpu::ComputePipeline classification_pass;
+  gpu::ComputePipeline trace_indirect_pass;
+
+  rendergraph::BufferResourceId reflective_indirect;
+  rendergraph::BufferResourceId glossy_indirect;
+  rendergraph::BufferResourceId reflective_tiles;
+  rendergraph::BufferResourceId glossy_tiles;
+
+  VkSampler sampler;
+
+  rendergraph::ImageResourceId rays;
+  rendergraph::ImageResourceId reflections;
+  rendergraph::ImageResourceId blurred_reflection;
+  rendergraph::ImageResourceId blurred_reflection_history;
+  rendergraph::ImageResourceId rays_occlusion;
+  rendergraph::ImageResourceId preintegrated_pdf;
+  rendergraph::ImageResourceId preintegrated_brdf;
+
+  uint32_t counter {0u};
+  Settings settings;
+
+  void advance_counter();
+  void run_trace_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion);
+  void run_filter_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff);
+  void run_blur_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const DrawTAAParams &taa_params, const Gbuffer &gbuff);
+};
+
+
+// ======================================================================================================
+// taa.hpp — temporal anti-aliasing resolve, public interface of src/taa.hpp:8-21.
+
+
+struct TAA {
+  TAA(rendergraph::RenderGraph &graph, uint32_t w, uint32_t h);
+
+  void run(rendergraph::RenderGraph &graph, const Gbuffer &gbuffer, rendergraph::ImageResourceId color, const DrawTAAParams &params);
+  void remap_targets(rendergraph::RenderGraph &graph);
+
+  rendergraph::ImageResourceId get_output() const { return target; }
+  rendergraph::ImageResourceId get_history() const { return history; }
+
+private:
+  rendergraph::ImageResourceId history;
+  rendergraph::ImageResourceId target;
+  gpu::ComputePipeline pipeline;
+  VkSampler sampler;
+};
+
+
+// ======================================================================================================
+// ssr.hpp — simple mirror SSR pass, public interface of src/ssr.hpp:7-24 (not called by the
+// reference's frame loop).
+
+
+rendergraph::ImageResourceId create_ssr_tex(rendergraph::RenderGraph &graph, uint32_t w, uint32_t h);
+
+struct SSRParams {
+  glm::mat4 normal_mat;
+  float fovy;
+  float aspect;
+  float znear;
+  float zfar;
+};
+
+void add_ssr_pass(
+  rendergraph::RenderGraph &graph,
+  rendergraph::ImageResourceId depth,
+  rendergraph::ImageResourceId normal,
+  rendergraph::ImageResourceId color,
+  rendergraph::ImageResourceId material,
+  rendergraph::ImageResourceId out,
+  const SSRParams &params);
+
+
+// ======================================================================================================
+// screen_trace.hpp — ScreenSpaceTrace, public interface of src/screen_trace.hpp:8-52 (SURVEY.md 8(a)
+// row R2): a one-bounce screen-space radiance + horizon-AO tracer with a 4x4 depth-aware filter and
+// a static-reprojection accumulator.  Not recorded by the reference's frame loop; kept as a drop-in.
+
+
+
+struct ScreenTraceParams {
+  glm::mat4 normal_mat;
+  float fovy;
+  float aspect;
+  float znear;
+  float zfar;
+};
+
+struct ScreenSpaceTrace {
+  ScreenSpaceTrace(rendergraph::RenderGraph &graph, uint32_t width, uint32_t height);
+
+  void add_main_pass(
+    rendergraph::RenderGraph &graph,
+    const ScreenTraceParams &params,
+    rendergraph::ImageResourceId depth,
+    rendergraph::ImageResourceId normal,
+    rendergraph::ImageResourceId color,
+    rendergraph::ImageResourceId material);
+
+  void add_filter_pass(
+    rendergraph::RenderGraph &graph,
+    const ScreenTraceParams &params,
+    rendergraph::ImageResourceId depth);
+
+  void add_accumulate_pass(
+    rendergraph::RenderGraph &graph,
+    const ScreenTraceParams &params,
+    rendergraph::ImageResourceId depth,
+    rendergraph::ImageResourceId prev_depth);
+
+  rendergraph::ImageResourceId raw;
+  rendergraph::ImageResourceId filtered;
+  rendergraph::ImageResourceId accumulated;
+
+  // headless control: the reference draws the angle jitter and random_offset from a
+  // std::default_random_engine each frame (screen_trace.cpp:49-53); parity runs pin both.
+  void pin_randoms(float angle_jitter, float random_offset) { pinned_jitter = angle_jitter; pinned_offset = random_offset; }
+  void set_frame_count(uint32_t n) { frame_count = n; }
+
+private:
+  std::uniform_real_distribution<float> random_floats {0.0, 1.0};
+  std::default_random_engine generator;
+  float pinned_jitter = std::numeric_limits<float>::quiet_NaN();
+  float pinned_offset = std::numeric_limits<float>::quiet_NaN();
+
+  gpu::ComputePipeline trace_pipeline;
+  gpu::ComputePipeline filter_pipeline;
+  gpu::ComputePipeline accum_pipeline;
+
+  uint32_t frame_count = 0;
+  VkSampler sampler;
+};
+
+
+// ======================================================================================================
+// defered_shading.hpp — deferred-shading composite, public interface of src/defered_shading.hpp:8-32
+// (produces TAA's colour input, main.cpp:390-391).  The SDL window of the
+// reference constructor only feeds ImGui; it is accepted and ignored.
+
+
+struct SDL_Window;
+
+struct DeferedShadingPass {
+  DeferedShadingPass(rendergraph::RenderGraph &graph, SDL_Window *window);
+
+  void update_params(const glm::mat4 &camera, const glm::mat4 &shadow, float fovy, float aspect, float znear, float zfar);
+
+  void draw(rendergraph::RenderGraph &graph,
+    const Gbuffer &gbuffer,
+    rendergraph::ImageResourceId shadow,
+    rendergraph::ImageResourceId ssao,
+    rendergraph::ImageResourceId brdf_tex,
+    rendergraph::ImageResourceId reflections,
+    rendergraph::ImageResourceId out_image);
+
+  // headless equivalents of the ImGui sliders (defered_shading.cpp:120-126)
+  void set_roughness_range(float lo, float hi) { min_max_roughness = glm::vec2 {lo, hi}; }
+  void set_only_ao(bool v) { only_ao = v; }
+
+private:
+  gpu::GraphicsPipeline pipeline;
+  VkSampler sampler;
+  rendergraph::BufferResourceId ubo_consts;
+
+  glm::vec2 min_max_roughness {0.f, 1.f};
+  bool only_ao = false;
+  rendergraph::RenderGraph *graph_ref = nullptr;  // update_params writes the constant buffer the graph owns
+};
+
+
+// ======================================================================================================
+// synthetic_gbuffer.hpp — headless replacement of the G-buffer raster stage
+// (SceneRenderer::draw_taa, src/scene_renderer.cpp:140-220 + shaders/gbuf/opaque_taa.*).
+// Writes the same attachments of `Gbuffer` from an analytic scene so the post-process chain runs
+// without Vulkan, geometry or textures.  Same call shape as draw_taa.
+
+
+struct SyntheticGbuffer {
+  explicit SyntheticGbuffer(uint32_t seed = 0x5EED0001u);
+
+  // fills albedo / normal / material / velocity_vectors / depth (mip 0) for `params`
+  void draw_taa(rendergraph::RenderGraph &graph, const Gbuffer &gbuffer, const DrawTAAParams &params);
+  // fills mip 0 of `depth_target` only, as seen from `camera` (used to seed prev_depth)
+  void draw_depth(rendergraph::RenderGraph &graph, rendergraph::ImageResourceId depth_target, const glm::mat4 &camera, const glm::mat4 &mvp,
+                  const glm::vec4 &fovy_aspect_znear_zfar);
+
+private:
+  gpu::GraphicsPipeline pipeline;
+  uint32_t seed;
+};
+
+
+// ======================================================================================================
+// image_readback.hpp — ReadBackSystem, public interface of src/image_readback.hpp:11-52, plus the
+// capture writers of src/main.cpp:118-176 (CSV of 24-bit hex depth, PNG of depth words, PNG of RGBA8
+// with alpha forced to 255) so that outputs of this build and captures of the Vulkan reference are
+// diffable in one format.
+//
+// HIP design: the "ImageRead" task is one hipMemcpy2DAsync from the pitch-linear image into pinned
+// host memory on the graph's stream; the request matures after frames_count + 1 calls of
+// after_submit() like the reference's fenced frames (image_readback.cpp:93,118-124), at which point
+// the stream is synchronised once for all matured requests.
+
+
+
+struct ReadBackData {
+  uint32_t width = 0;
+  uint32_t height = 0;
+  VkFormat texel_fmt = VK_FORMAT_UNDEFINED;
+  uint32_t texel_size = 0;
+  std::unique_ptr<uint8_t[]> bytes {nullptr};
+};
+
+using ReadBackID = uint64_t;
+const ReadBackID INVALID_READBACK = ~0ull;
+
+struct ReadBackSystem {
+  ReadBackID read_image(rendergraph::RenderGraph &graph, rendergraph::ImageResourceId image);
+  ReadBackID read_image(rendergraph::RenderGraph &graph, rendergraph::ImageResourceId image, VkImageAspectFlags aspect, uint32_t mip, uint32_t layer);
+
+  void after_submit(rendergraph::RenderGraph &graph);
+  bool is_data_available(ReadBackID id) const { return processed_requests.count(id); }
+
+  ReadBackData get_data(ReadBackID id);
+  void clear();
+  ~ReadBackSystem() { clear(); }
+
+private:
+  struct Request {
+    uint32_t wait_frames;
+    uint32_t width;
+    uint32_t height;
+    VkFormat texel_fmt;
+    uint32_t texel_size;
+    std::shared_ptr<void> pinned;  // tightly packed rows, hipHostMalloc
+  };
+
+  ReadBackID next_request_id = 0;
+  std::unordered_map<ReadBackID, Request> requests;
+  std::unordered_map<ReadBackID, ReadBackData> processed_requests;
+};
+
+// ---- capture writers (main.cpp:118-176); `path` replaces the hard-coded "captures/..." names ----
+// "y, 0,1,...\n" header, then one "y,0x<hex24>,...\n" row per image row
+void write_depth_csv(const ReadBackData &image, const std::string &path);
+// depth words masked to 24 bits, written as a 4-channel PNG (R = low byte)
+bool write_depth_png(ReadBackData &image, const std::string &path);
+// RGBA8 with alpha forced to 255
+bool write_rgba_png(ReadBackData &image, const std::string &path);
+// 8-bit PNG encoder used by the two above (stored deflate blocks: byte-exact pixels, no compression)
+bool write_png_rgba8(const std::string &path, uint32_t width, uint32_t height, const uint8_t *rgba);
+
+
+#endif

@@ -1,86 +1,3 @@
-// scene.hpp — the compiled scene the raster stage draws: the subset of src/scene/scene.hpp:11-87 that
-// SceneRenderer reads (interleaved vertex / index buffers, primitives, materials, node tree, textures with
-// their mip chains).  The reference fills it from a glTF file through tinygltf + stb_image
-// (scene/scene.cpp:144-361, scene/images.cpp:20-60), neither of which is in this image; here it is
-// filled from plain arrays (`make_scene`), e.g. by vk-renderer_amd/scene.py, which follows the same
-// loading rules.
-#ifndef SCENE_HPP_INCLUDED
-#define SCENE_HPP_INCLUDED
-
-#include <memory>
-#include <vector>
-
-#include "glm_compat.hpp"
-#include "gpu/gpu.hpp"
-
-namespace scene {
-
-constexpr uint32_t INVALID_TEXTURE = ~0u;
-
-struct Vertex {
-  glm::vec3 pos;
-  glm::vec3 norm;
-  glm::vec2 uv;
-};
-static_assert(sizeof(Vertex) == sizeof(vkr_raster_vertex), "Vertex must match the C-ABI");
-
-struct Primitive {
-  uint32_t vertex_offset;
-  uint32_t index_offset;
-  uint32_t index_count;
-  uint32_t material_index;
-};
-
-struct BaseMesh {
-  std::vector<Primitive> primitives;
-};
-
-struct BaseNode {
-  glm::mat4 transform;
-  std::vector<BaseNode> children;
-  int mesh_index;
-};
-
-struct Material {
-  uint32_t albedo_tex_index = INVALID_TEXTURE;
-  uint32_t metalic_roughness_index = INVALID_TEXTURE;
-  bool clip_alpha = false;
-  float alpha_cutoff = 0.f;
-};
-
-struct Texture {
-  uint32_t image_index;
-  uint32_t sampler_index;
-};
-
-struct CompiledScene {
-  gpu::BufferPtr vertex_buffer;
-  gpu::BufferPtr index_buffer;
-  std::vector<gpu::ImagePtr> images;
-  std::vector<VkSampler> samplers;
-  std::vector<Texture> textures;
-  std::vector<Material> materials;
-  std::vector<BaseMesh> root_meshes;
-  std::vector<BaseNode> base_nodes;
-};
-
-// one mip chain of RGBA8 texels, level 0 first, rows tightly packed
-struct TextureData {
-  uint32_t width, height, mip_levels;
-  const uint8_t *levels[VKR_MAX_MIPS];
-};
-
-// Flat description of a scene: node i draws mesh i (one primitive) with material i.
-struct FlatDraw {
-  glm::mat4 transform;
-  uint32_t vertex_offset, index_offset, index_count;
-  uint32_t albedo_tex_index, metalic_roughness_index;
-  bool clip_alpha;
-};
-
-CompiledScene make_scene(const Vertex *vertices, uint32_t vertex_count, const uint32_t *indices, uint32_t index_count,
-                         const FlatDraw *draws, uint32_t draw_count, const TextureData *textures, uint32_t texture_count);
-
-}
-
-#endif
+// scene.hpp — kept so that `#include "scene.hpp"` of the reference's sources resolves; the declarations live in passes.hpp.
+#pragma once
+#include "passes.hpp"
