@@ -377,6 +377,19 @@ int vkr_synth_gbuffer(const vkr_img* depth, const vkr_img* normal, const vkr_img
                       const vkr_img* material, const vkr_img* velocity,
                       const vkr_synth_params* params, void* stream);
 
+/* Multi-GPU exchange helper (the reference is single-GPU, so there is no program this
+ * replaces): copies `count` pitch-linear byte rectangles on `stream`, VKR_MAX_RECTS per launch.  Used to pack
+ * a tile's surfaces for the all-gather, to scatter the gathered tiles into the whole-frame images and to
+ * pack / unpack the halo rings of the history surfaces.  Addresses are device addresses; addresses, pitches
+ * and row lengths must be multiples of 4 bytes (16 selects the wide path).  `rects` is host memory.       */
+#define VKR_MAX_RECTS 64
+typedef struct vkr_rect_copy {
+  uint64_t src, dst;
+  uint32_t src_pitch, dst_pitch; /* bytes between rows */
+  uint32_t row_bytes, rows;
+} vkr_rect_copy;
+int vkr_copy_rects(const vkr_rect_copy* rects, uint32_t count, void* stream);
+
 /* float4 streaming-read microbenchmark: the measured-roofline denominator of
  * SURVEY.md 8(d).  Reads `bytes` from `src`, writes one float per block to `sink`.      */
 int vkr_stream_read(const void* src, uint64_t bytes, float* sink, uint32_t sink_len, void* stream);

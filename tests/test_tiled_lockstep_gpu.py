@@ -1,7 +1,7 @@
 """The multi-GPU configuration on ONE GPU: every rank of a 2x2 (and a 2x1) grid is an in-process TiledFrame over its own
 window (tile + halo, origin != 0) driven through the C++ host mirror and the HIP kernels; the exchanges are played by
 copying the packed buffers between the in-process ranks (same pack / unpack code as the RCCL path, only the wire is
-replaced).  After two frames every rank's tile interior must equal the plain single-GPU frame bit for bit — this is
+replaced).  After three frames every rank's tile interior must equal the plain single-GPU frame bit for bit — this is
 the windowed addressing of every kernel, the whole-frame Hi-Z / normals / albedo path and the history halos, on the
 product."""
 import numpy as np
@@ -13,33 +13,34 @@ OUTPUTS = (("rays", 1), ("raw", 1), ("reflections", 1), ("filtered", 1), ("blurr
            ("dn", 1), ("dv", 1), ("depth", 0))
 
 
+def _move_halos(ranks, which):
+    """what the point-to-point sends deliver: every receive buffer gets the matching send buffer of its neighbour"""
+    for r, t in enumerate(ranks):
+        for nb, _, rbuf in t.halo_peers(which):
+            if rbuf is not None:
+                sbuf = [p for p in ranks[nb].halo_peers(which) if p[0] == r][0][1]
+                assert sbuf.numel() == rbuf.numel()
+                rbuf.copy_(sbuf)
+
+
 def _lockstep_frame(ranks):
+    """Advances every rank's TiledFrame.phases() — the production frame order — one exchange point at a time and
+    plays the wire in between."""
     world = len(ranks)
-    for t in ranks:
-        t.backend.run_stage("downsample")
-    for group, stages_before, stages_after in (("hiz", ("taa",), ("trace", "gtao")), ("albedo", (), ("ssr_resolve",))):
-        packed = [t.gather_pack(group) for t in ranks]
-        for t in ranks:
-            for st in stages_before:
-                t.backend.run_stage(st)
-        for r, t in enumerate(ranks):
-            send, recv, plan, sizes, chunk = packed[r]
-            for src in range(world):  # what all_gather_into_tensor delivers
-                recv[src * chunk: (src + 1) * chunk].copy_(packed[src][0])
-            t.gather_unpack(plan, sizes, chunk, recv)
-            for st in stages_after:
-                t.backend.run_stage(st)
-    for t in ranks:
-        t.backend.end_frame()
-    plans = [t.halo_pack() for t in ranks]
-    for r, plan in enumerate(plans):
-        for nb, send, sbuf, recv, rbuf in plan:
-            if recv:  # the matching send buffer of neighbour `nb` towards rank r
-                peer = [p for p in plans[nb] if p[0] == r][0]
-                assert peer[2].numel() == rbuf.numel()
-                rbuf.copy_(peer[2])
-    for t, plan in zip(ranks, plans):
-        t.halo_unpack(plan)
+    gens = [t.phases() for t in ranks]
+    while True:
+        ops = [next(g, None) for g in gens]
+        if ops[0] is None:
+            assert all(o is None for o in ops)
+            return
+        kind = ops[0][0]
+        assert all(o[0] == kind for o in ops), "ranks diverged"
+        if kind == "gather_wait":  # what all_gather_into_tensor delivers
+            for _, g in ops:
+                for src in range(world):
+                    g.recv[src * g.chunk: (src + 1) * g.chunk].copy_(ops[src][1].send)
+        elif kind == "halo_wait":
+            _move_halos(ranks, ops[0][1])
 
 
 @pytest.mark.parametrize("grid", [(2, 1), (2, 2)])
@@ -57,7 +58,7 @@ def test_tiled_ranks_match_single_gpu_frame(grid):
 
     plain = TiledFrame(FrameSetup(W, H), 0, 1, 1, 1, device)
     plain.prepare()
-    for _ in range(2):
+    for _ in range(3):
         plain.step()
     plain.backend.sync()
     want = {n: plain.frame.download(n) for n, _ in OUTPUTS}
@@ -67,8 +68,12 @@ def test_tiled_ranks_match_single_gpu_frame(grid):
     for t in ranks:
         assert t.tiled and t.window != (0, 0, W, H)
         t.prepare()
-    for _ in range(2):
+    for _ in range(3):  # the third frame reuses the exchange plans cached for the first (ping-pong parity)
         _lockstep_frame(ranks)
+    for which in ("taa", "ao", "ssr"):  # the refreshes the last frame left in flight
+        _move_halos(ranks, which)
+    for t in ranks:
+        t.flush()
     torch.cuda.synchronize()
     bad = 0
     for r, t in enumerate(ranks):

@@ -34,6 +34,7 @@ def test_tiled_path_on_one_rank_matches_plain_frame():
             t.prepare()
             for _ in range(2):  # second frame consumes the histories written by the first
                 t.step()
+            t.flush()
             t.backend.sync()
             results.append({n: t.frame.download(n).to_host().copy() for n in OUTPUTS})
             if force:

@@ -1,6 +1,6 @@
 """Multi-process tiling rehearsed on the CPU: world_size 2 and 4 over gloo, compute
 backend = oracle.  Every rank's tile interior must equal the single-process whole-frame result
-bit for bit after two frames (all-gather of Hi-Z / normals / albedo + history halo exchange)."""
+bit for bit after three frames (all-gather of Hi-Z / normals / albedo + history halo exchange)."""
 import os
 import socket
 import subprocess
@@ -28,11 +28,12 @@ WORKER = textwrap.dedent("""
     setup = FrameSetup(W, H)
     t = TiledFrame(setup, rank, world, cols, rows, None, backend=binding.OracleBackend, halo=64)
     t.prepare()
-    for _ in range(2):
+    for _ in range(3):  # the third frame reuses the exchange plans cached for the first (ping-pong parity)
         t.step()
+    t.flush()
     ref = PostFxChain(W, H, backend='oracle', setup=setup)
     ref.synth(); ref.build_prev_hiz(); ref.init_histories(); ref.preintegrate_pdf()
-    for _ in range(2):
+    for _ in range(3):
         ref.frame(); ref.swap_histories()
     x0, y0, tw, th = t.tile
     c = t.backend.chain

@@ -219,6 +219,11 @@ ENTRY_ARGS = {
 }
 
 
+class RectCopy(C.Structure):  # vkr_rect_copy
+    _fields_ = [("src", C.c_uint64), ("dst", C.c_uint64), ("src_pitch", C.c_uint32), ("dst_pitch", C.c_uint32),
+                ("row_bytes", C.c_uint32), ("rows", C.c_uint32)]
+
+
 class ExtensionMissing(RuntimeError):
     pass
 
@@ -249,6 +254,8 @@ def product():
             fn.restype = C.c_int
         lib.vkr_stream_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.vkr_stream_read.restype = C.c_int
+        lib.vkr_copy_rects.argtypes = [P(RectCopy), C.c_uint32, C.c_void_p]
+        lib.vkr_copy_rects.restype = C.c_int
         lib.vkr_raster_scratch_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         lib.vkr_raster_scratch_bytes.restype = C.c_uint64
         lib.vkr_halton23_fill.argtypes = [C.c_void_p, C.c_uint32]

@@ -480,27 +480,34 @@ __global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
     v2f acc_r = {0.0f, 0.0f}, acc_g = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f}, acc_w = {0.0f, 0.0f};
     f4 edgeA = mk4(0, 0, 0, 0), edgeB = mk4(0, 0, 0, 0);
     v2f ei = e_edge, rho_i = rho_edge;
-    const v2f zero2 = {0.0f, 0.0f}, one2 = {1.0f, 1.0f};
     const v2f kcd = kb * cd;  // bilateral term: 1 - min(|k*cd - k*d|, 1)
+    // The normalisation g is applied once after the loop, so every running weight E(i)*E(j)*nw*bil
+    // stays in [0, 1] and the two max(., 0) of the shader become the free `clamp` output modifier.
 #pragma unroll 1
     for (int i = -r; i <= r; i++) {
-      const v2f gi = g2 * ei;
       const int col = tcA + i;
       // unpaired ends of the column: A's row -r and B's row +r (tcB + r*TW = tcA + (r+1)*TW)
-      blur_tap(s_nd, s_refl, c[0], col - r * BLUR_TW, gi.x * e_edge.x, edgeA);
-      blur_tap(s_nd, s_refl, c[1], col + (r + 1) * BLUR_TW, gi.y * e_edge.y, edgeB);
-      v2f wj = gi * ej_first, rho_j = rhoj_first;  // running g * E(i) * E(j)
+      blur_tap(s_nd, s_refl, c[0], col - r * BLUR_TW, ei.x * e_edge.x, edgeA);
+      blur_tap(s_nd, s_refl, c[1], col + (r + 1) * BLUR_TW, ei.y * e_edge.y, edgeB);
+      v2f wj = ei * ej_first, rho_j = rhoj_first;  // running E(i) * E(j)
       int t = col - (r - 1) * BLUR_TW;
 #pragma unroll 2
       for (int j = -r + 1; j <= r; j++, t += BLUR_TW) {
         const float4 nd = s_nd[t];
         const uint32_t colr = s_refl[t];
-        const v2f kdz = __builtin_elementwise_fma(-kb, splat2(nd.w), kcd);
-        const v2f m = __builtin_elementwise_min(__builtin_elementwise_abs(kdz), one2);
-        v2f nw = __builtin_elementwise_fma(cnz, splat2(nd.z), __builtin_elementwise_fma(cny, splat2(nd.y), cnx * splat2(nd.x)));
-        nw = __builtin_elementwise_max(nw, zero2);
+        const v2f nzw = {nd.z, nd.w};
+        const v2f nxy = __builtin_elementwise_fma(cny, splat2(nd.y), cnx * splat2(nd.x));
+        v2f nw, kdz;
+        // nw = clamp(cnz * n.z + nxy): v_pk_* has no max, the clamp modifier does it for free
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] clamp" : "=v"(nw) : "v"(cnz), "v"(nzw), "v"(nxy));
+        // kdz = kcd - kb * n.w (both lanes read the high half of {n.z, n.w})
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+            : "=v"(kdz) : "v"(kb), "v"(nzw), "v"(kcd));
         const v2f tw = wj * nw;
-        const v2f w = __builtin_elementwise_fma(-m, tw, tw);  // wj * nw * (1 - m)
+        // tw * max(1 - |kdz|, 0) = clamp(tw - |kdz| * tw) since 0 <= tw <= 1: one v_fma_f32 with |.| and clamp
+        v2f w;
+        w.x = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(kdz.x), tw.x, tw.x), 0.0f), 1.0f);
+        w.y = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(kdz.y), tw.y, tw.y), 0.0f), 1.0f);
         acc_r = __builtin_elementwise_fma(w, splat2((float)(colr & 0xFFu)), acc_r);
         acc_g = __builtin_elementwise_fma(w, splat2((float)((colr >> 8) & 0xFFu)), acc_g);
         acc_b = __builtin_elementwise_fma(w, splat2((float)((colr >> 16) & 0xFFu)), acc_b);
@@ -510,7 +517,9 @@ __global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
       ei *= rho_i; rho_i *= kappa;
     }
     accA = mk4(acc_r.x + edgeA.x, acc_g.x + edgeA.y, acc_b.x + edgeA.z, acc_w.x + edgeA.w);
+    accA = mk4(accA.x * g2.x, accA.y * g2.x, accA.z * g2.x, accA.w * g2.x);
     accB = mk4(acc_r.y + edgeB.x, acc_g.y + edgeB.y, acc_b.y + edgeB.z, acc_w.y + edgeB.w);
+    accB = mk4(accB.x * g2.y, accB.y * g2.y, accB.z * g2.y, accB.w * g2.y);
   }
 
 #pragma unroll

@@ -12,9 +12,17 @@ are served from whole-frame copies:
       on every rank; the coarser Hi-Z mips are then rebuilt locally.  Both are issued
       asynchronously right after the downsample: TAA (independent of them) runs while the first
       is in flight, the trace and GTAO while the second is.
-  exchange B (every frame, after the history remaps):  the halo ring of the three history
-      surfaces (TAA, accumulated AO, blurred reflections) is refreshed from the neighbours'
-      interiors with point-to-point sends (up to 8 neighbours).
+  exchange B (every frame, one per history surface):  the halo ring of the TAA output, the
+      accumulated AO and the blurred reflections is refreshed from the neighbours' interiors with
+      point-to-point sends (up to 8 neighbours).  Each is issued right after the pass that
+      produces the surface and awaited right before the pass that consumes it in the NEXT frame,
+      so the transfer hides behind everything in between.
+
+Every pack / scatter step is one launch of the C-ABI's vkr_copy_rects (a fixed list of byte rectangles,
+built once per ping-pong parity of the history images), not a torch op per surface and neighbour: at eight
+ranks that is 10 launches per frame instead of ~70.  `TiledFrame.phases()` is the single definition of the
+frame order; it yields wherever bytes must cross ranks, and the caller moves them — RCCL in `step()`, plain
+copies between in-process ranks in the lockstep test.
 
 Collectives go through torch.distributed: backend "nccl" is RCCL over xGMI on the GPU box,
 "gloo" in the CPU tests (which plug their own compute backend into TiledFrame).  No data-path collective is
@@ -113,8 +121,12 @@ class TiledFrame:
         self.frame = self.backend.frame
         self.device = self.backend.device
         self._xchg_s = 0.0
-        self._gather_buf = {}
-        self._halo_cache = None
+        self._frame_no = 0       # history images ping-pong: every address-dependent plan is cached per parity
+        self._gather_cache = {}
+        self._halo_cache = {}
+        self._halo_bufs = {}
+        self._halo_packed = {}   # surface -> plan whose send buffers are filled and whose receive is outstanding
+        self._halo_works = {}
         self.stage_plan = None  # single-GPU only: list of stage masks run per step instead of STAGE_CHAIN
 
     # ---- set-up ---------------------------------------------------------------------------------
@@ -145,6 +157,47 @@ class TiledFrame:
         a[..., 1] = 1.0 / 255.0
 
     # ---- one frame ----------------------------------------------------------------------------------
+    def phases(self):
+        """The tiled frame, as a generator that yields wherever bytes must cross ranks:
+            ("gather_start", g)  g.send is packed: start all_gather(g.recv <- every rank's g.send)
+            ("gather_wait", g)   g.recv must be complete before resuming (it is scattered next)
+            ("halo_start", s)    surface s: the send buffers of halo_peers(s) are packed: start the sends / receives
+            ("halo_wait", s)     the receive buffers of surface s (started in the PREVIOUS frame) must be complete
+        downsample -> [gather Hi-Z + normals || TAA] -> trace -> GTAO -> [gather albedo, in flight since the
+        downsample] -> filter, blur.  GTAO only needs the trace's (occlusion, pdf), not the albedo, so it runs
+        ahead of the reference's order to hide more of the second gather."""
+        b = self.backend
+        b.run_stage("downsample")
+        hiz = self.gather_pack("hiz")
+        yield "gather_start", hiz
+        albedo = self.gather_pack("albedo")
+        yield "gather_start", albedo
+        yield "halo_wait", "taa"
+        self.halo_unpack("taa")
+        b.run_stage("taa")
+        self.halo_pack("taa")
+        yield "halo_start", "taa"
+        yield "gather_wait", hiz
+        hiz.unpack.run()
+        b.run_stage("trace")
+        yield "halo_wait", "ao"
+        self.halo_unpack("ao")
+        b.run_stage("gtao")
+        self.halo_pack("ao")
+        yield "halo_start", "ao"
+        yield "gather_wait", albedo
+        albedo.unpack.run()
+        yield "halo_wait", "ssr"
+        self.halo_unpack("ssr")
+        b.run_stage("ssr_resolve")
+        self.halo_pack("ssr")
+        yield "halo_start", "ssr"
+        self.end_frame()
+
+    def end_frame(self):
+        self.backend.end_frame()
+        self._frame_no += 1
+
     def step(self):
         if not self.tiled:
             if self.stage_plan:
@@ -152,31 +205,30 @@ class TiledFrame:
                     self.frame.run(mask)
             else:
                 self.backend.run_all()
-            self.backend.end_frame()
+            self.end_frame()
             return
-        # downsample -> [gather Hi-Z + normals || TAA] -> trace -> GTAO -> [gather albedo, in flight since
-        # the downsample] -> filter, blur.  GTAO only needs the trace's (occlusion, pdf), not the albedo,
-        # so it runs ahead of the reference's order to hide more of the second gather.  The collectives
-        # run on the communicator's own stream; wait() only orders the compute stream behind them.
-        self.backend.run_stage("downsample")
-        t0 = time.perf_counter()
-        pending_hiz = self.gather_start("hiz")
-        pending_albedo = self.gather_start("albedo")
-        self._xchg_s += time.perf_counter() - t0
-        self.backend.run_stage("taa")
-        t0 = time.perf_counter()
-        self.gather_finish(pending_hiz)
-        self._xchg_s += time.perf_counter() - t0
-        self.backend.run_stage("trace")
-        self.backend.run_stage("gtao")
-        t0 = time.perf_counter()
-        self.gather_finish(pending_albedo)
-        self._xchg_s += time.perf_counter() - t0
-        self.backend.run_stage("ssr_resolve")
-        self.backend.end_frame()
-        t0 = time.perf_counter()
-        self.exchange_history_halos()
-        self._xchg_s += time.perf_counter() - t0
+        # The collectives run on the communicator's own stream; wait() only orders the compute stream behind
+        # them, the host never blocks.
+        for op, arg in self.phases():
+            t0 = time.perf_counter()
+            if op == "gather_start":
+                arg.work = dist.all_gather_into_tensor(arg.recv, arg.send, async_op=True)
+            elif op == "gather_wait":
+                if arg.work is not None:
+                    arg.work.wait()
+            elif op == "halo_start":
+                self._halo_works[arg] = self._halo_issue(arg)
+            else:  # halo_wait
+                for work in self._halo_works.pop(arg, ()):
+                    work.wait()
+            self._xchg_s += time.perf_counter() - t0
+
+    def flush(self):
+        """Completes the halo exchanges the last frame left in flight (call before reading results / stopping a clock)."""
+        for which in list(self._halo_packed):
+            for work in self._halo_works.pop(which, ()):
+                work.wait()
+            self.halo_unpack(which)
 
     def exchange_ms(self, steps):
         """host-side time spent issuing exchanges per step (device time shows in ms_per_step)"""
@@ -190,8 +242,17 @@ class TiledFrame:
         return [("albedo", 0, "frame_albedo", 0, 0)]
 
     def gather_pack(self, group):
-        """Packs this tile's share of `group` into the send buffer -> (send, recv, plan, sizes, chunk).  The collective
-        itself is separate so that a test harness can move the bytes between in-process ranks instead."""
+        """Packs this tile's share of `group` into the send buffer and returns the exchange's state: .send / .recv
+        (recv = [rank][send bytes]) and .unpack, the scatter of the received tiles into the whole-frame images.
+        The collective itself is separate so that a test harness can move the bytes between in-process ranks."""
+        key = (group, self._frame_no & 1)
+        g = self._gather_cache.get(key)
+        if g is None:
+            g = self._gather_cache[key] = self._build_gather(group)
+        g.pack.run()
+        return g
+
+    def _build_gather(self, group):
         plan = self._gather_plan(group)
         x0, y0, tw, th = self.tile
         sizes = []
@@ -199,48 +260,29 @@ class TiledFrame:
             _, bpp, _ = self.backend.rows(src, mip)
             sizes.append((th >> dv) * (tw >> dv) * bpp)
         chunk = sum(sizes)
-        if group not in self._gather_buf:
-            self._gather_buf[group] = (torch.empty(chunk, dtype=torch.uint8, device=self.device),
-                                       torch.empty(chunk * self.world, dtype=torch.uint8, device=self.device))
-        send, recv = self._gather_buf[group]
-        off = 0
-        for (src, mip, _, _, dv), n in zip(plan, sizes):
+        other = self._gather_cache.get((group, 1 - (self._frame_no & 1)))
+        if other is not None:  # both parities share the buffers
+            send, recv = other.send, other.recv
+        else:
+            send = torch.empty(chunk, dtype=torch.uint8, device=self.device)
+            recv = torch.empty(chunk * self.world, dtype=torch.uint8, device=self.device)
+        per_rank = recv.view(self.world, chunk)
+        pack, unpack, off = [], [], 0
+        for (src, mip, dst, dmip, dv), n in zip(plan, sizes):
             rows, bpp, (ox, oy, _, _) = self.backend.rows(src, mip)
             lx, ly, w, h = (x0 >> dv) - ox, (y0 >> dv) - oy, tw >> dv, th >> dv
-            send[off: off + n].view(h, w * bpp).copy_(rows[ly: ly + h, lx * bpp: (lx + w) * bpp])
+            pack.append((send[off: off + n].view(h, w * bpp), rows[ly: ly + h, lx * bpp: (lx + w) * bpp]))
+            # recv is [rank][surface bytes]; rank r sits at column r % cols, row r // cols of the grid
+            frows, fbpp, (fox, foy, _, _) = self.backend.rows(dst, dmip)
+            assert fox == 0 and foy == 0 and fbpp == bpp, "whole-frame images start at the frame origin"
+            for r in range(self.world):
+                cx, cy = r % self.cols, r // self.cols
+                unpack.append((frows[cy * h: (cy + 1) * h, cx * w * bpp: (cx + 1) * w * bpp], per_rank[r, off: off + n].view(h, w * bpp)))
             off += n
-        return send, recv, plan, sizes, chunk
-
-    def gather_start(self, group):
-        """Packs and issues the all-gather asynchronously."""
-        send, recv, plan, sizes, chunk = self.gather_pack(group)
-        work = dist.all_gather_into_tensor(recv, send, async_op=True)
-        return work, plan, sizes, chunk, recv
-
-    def gather_finish(self, pending):
-        """Orders the compute stream behind the collective and scatters the tiles into the frame images."""
-        work, plan, sizes, chunk, recv = pending
-        work.wait()
-        self.gather_unpack(plan, sizes, chunk, recv)
-
-    def gather_unpack(self, plan, sizes, chunk, recv):
-        # one strided copy per surface: recv is [rank = (row, col)][surface bytes]; the frame image is
-        # [row][y][col][x bytes] (rank r sits at column r % cols, row r // cols of the grid)
-        per_rank = recv.view(self.world, chunk)
-        off = 0
-        for (_, _, dst, dmip, dv), n in zip(plan, sizes):
-            rows, bpp, (ox, oy, _, _) = self.backend.rows(dst, dmip)
-            assert ox == 0 and oy == 0, "whole-frame images start at the frame origin"
-            w, h = self.tw >> dv, self.th >> dv
-            src = per_rank[:, off: off + n].view(self.rows_n, self.cols, h, w * bpp)
-            out = rows[: self.rows_n * h, : self.cols * w * bpp].unflatten(0, (self.rows_n, h)).unflatten(2, (self.cols, w * bpp))
-            out.copy_(src.permute(0, 2, 1, 3))
-            off += n
-
-    def exchange_gather(self):
-        """Both groups back to back (kept for callers that do not overlap)."""
-        for group in ("hiz", "albedo"):
-            self.gather_finish(self.gather_start(group))
+        g = _Gather()
+        g.send, g.recv, g.chunk, g.work = send, recv, chunk, None
+        g.pack, g.unpack = RectBatch(pack, self.device), RectBatch(unpack, self.device)
+        return g
 
     # ---- exchange B: history halos -------------------------------------------------------------------
     def _neighbours(self):
@@ -258,57 +300,95 @@ class TiledFrame:
         x1, y1 = min(a[0] + a[2], b[0] + b[2]), min(a[1] + a[3], b[1] + b[3])
         return (x0, y0, x1 - x0, y1 - y0) if x1 > x0 and y1 > y0 else None
 
-    def _halo_plan(self):
-        """Static geometry of exchange B: per neighbour, the slices of each history surface to send (my
-        interior inside its window) and to receive (its interior inside my window), packed back to back
-        in one persistent buffer per direction."""
-        if self._halo_cache is not None:
-            return self._halo_cache
-        plan = []
-        for dx, dy, nb in self._neighbours():
-            send, recv, sbytes, rbytes = [], [], 0, 0
-            for name, dv in (("taa_hist", 0), ("acc_hist", 1), ("blurred_hist", 1)):
-                _, bpp, (ox, oy, ww, wh) = self.backend.rows(name)
-                mine = tuple(v >> dv for v in self.tile)
-                nb_tile = tuple(v >> dv for v in tile_rect(nb, self.cols, self.rows_n, self.tw, self.th))
-                nb_win = tuple(v >> dv for v in window_rect(nb, self.cols, self.rows_n, self.tw, self.th, self.halo))
-                s = self._overlap(mine, nb_win)
-                if s:
-                    send.append((name, s[1] - oy, s[3], (s[0] - ox) * bpp, s[2] * bpp, sbytes))
-                    sbytes += s[3] * s[2] * bpp
-                r = self._overlap(nb_tile, (ox, oy, ww, wh))
-                if r:
-                    recv.append((name, r[1] - oy, r[3], (r[0] - ox) * bpp, r[2] * bpp, rbytes))
-                    rbytes += r[3] * r[2] * bpp
-            plan.append((nb, send, torch.empty(max(sbytes, 1), dtype=torch.uint8, device=self.device),
-                         recv, torch.empty(max(rbytes, 1), dtype=torch.uint8, device=self.device)))
-        self._halo_cache = plan
+    def _halo_plan(self, which):
+        """Geometry of the halo refresh of one history surface: per neighbour, the slice to send (my interior inside
+        its window) and to receive (its interior inside my window), one persistent buffer per neighbour and
+        direction.  The surface is addressed by the name of the pass OUTPUT (it becomes the history at the remap)."""
+        key = (which, self._frame_no & 1)
+        plan = self._halo_cache.get(key)
+        if plan is not None:
+            return plan
+        name, dv = HALO_SURFACES[which]
+        rows, bpp, (ox, oy, ww, wh) = self.backend.rows(name)
+        bufs = self._halo_bufs.setdefault(which, {})
+        mine = tuple(v >> dv for v in self.tile)
+        pack, unpack, peers = [], [], []
+        for _, _, nb in self._neighbours():
+            nb_tile = tuple(v >> dv for v in tile_rect(nb, self.cols, self.rows_n, self.tw, self.th))
+            nb_win = tuple(v >> dv for v in window_rect(nb, self.cols, self.rows_n, self.tw, self.th, self.halo))
+            s, r = self._overlap(mine, nb_win), self._overlap(nb_tile, (ox, oy, ww, wh))
+            if nb not in bufs:
+                bufs[nb] = (torch.empty(s[2] * s[3] * bpp if s else 0, dtype=torch.uint8, device=self.device),
+                            torch.empty(r[2] * r[3] * bpp if r else 0, dtype=torch.uint8, device=self.device))
+            sbuf, rbuf = bufs[nb]
+            if s:
+                pack.append((sbuf.view(s[3], s[2] * bpp), rows[s[1] - oy: s[1] - oy + s[3], (s[0] - ox) * bpp: (s[0] - ox + s[2]) * bpp]))
+            if r:
+                unpack.append((rows[r[1] - oy: r[1] - oy + r[3], (r[0] - ox) * bpp: (r[0] - ox + r[2]) * bpp], rbuf.view(r[3], r[2] * bpp)))
+            peers.append((nb, sbuf if s else None, rbuf if r else None))
+        plan = self._halo_cache[key] = _Halo()
+        plan.pack, plan.unpack, plan.peers = RectBatch(pack, self.device), RectBatch(unpack, self.device), peers
         return plan
 
-    def halo_pack(self):
-        """Fills every neighbour's send buffer -> the plan [(neighbour, send slices, send buffer, recv slices, recv buffer)]."""
-        plan = self._halo_plan()
-        rows = {name: self.backend.rows(name)[0] for name in ("taa_hist", "acc_hist", "blurred_hist")}
-        for nb, send, sbuf, recv, rbuf in plan:
-            for name, y, h, xb, wb, off in send:
-                sbuf[off: off + h * wb].view(h, wb).copy_(rows[name][y: y + h, xb: xb + wb])
-        return plan
+    def halo_pack(self, which):
+        """Fills every neighbour's send buffer with this frame's output of surface `which` -> [(neighbour, send buffer |
+        None, receive buffer | None)].  The matching halo_unpack happens in the next frame, into the same image."""
+        assert which not in self._halo_packed, "the previous halo exchange of this surface was never completed"
+        plan = self._halo_plan(which)
+        plan.pack.run()
+        self._halo_packed[which] = plan
+        return plan.peers
 
-    def halo_unpack(self, plan):
-        rows = {name: self.backend.rows(name)[0] for name in ("taa_hist", "acc_hist", "blurred_hist")}
-        for nb, send, sbuf, recv, rbuf in plan:
-            for name, y, h, xb, wb, off in recv:
-                rows[name][y: y + h, xb: xb + wb].copy_(rbuf[off: off + h * wb].view(h, wb))
+    def halo_peers(self, which):
+        return self._halo_packed[which].peers if which in self._halo_packed else []
 
-    def exchange_history_halos(self):
-        plan = self.halo_pack()
+    def halo_unpack(self, which):
+        plan = self._halo_packed.pop(which, None)
+        if plan is not None:
+            plan.unpack.run()
+
+    def _halo_issue(self, which):
         ops = []
-        for nb, send, sbuf, recv, rbuf in plan:
-            if send:
+        for nb, sbuf, rbuf in self.halo_peers(which):
+            if sbuf is not None:
                 ops.append(dist.P2POp(dist.isend, sbuf, nb))
-            if recv:
+            if rbuf is not None:
                 ops.append(dist.P2POp(dist.irecv, rbuf, nb))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        self.halo_unpack(plan)
+        return dist.batch_isend_irecv(ops) if ops else []
+
+
+HALO_SURFACES = {"taa": ("taa_target", 0), "ao": ("acc_ao", 1), "ssr": ("blurred", 1)}  # pass output, divisor
+
+
+class _Gather:
+    pass
+
+
+class _Halo:
+    pass
+
+
+class RectBatch:
+    """A fixed list of byte-rectangle copies [(dst, src)], uint8 [rows, row bytes] views with a row pitch.  On the
+    GPU the list is one vkr_copy_rects launch on the current stream; host tensors (gloo tests) are copied one by one."""
+
+    def __init__(self, pairs, device):
+        self.pairs = pairs
+        self.device = device if device is not None and torch.device(device).type == "cuda" else None
+        for dst, src in pairs:
+            assert dst.shape == src.shape and dst.dtype == src.dtype == torch.uint8 and dst.dim() == 2
+            assert dst.shape[1] == 0 or (dst.stride(1) == 1 and src.stride(1) == 1)
+        if self.device is not None and pairs:
+            self.table = (abi.RectCopy * len(pairs))()
+            for i, (dst, src) in enumerate(pairs):
+                self.table[i] = abi.RectCopy(src.data_ptr(), dst.data_ptr(), src.stride(0), dst.stride(0), src.shape[1], src.shape[0])
+
+    def run(self):
+        if not self.pairs:
+            return
+        if self.device is None:
+            for dst, src in self.pairs:
+                dst.copy_(src)
+            return
+        lib = abi.product()
+        abi.check(lib.vkr_copy_rects(self.table, len(self.pairs), torch.cuda.current_stream(self.device).cuda_stream), lib)
