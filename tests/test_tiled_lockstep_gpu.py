@@ -1,4 +1,4 @@
-"""The multi-GPU configuration on ONE GPU: every rank of a 2x2 (and a 2x1) grid is an in-process TiledFrame over its own
+"""The multi-GPU configuration on ONE GPU: every rank of a grid (2-D: 2x1, 2x2; strips: 1x2, 1x4) is an in-process TiledFrame over its own
 window (tile + halo, origin != 0) driven through the C++ host mirror and the HIP kernels; the exchanges are played by
 copying the packed buffers between the in-process ranks (same pack / unpack code as the RCCL path, only the wire is
 replaced).  After three frames every rank's tile interior must equal the plain single-GPU frame bit for bit — this is
@@ -37,13 +37,14 @@ def _lockstep_frame(ranks):
         assert all(o[0] == kind for o in ops), "ranks diverged"
         if kind == "gather_wait":  # what all_gather_into_tensor delivers
             for _, g in ops:
-                for src in range(world):
-                    g.recv[src * g.chunk: (src + 1) * g.chunk].copy_(ops[src][1].send)
+                for i, (_, recv) in enumerate(g.parts):
+                    for src in range(world):
+                        recv.view(world, -1)[src].copy_(ops[src][1].parts[i][0])
         elif kind == "halo_wait":
             _move_halos(ranks, ops[0][1])
 
 
-@pytest.mark.parametrize("grid", [(2, 1), (2, 2)])
+@pytest.mark.parametrize("grid", [(2, 1), (2, 2), (1, 2), (1, 4)])  # 2-D grids: packed gathers; strips: in place
 def test_tiled_ranks_match_single_gpu_frame(grid):
     import torch
 

@@ -23,7 +23,7 @@ WORKER = textwrap.dedent("""
     binding.install()
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     dist.init_process_group('gloo')
-    cols, rows = grid_for(world)
+    cols, rows = (int(v) for v in os.environ['VKR_GRID'].split('x'))
     W, H = 128 * cols, 144 * rows
     setup = FrameSetup(W, H)
     t = TiledFrame(setup, rank, world, cols, rows, None, backend=binding.OracleBackend, halo=64)
@@ -66,11 +66,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_tiled_frame_matches_single_process(world, tmp_path, oracle_lib):
+@pytest.mark.parametrize("grid", ["1x2", "2x1", "2x2"])  # strips gather in place, 2-D grids pack and scatter
+def test_tiled_frame_matches_single_process(grid, tmp_path, oracle_lib):
+    world = int(grid[0]) * int(grid[2])
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2", VKR_GRID=grid)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -78,10 +79,16 @@ def test_tiled_frame_matches_single_process(world, tmp_path, oracle_lib):
 
 
 def test_grid_and_windows():
-    from vk_renderer_amd.tiling import grid_for, tile_rect, window_rect
+    from vk_renderer_amd.tiling import grid_for
 
-    assert grid_for(1) == (1, 1) and grid_for(2) == (2, 1) and grid_for(4) == (2, 2) and grid_for(8) == (4, 2)
-    cols, rows = grid_for(8)
+    assert grid_for(1) == (1, 1) and grid_for(2) == (1, 2) and grid_for(4) == (1, 4) and grid_for(8) == (1, 8)
+    for cols, rows in (grid_for(8), (4, 2)):
+        _check_grid(cols, rows)
+
+
+def _check_grid(cols, rows):
+    from vk_renderer_amd.tiling import tile_rect, window_rect
+
     seen = set()
     for r in range(8):
         x0, y0, w, h = tile_rect(r, cols, rows, 3840, 2160)

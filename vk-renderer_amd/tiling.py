@@ -40,7 +40,11 @@ GATHER_MIPS = 4    # depth image-mips 1..4 are tile-aligned for tiles divisible 
 
 
 def grid_for(world):
-    return {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}.get(world, (world, 1))
+    """Horizontal strips, one tile per rank stacked top to bottom.  A strip's share of every whole-frame surface is a
+    run of whole rows, i.e. contiguous, so the all-gathers deliver in place with no pack and no scatter; 2-D grids
+    (still supported by TiledFrame) balance a little better but pay 2 x the gathered bytes in HBM copies per frame
+    (tools/lockstep_profile.py: slowest rank 1.19 ms for 1x8 vs 1.16 ms + ~0.25 ms of copies for 4x2)."""
+    return (1, world)
 
 
 def tile_rect(rank, cols, rows, tw, th):
@@ -159,8 +163,8 @@ class TiledFrame:
     # ---- one frame ----------------------------------------------------------------------------------
     def phases(self):
         """The tiled frame, as a generator that yields wherever bytes must cross ranks:
-            ("gather_start", g)  g.send is packed: start all_gather(g.recv <- every rank's g.send)
-            ("gather_wait", g)   g.recv must be complete before resuming (it is scattered next)
+            ("gather_start", g)  for (send, recv) in g.parts: start all_gather(recv <- every rank's send), recv = [rank][send bytes]
+            ("gather_wait", g)   every recv of g.parts must be complete before resuming
             ("halo_start", s)    surface s: the send buffers of halo_peers(s) are packed: start the sends / receives
             ("halo_wait", s)     the receive buffers of surface s (started in the PREVIOUS frame) must be complete
         downsample -> [gather Hi-Z + normals || TAA] -> trace -> GTAO -> [gather albedo, in flight since the
@@ -212,16 +216,24 @@ class TiledFrame:
         for op, arg in self.phases():
             t0 = time.perf_counter()
             if op == "gather_start":
-                arg.work = dist.all_gather_into_tensor(arg.recv, arg.send, async_op=True)
+                arg.works = self._all_gather(arg.parts)
             elif op == "gather_wait":
-                if arg.work is not None:
-                    arg.work.wait()
+                for work in arg.works:
+                    work.wait()
             elif op == "halo_start":
                 self._halo_works[arg] = self._halo_issue(arg)
             else:  # halo_wait
                 for work in self._halo_works.pop(arg, ()):
                     work.wait()
             self._xchg_s += time.perf_counter() - t0
+
+    @staticmethod
+    def _all_gather(parts):
+        """One collective launch for all (send, recv) pairs of a group: every call into torch.distributed costs ~35 us of
+        host time, and with strips a group is up to five surfaces."""
+        if len(parts) == 1:
+            return [dist.all_gather_into_tensor(parts[0][1], parts[0][0], async_op=True)]
+        return [dist.group.WORLD.allgather_into_tensor_coalesced([recv for _, recv in parts], [send for send, _ in parts])]
 
     def flush(self):
         """Completes the halo exchanges the last frame left in flight (call before reading results / stopping a clock)."""
@@ -242,17 +254,40 @@ class TiledFrame:
         return [("albedo", 0, "frame_albedo", 0, 0)]
 
     def gather_pack(self, group):
-        """Packs this tile's share of `group` into the send buffer and returns the exchange's state: .send / .recv
-        (recv = [rank][send bytes]) and .unpack, the scatter of the received tiles into the whole-frame images.
-        The collective itself is separate so that a test harness can move the bytes between in-process ranks."""
+        """Prepares this tile's share of `group` for the all-gather and returns the exchange's state: .parts =
+        [(send, recv)] with recv = [rank][send bytes], and .unpack, what is left to do once the bytes have arrived.
+        The collective itself is separate so that a test harness can move the bytes between in-process ranks.
+
+        Strips (cols == 1): a tile's rows of every surface are contiguous in the window image AND in the whole-frame
+        image (same width, same pitch), so each surface is gathered in place — send = the tile's rows where they lie,
+        recv = the frame image itself; nothing is packed and nothing is scattered.
+        2-D grids: the surfaces are packed into one send buffer (one copy_rects launch), gathered with one collective
+        and scattered into the frame images (one more launch)."""
         key = (group, self._frame_no & 1)
         g = self._gather_cache.get(key)
         if g is None:
-            g = self._gather_cache[key] = self._build_gather(group)
+            g = self._gather_cache[key] = self._build_gather_in_place(group) if self.cols == 1 else self._build_gather_packed(group)
         g.pack.run()
         return g
 
-    def _build_gather(self, group):
+    def _build_gather_in_place(self, group):
+        x0, y0, tw, th = self.tile
+        parts = []
+        for src, mip, dst, dmip, dv in self._gather_plan(group):
+            rows, bpp, (ox, oy, w, _) = self.backend.rows(src, mip)
+            frows, fbpp, (fox, foy, fw, fh) = self.backend.rows(dst, dmip)
+            h = th >> dv
+            assert ox == 0 and fox == 0 and foy == 0 and w == fw == tw >> dv and fh == h * self.world and fbpp == bpp
+            assert rows.stride(0) == frows.stride(0), "strips are gathered in place: window and frame images must share the row pitch"
+            ly = (y0 >> dv) - oy
+            parts.append((rows[ly: ly + h].reshape(-1), frows[: fh].reshape(-1)))  # both are views: rows are whole pitches
+            assert parts[-1][0].data_ptr() == rows[ly].data_ptr() and parts[-1][1].data_ptr() == frows.data_ptr()
+        g = _Gather()
+        g.parts, g.works = parts, []
+        g.pack, g.unpack = RectBatch([], self.device), RectBatch([], self.device)
+        return g
+
+    def _build_gather_packed(self, group):
         plan = self._gather_plan(group)
         x0, y0, tw, th = self.tile
         sizes = []
@@ -262,7 +297,7 @@ class TiledFrame:
         chunk = sum(sizes)
         other = self._gather_cache.get((group, 1 - (self._frame_no & 1)))
         if other is not None:  # both parities share the buffers
-            send, recv = other.send, other.recv
+            send, recv = other.parts[0]
         else:
             send = torch.empty(chunk, dtype=torch.uint8, device=self.device)
             recv = torch.empty(chunk * self.world, dtype=torch.uint8, device=self.device)
@@ -280,7 +315,7 @@ class TiledFrame:
                 unpack.append((frows[cy * h: (cy + 1) * h, cx * w * bpp: (cx + 1) * w * bpp], per_rank[r, off: off + n].view(h, w * bpp)))
             off += n
         g = _Gather()
-        g.send, g.recv, g.chunk, g.work = send, recv, chunk, None
+        g.parts, g.works = [(send, recv)], []
         g.pack, g.unpack = RectBatch(pack, self.device), RectBatch(unpack, self.device)
         return g
 
