@@ -421,35 +421,77 @@ __global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
   const int bx0 = a.out.ox + blk.x * BLUR_BX - BLUR_R;  // frame coordinates of the tile origin
   const int by0 = a.out.oy + blk.y * BLUR_BY - BLUR_R;
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
-  for (int t = tid; t < BLUR_TW * BLUR_TH; t += BLUR_THREADS) {
+
+  // Global loads are issued in batches and decoded afterwards, so that a wave pays one memory latency per
+  // batch instead of one per sample: (1) the velocity of its two pixels, (2) the raw texels of the <= 6 tile
+  // pixels it stages, (3) everything else its two pixels need (roughness, centre normal, the reprojection
+  // test's depths, the history colour).  The tap loop and the epilogue then run from registers and LDS only.
+  const int lx = blk.x * BLUR_BX + threadIdx.x;
+  const int lyA = blk.y * BLUR_BY + 2 * threadIdx.y;
+  const bool live = lx < a.out.w && lyA < a.out.h;  // (whole blocks past the window do not exist; rows / columns may)
+  const bool has_b = lyA + 1 < a.out.h;
+  f2 uv_c[2];
+  BilinearTaps velocity_taps[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int gx = a.out.ox + min(lx, a.out.w - 1), gy = a.out.oy + min(lyA + k, a.out.h - 1);
+    uv_c[k] = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
+    velocity_taps[k] = bilinear_taps_u32(a.velocity, uv_c[k]);
+  }
+
+  constexpr int STAGE_ITERS = (BLUR_TW * BLUR_TH + BLUR_THREADS - 1) / BLUR_THREADS;
+  BilinearTaps stage_normal[STAGE_ITERS];
+  uint32_t stage_depth[STAGE_ITERS], stage_refl[STAGE_ITERS];
+#pragma unroll
+  for (int k = 0; k < STAGE_ITERS; k++) {
+    const int t = min(tid + k * BLUR_THREADS, BLUR_TW * BLUR_TH - 1);  // the last batch re-stages the last pixel
     const int tx = t % BLUR_TW, ty = t / BLUR_TW;
     const int px = bx0 + tx, py = by0 + ty;
     const f2 uv = mk2((float)px / tex_size.x, (float)py / tex_size.y);
-    const f3 n = decode_normal_fast(sample<FmtRG16U>(a.normal, uv));  // only enters the normal weight
-    s_nd[t] = make_float4(n.x, n.y, n.z, fetch<FmtD24>(a.depth1, px, py));
-    // texelFetch out of the frame -> 0
-    const bool inside = px >= 0 && py >= 0 && px < a.refl.fw && py < a.refl.fh;
-    s_refl[t] = inside ? *texel_ptr<const uint32_t>(a.refl, iclamp(px - a.refl.ox, 0, a.refl.w - 1), iclamp(py - a.refl.oy, 0, a.refl.h - 1)) : 0u;
+    stage_normal[k] = bilinear_taps_u32(a.normal, uv);
+    // texelFetch out of the frame -> 0 (the loads themselves are clamped into the window)
+    const bool in_depth = px >= 0 && py >= 0 && px < a.depth1.fw && py < a.depth1.fh;
+    const bool in_refl = px >= 0 && py >= 0 && px < a.refl.fw && py < a.refl.fh;
+    const uint32_t d = load_u32_clamped(a.depth1, px, py), c = load_u32_clamped(a.refl, px, py);
+    stage_depth[k] = in_depth ? d : 0u;  // D24 word 0 decodes to 0.0f
+    stage_refl[k] = in_refl ? c : 0u;
   }
-  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < STAGE_ITERS; k++) {
+    const int t = min(tid + k * BLUR_THREADS, BLUR_TW * BLUR_TH - 1);
+    const f3 n = decode_normal_fast(taps_resolve<FmtRG16U>(stage_normal[k]));  // only enters the normal weight
+    s_nd[t] = make_float4(n.x, n.y, n.z, FmtD24::decode(stage_depth[k]));
+    s_refl[t] = stage_refl[k];
+  }
 
-  const int lx = blk.x * BLUR_BX + threadIdx.x;
-  const int lyA = blk.y * BLUR_BY + 2 * threadIdx.y;
-  if (lx >= a.out.w || lyA >= a.out.h) return;
-  const bool has_b = lyA + 1 < a.out.h;
-
-  // per-pixel set-up (blur.comp:34-55) for A and B
-  BlurCentre c[2];
-  f2 uv_c[2];
+  // (3): prev_uv needs the velocity, which has arrived by now
+  f2 velocity[2], prev_uv[2];
+  BilinearTaps rough_taps[2], normal_taps[2], depth_taps[2], prev_depth_taps[2], history_taps[2];
 #pragma unroll
   for (int k = 0; k < 2; k++) {
-    const int gx = a.out.ox + lx, gy = a.out.oy + lyA + k;
-    uv_c[k] = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
-    float roughness = sample_srgb_channel(a.material, uv_c[k], 1, s_lut);
+    velocity[k] = taps_resolve<FmtRG16F>(velocity_taps[k]);
+    prev_uv[k] = uv_c[k] + velocity[k];
+    const f2 safe_prev = mk2(vclamp(prev_uv[k].x, 0.0f, 1.0f), vclamp(prev_uv[k].y, 0.0f, 1.0f));  // only consumed when prev_uv is inside
+    rough_taps[k] = bilinear_taps_u32(a.material, uv_c[k]);
+    normal_taps[k] = bilinear_taps_u32(a.normal, uv_c[k]);
+    depth_taps[k] = bilinear_taps_u32(a.depth1, uv_c[k]);
+    prev_depth_taps[k] = bilinear_taps_u32(a.hist_depth1, safe_prev);
+    history_taps[k] = bilinear_taps_u32(a.history, uv_c[k]);  // screen_uv, not prev_uv (blur.comp:103)
+  }
+  __syncthreads();
+  if (!live) return;
+
+  // per-pixel set-up (blur.comp:34-55) and the temporal test (blur.comp:79-105) for A and B
+  BlurCentre c[2];
+  bool reprojected[2];
+  f3 history_color[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    float roughness = taps_srgb_channel(rough_taps[k], 1, s_lut);
     roughness = mixf(0.0f, a.max_roughness, roughness);
     c[k].tc = (2 * threadIdx.y + k + BLUR_R) * BLUR_TW + (threadIdx.x + BLUR_R);
     c[k].depth = s_nd[c[k].tc].w;
-    c[k].normal = decode_normal_fast(sample<FmtRG16U>(a.normal, uv_c[k]));
+    c[k].normal = decode_normal_fast(taps_resolve<FmtRG16U>(normal_taps[k]));
     float sigma = mixf(0.4f, 4.0f, roughness);
     if (a.disable_blur != 0) sigma = 0.35f;
     c[k].r = min(f2i(floorf(3.0f * sigma - 0.01f)), BLUR_R);
@@ -457,6 +499,22 @@ __global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
     const float e = (2.0f * sigma) * sigma;
     c[k].neg_inv_e_log2 = -1.4426950408889634f / e;
     c[k].k_bilateral = 1000.0f / c[k].depth;
+
+    reprojected[k] = false;
+    const f2 screen_uv = uv_c[k];
+    const float delta_len = length(velocity[k]);
+    if (prev_uv[k].x >= 0.0f && prev_uv[k].y >= 0.0f && prev_uv[k].x <= 1.0f && prev_uv[k].y <= 1.0f) {
+      const f3 vc = reconstruct_view_vec(screen_uv, taps_resolve<FmtD24>(depth_taps[k]), a.pr);
+      const f3 v_world_cur = xyz(mul(a.inverse_camera, mk4(vc.x, vc.y, vc.z, 1.0f)));
+      const f3 vp = reconstruct_view_vec(prev_uv[k], taps_resolve<FmtD24>(prev_depth_taps[k]), a.pr);
+      const f3 v_world_prev = xyz(mul(a.prev_inverse_camera, mk4(vp.x, vp.y, vp.z, 1.0f)));
+      const f3 v_camera = xyz(mul(a.inverse_camera, mk4(0, 0, 0, 1)));
+      const float error = length(v_world_cur - v_world_prev);
+      const float pixel_dist = length(v_world_cur - v_camera);
+      reprojected[k] = (delta_len < 0.0001f) || (error < vclamp((0.1f * pixel_dist) * delta_len, 0.01f, 0.1f));
+    }
+    if (a.accumulate == 0) reprojected[k] = false;
+    history_color[k] = taps_resolve<FmtRGBA8>(history_taps[k]);
   }
 
   f4 accA, accB = mk4(0, 0, 0, 0);
@@ -528,27 +586,7 @@ __global__ __launch_bounds__(BLUR_THREADS) void k_sssr_blur(BlurArgs a) {
     const f4 acc = k == 0 ? accA : accB;
     f3 color = mk3(acc.x, acc.y, acc.z) * (1.0f / 255.0f);
     color = color / vmax(acc.w, 0.001f);
-    const f2 screen_uv = uv_c[k];
-    // temporal part (blur.comp:79-105)
-    bool reprojected = false;
-    const f2 velocity = sample<FmtRG16F>(a.velocity, screen_uv);
-    const float delta_len = length(velocity);
-    const f2 prev_uv = screen_uv + velocity;
-    if (prev_uv.x >= 0.0f && prev_uv.y >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y <= 1.0f) {
-      const f3 vc = reconstruct_view_vec(screen_uv, sample<FmtD24>(a.depth1, screen_uv), a.pr);
-      const f3 v_world_cur = xyz(mul(a.inverse_camera, mk4(vc.x, vc.y, vc.z, 1.0f)));
-      const f3 vp = reconstruct_view_vec(prev_uv, sample<FmtD24>(a.hist_depth1, prev_uv), a.pr);
-      const f3 v_world_prev = xyz(mul(a.prev_inverse_camera, mk4(vp.x, vp.y, vp.z, 1.0f)));
-      const f3 v_camera = xyz(mul(a.inverse_camera, mk4(0, 0, 0, 1)));
-      const float error = length(v_world_cur - v_world_prev);
-      const float pixel_dist = length(v_world_cur - v_camera);
-      reprojected = (delta_len < 0.0001f) || (error < vclamp((0.1f * pixel_dist) * delta_len, 0.01f, 0.1f));
-    }
-    if (a.accumulate == 0) reprojected = false;
-    if (reprojected) {
-      const f3 history_color = sample<FmtRGBA8>(a.history, screen_uv);  // screen_uv, not prev_uv (blur.comp:103)
-      color = mix3(history_color, color, 0.1f);
-    }
+    if (reprojected[k]) color = mix3(history_color[k], color, 0.1f);
     *texel_ptr<uint32_t>(a.out, lx, lyA + k) =
         float_to_unorm8(color.x) | (float_to_unorm8(color.y) << 8) | (float_to_unorm8(color.z) << 16);
   }

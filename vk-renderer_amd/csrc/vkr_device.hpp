@@ -182,7 +182,8 @@ struct Pyramid {
 };
 
 struct FmtD24 { typedef float T; static VKR_DEV T zero() { return 0.0f; }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { return d24_to_float(*(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4)); }
+  static VKR_DEV T decode(uint32_t v) { return d24_to_float(v); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4)); }
   static VKR_DEV T lerp(T a, T b, float f) { return mixf(a, b, f); } };
 struct FmtR32F { typedef float T; static VKR_DEV T zero() { return 0.0f; }
   static VKR_DEV T load(const Tex& t, int lx, int ly) { return *(const float*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4); }
@@ -191,12 +192,12 @@ struct FmtR16F { typedef float T; static VKR_DEV T zero() { return 0.0f; }
   static VKR_DEV T load(const Tex& t, int lx, int ly) { return half_bits_to_float(*(const uint16_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 2)); }
   static VKR_DEV T lerp(T a, T b, float f) { return mixf(a, b, f); } };
 struct FmtRG16U { typedef f2 T; static VKR_DEV T zero() { return mk2(0, 0); }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint32_t v = *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);
-    return mk2(unorm16_to_float(v & 0xFFFFu), unorm16_to_float(v >> 16)); }
+  static VKR_DEV T decode(uint32_t v) { return mk2(unorm16_to_float(v & 0xFFFFu), unorm16_to_float(v >> 16)); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4)); }
   static VKR_DEV T lerp(T a, T b, float f) { return mix2(a, b, f); } };
 struct FmtRG16F { typedef f2 T; static VKR_DEV T zero() { return mk2(0, 0); }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint32_t v = *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);
-    return mk2(half_bits_to_float(v & 0xFFFFu), half_bits_to_float(v >> 16)); }
+  static VKR_DEV T decode(uint32_t v) { return mk2(half_bits_to_float(v & 0xFFFFu), half_bits_to_float(v >> 16)); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4)); }
   static VKR_DEV T lerp(T a, T b, float f) { return mix2(a, b, f); } };
 // rgb of an RGBA8_SRGB texel (alpha is never consumed on this path)
 struct FmtSRGB8 { typedef f3 T; static VKR_DEV T zero() { return mk3(0, 0, 0); }
@@ -204,8 +205,8 @@ struct FmtSRGB8 { typedef f3 T; static VKR_DEV T zero() { return mk3(0, 0, 0); }
     return mk3(srgb8_to_float(v & 0xFFu), srgb8_to_float((v >> 8) & 0xFFu), srgb8_to_float((v >> 16) & 0xFFu)); }
   static VKR_DEV T lerp(T a, T b, float f) { return mix3(a, b, f); } };
 struct FmtRGBA8 { typedef f3 T; static VKR_DEV T zero() { return mk3(0, 0, 0); }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint32_t v = *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);
-    return mk3(unorm8_to_float(v & 0xFFu), unorm8_to_float((v >> 8) & 0xFFu), unorm8_to_float((v >> 16) & 0xFFu)); }
+  static VKR_DEV T decode(uint32_t v) { return mk3(unorm8_to_float(v & 0xFFu), unorm8_to_float((v >> 8) & 0xFFu), unorm8_to_float((v >> 16) & 0xFFu)); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4)); }
   static VKR_DEV T lerp(T a, T b, float f) { return mix3(a, b, f); } };
 struct FmtRGBA16U { typedef f4 T; static VKR_DEV T zero() { return mk4(0, 0, 0, 0); }
   static VKR_DEV T load(const Tex& t, int lx, int ly) { uint2 v = *(const uint2*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 8);
@@ -278,7 +279,18 @@ VKR_DEV BilinearTaps bilinear_taps_u32(const Tex& t, f2 uv) {
   b.t01 = load_u32_clamped(t, x0, y0 + 1); b.t11 = load_u32_clamped(t, x0 + 1, y0 + 1);
   return b;
 }
+// The value sample<F>(tex, uv) returns, from taps issued earlier: lets a kernel put the loads of several
+// samples in flight together and decode them once they have arrived (one memory latency instead of one each).
+template <class F> VKR_DEV typename F::T taps_resolve(const BilinearTaps& b) {
+  return F::lerp(F::lerp(F::decode(b.t00), F::decode(b.t10), b.fx), F::lerp(F::decode(b.t01), F::decode(b.t11), b.fx), b.fy);
+}
 // one channel (0 = r, 1 = g, 2 = b) of texture() on an RGBA8_SRGB image
+VKR_DEV float taps_srgb_channel(const BilinearTaps& b, int channel, const float* lut) {
+  const int sh = channel * 8;
+  const float a00 = lut[(b.t00 >> sh) & 0xFFu], a10 = lut[(b.t10 >> sh) & 0xFFu];
+  const float a01 = lut[(b.t01 >> sh) & 0xFFu], a11 = lut[(b.t11 >> sh) & 0xFFu];
+  return mixf(mixf(a00, a10, b.fx), mixf(a01, a11, b.fx), b.fy);
+}
 VKR_DEV float sample_srgb_channel(const Tex& t, f2 uv, int channel, const float* lut) {
   const BilinearTaps b = bilinear_taps_u32(t, uv);
   const int sh = channel * 8;
