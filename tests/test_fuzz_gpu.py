@@ -39,7 +39,7 @@ STAGES = [("downsample", ("depth", "dn", "dv")), ("ssr_trace", ("rays", "raw")),
           ("gtao_main", ("raw",)), ("gtao_filter", ("filtered",)), ("gtao_accumulate", ("acc_ao",)), ("taa", ("taa_target",))]
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(16))
 def test_random_parameters_stagewise(seed, oracle_lib):
     import torch
 

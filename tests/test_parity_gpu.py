@@ -85,7 +85,7 @@ def test_pdf_lut(oracle_lib):
     assert n == 0
 
 
-@pytest.mark.parametrize("size", [(256, 144), (640, 360), (1920, 1080), (500, 282), (70, 38)])
+@pytest.mark.parametrize("size", [(256, 144), (640, 360), (1920, 1080), (500, 282), (70, 38), (206, 226)])  # 206x226: half-res 103x113, floor-dispatch extent 96x112 (uv -> texel map stretched by 7 %)
 def test_chain_stagewise(size, oracle_lib):
     """Each pass gets bit-identical inputs (the oracle's), so a failure names the pass."""
     ref, gpu = _pair(*size, oracle_lib)

@@ -44,14 +44,24 @@ VKR_DEV float tile_sample(const DepthTile& t, f2 uv) {
   return mixf(mixf(p[0], p[1], fx), mixf(p[GT_TW], p[GT_TW + 1], fx), fy);
 }
 
+// texture(depth, uv) of the main pass.  TILED: from the LDS tile, valid when screen_uv maps pixel (x, y) onto
+// texel (x, y), i.e. when the floor-dispatch extent equals the image extent (every size divisible by 8 x 4: all
+// benchmark configurations).  Ragged sizes stretch the uv -> texel map by fw / tex_w (main.comp:54 derives tex_size
+// from gl_NumWorkGroups), the samples of a block then leave its tile, and the pass reads global memory instead.
+template <bool TILED> VKR_DEV float depth_sample(const DepthTile& t, const Tex& depth, f2 uv) {
+  if (TILED) return tile_sample(t, uv);
+  return sample<FmtD24>(depth, uv);
+}
+
 // main.comp:84-108
-VKR_DEV float find_horizon(const DepthTile& depth, const Proj& pr, f2 start, f3 camera_start, f2 dir, f3 v) {
+template <bool TILED>
+VKR_DEV float find_horizon(const DepthTile& depth, const Tex& depth_tex, const Proj& pr, f2 start, f3 camera_start, f2 dir, f3 v) {
   float h_cos = -1.0f;
   float previous_z = camera_start.z;
 #pragma unroll 1
   for (int i = 1; i <= 16; i++) {
     f2 tc = start + ((float)i / 16.0f) * dir;
-    float sample_depth = tile_sample(depth, tc);
+    float sample_depth = depth_sample<TILED>(depth, depth_tex, tc);
     f3 sample_pos = reconstruct_view_vec(tc, sample_depth, pr);
     if (sample_pos.z > previous_z + 0.1f) break;  // MAX_THIKNESS, main.comp:82
     previous_z = sample_pos.z;
@@ -66,6 +76,7 @@ VKR_DEV float find_horizon(const DepthTile& depth, const Proj& pr, f2 start, f3 
 // One thread per half-res pixel.  The slice-direction pattern repeats every 4x4 pixels
 // (main.comp:276-278), so its 16 (cos,sin) pairs are kernel arguments evaluated once on the host
 // instead of per pixel.
+template <bool TILED>
 __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
   const i2 blk = xcd_block<2, 4>();  // chunks of 128 x 64 output pixels
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
@@ -77,8 +88,9 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
   tile.x0 = a.out.ox + blk.x * GT_BX - GT_R;
   tile.y0 = a.out.oy + blk.y * GT_BY - GT_R;
   tile.fw = (float)a.depth.fw; tile.fh = (float)a.depth.fh;
-  for (int t = tid; t < GT_TW * GT_TH; t += GT_BX * GT_BY)
-    s_depth[t] = fetch_clamped<FmtD24>(a.depth, tile.x0 + t % GT_TW, tile.y0 + t / GT_TW);
+  if (TILED)
+    for (int t = tid; t < GT_TW * GT_TH; t += GT_BX * GT_BY)
+      s_depth[t] = fetch_clamped<FmtD24>(a.depth, tile.x0 + t % GT_TW, tile.y0 + t / GT_TW);
   __syncthreads();
   const int lx = blk.x * GT_BX + threadIdx.x;
   const int ly = blk.y * GT_BY + threadIdx.y;
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
   float occ_x = 0.0f, occ_y = pdf_uniform;
   uint2* dst = texel_ptr<uint2>(a.out, lx, ly);
 
-  const float frag_depth = tile_sample(tile, screen_uv);
+  const float frag_depth = depth_sample<TILED>(tile, a.depth, screen_uv);
   if (frag_depth >= 1.0f) {  // sky: mis -> (0,1), non-mis -> 0 (main.comp:187-189,221-223)
     occ_x = 0.0f;
     occ_y = a.use_mis ? 1.0f : pdf_uniform;
@@ -112,13 +124,23 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
       const f2 cs = mk2(a.slice_cs[di][dir_slot][0], a.slice_cs[di][dir_slot][1]);
       const f2 sample_direction = dir_radius * cs;
       const f3 sample_end_pos = reconstruct_view_vec(screen_uv + sample_direction, frag_depth, a.pr);
-      const f3 slice_normal = normalize_fast(cross(w0, -sample_end_pos));
-      const f3 normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
-      const f3 X = -normalize_fast(cross(slice_normal, w0));
+      f3 slice_normal = normalize_fast(cross(w0, -sample_end_pos));
+      f3 normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
+      f3 X = -normalize_fast(cross(slice_normal, w0));
       const float np_len2 = dot(normal_projected, normal_projected);
-      const float np_len = fast_sqrt(np_len2);
-      const float n = VKR_PI / 2.0f - acosf(dot(normal_projected, X) * fast_rsq(np_len2));
-      const float h_cos = find_horizon(tile, a.pr, screen_uv, camera_pos, sample_direction, w0);
+      float np_len = fast_sqrt(np_len2);
+      float n_cos = dot(normal_projected, X) * fast_rsq(np_len2);
+      if (!(fabsf(n_cos) <= 0.9999f)) {
+        // acos cliff (surface seen edge-on in this slice): whether the argument rounds past +-1 — NaN in the shader,
+        // which zeroes the slice's arc — is decided by its last bit, so this rare case takes the exact sequence
+        slice_normal = normalize(cross(w0, -sample_end_pos));
+        normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
+        X = -normalize(cross(slice_normal, w0));
+        n_cos = dot(normalize(normal_projected), X);
+        np_len = length(normal_projected);
+      }
+      const float n = VKR_PI / 2.0f - acosf(n_cos);
+      const float h_cos = find_horizon<TILED>(tile, a.depth, a.pr, screen_uv, camera_pos, sample_direction, w0);
       float h = acosf(h_cos);
       h = vmin(n + vmin(h - n, VKR_PI / 2.0f), h);
       const float arc = vmax((-cosf(2.0f * h - n) + cosf(n)) + (2.0f * h) * sinf(n), 0.0f);
@@ -286,7 +308,10 @@ extern "C" int vkr_gtao_main(const vkr_img* depth, const vkr_gtao_params* params
     }
   }
   dim3 block(GT_BX, GT_BY);
-  hipLaunchKernelGGL(k_gtao_main, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  if (a.tex_w == a.out.fw && a.tex_h == a.out.fh && same_window(a.depth, a.out))
+    hipLaunchKernelGGL(k_gtao_main<true>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(k_gtao_main<false>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   return launch_status("gtao_main");
 }
 
