@@ -183,7 +183,8 @@ def test_defered_shading(size, oracle_lib):
     _compare(ref, gpu, ("taa_target",), budget=1e-4)
 
 
-def test_host_mirror_frame_with_shading(oracle_lib):
+@pytest.mark.parametrize("size", [(640, 360), (206, 226)])  # the second: ragged against every workgroup size
+def test_host_mirror_frame_with_shading(size, oracle_lib):
     """The C++ host mirror (rendergraph + pass structs, host/frame.cpp) drives the whole frame including the
     deferred-shading composite; every output must match the oracle driven through the flat Python chain."""
     import torch
@@ -192,7 +193,7 @@ def test_host_mirror_frame_with_shading(oracle_lib):
     from vk_renderer_amd.camera import FrameSetup
     from parity import mismatches
 
-    W, H = 640, 360
+    W, H = size
     setup = FrameSetup(W, H)
     frame = host.HostFrame(setup, device="cuda")
     frame.run(host.STAGE_LUT | host.STAGE_BRDF_LUT | host.STAGE_GBUFFER | host.STAGE_PREV_DEPTH)
