@@ -105,6 +105,9 @@ def main():
                     help="N=1 only: run the multi-GPU code path (RCCL gathers, staged frame) on a one-rank group")
     ap.add_argument("--tile", type=str, default=f"{TILE_W}x{TILE_H}", help="per-GPU tile, WxH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="let the rendergraph spread independent passes of a frame over several streams (measured slower: "
+                         "the passes are VALU-bound, see DESIGN.md section 3)")
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c5"],
                     help="BASELINE.json configs: c1 1920x1080 GTAO main only (non-MIS); c2 3840x2160 composite (default, the "
                          "metric's config); c3 7680x4320 composite (analytic scene: Sponza.bin is absent from the reference mount); "
@@ -149,6 +152,7 @@ def main():
     setup = FrameSetup(W, H, use_mis=0 if args.config == "c1" else 1)
     tiled = TiledFrame(setup, rank, world, cols, rows, device, force_tiled=args.rehearse_tiled)
     frame = tiled.frame
+    frame.set_async(args.overlap)
     if args.config == "c1":      # GTAO main pass only (BASELINE configs[0]); non-MIS: 1+4 read, 2 written = 7 B/px
         tiled.stage_plan = [host.STAGE_GTAO_MAIN_ONLY]
         BYTES_PER_PX["GTAO_main"] = 7.0

@@ -87,3 +87,31 @@ def test_capture_writers(tmp_path):
     col = np.array(Image.open(tmp_path / "color.png"))
     assert np.array_equal(col[..., 0], (x & 0xFF).astype(np.uint8)) and np.array_equal(col[..., 1], (y & 0xFF).astype(np.uint8))
     assert np.array_equal(col[..., 2], ((x ^ y) & 0xFF).astype(np.uint8)) and np.all(col[..., 3] == 255)
+
+
+@pytest.mark.gpu
+def test_async_lanes_follow_declared_hazards():
+    """RenderGraph::set_async(true): the tasks of one submission spread over stream lanes along the hazards of their
+    declared accesses — SSR chain on the frame's stream, the GTAO chain (needs the trace's output) on a second lane,
+    TAA (needs only the pyramid) on a third — and the frame's outputs stay bit-identical to the one-stream frame."""
+    import numpy as np
+
+    from vk_renderer_amd import host
+    from vk_renderer_amd.camera import FrameSetup
+
+    outs = {}
+    for overlap in (False, True):
+        frame = host.HostFrame(FrameSetup(512, 288), device="cuda")
+        frame.set_async(overlap)
+        frame.run(host.STAGE_LUT | host.STAGE_GBUFFER | host.STAGE_PREV_DEPTH)
+        for _ in range(3):
+            frame.run(host.STAGE_CHAIN)
+            tasks, lanes = frame.last_tasks(), frame.last_lanes()
+            frame.end_frame()
+        assert tasks == ["DownsampleGbuffer", "DownsampleDepth", "SSSR_trace", "SSSR_filter", "SSSR_blur", "GTAO_main", "GTAO_filter",
+                         "GTAO_accumulate", "TAA"]
+        assert lanes == ([0, 0, 0, 0, 0, 1, 1, 1, 2] if overlap else [0] * 9)
+        outs[overlap] = {n: frame.download(n).to_host().copy() for n in ("rays", "raw", "reflections", "blurred_hist", "filtered", "acc_hist", "taa_hist")}
+        frame.close()
+    for n in outs[False]:
+        assert np.array_equal(outs[False][n], outs[True][n]), f"{n}: overlapped frame differs from the one-stream frame"

@@ -64,6 +64,9 @@ def lib():
                                       C.POINTER(SceneTexture), C.c_uint32]
         l.vkrh_last_tasks.argtypes = [C.c_void_p]
         l.vkrh_last_tasks.restype = C.c_char_p
+        l.vkrh_last_lanes.argtypes = [C.c_void_p]
+        l.vkrh_last_lanes.restype = C.c_char_p
+        l.vkrh_set_async.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_enable_task_timing.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_collect_task_times.argtypes = [C.c_void_p]
         l.vkrh_collect_task_times.restype = C.c_char_p
@@ -210,6 +213,14 @@ class HostFrame:
 
     def last_tasks(self):
         return lib().vkrh_last_tasks(self.h).decode().split()
+
+    def last_lanes(self):
+        """stream lane (0 = the frame's stream) of each task of the last run()"""
+        return [int(v) for v in lib().vkrh_last_lanes(self.h).decode().split()]
+
+    def set_async(self, on):
+        """False (default): one in-order stream.  True: independent passes of one run() overlap on up to three streams."""
+        self._check(lib().vkrh_set_async(self.h, 1 if on else 0))
 
     def download(self, name, layer=None):
         """Copies the named image (or one layer of an array image) into a host ImageBuf with the same layout rules (tests)."""

@@ -53,7 +53,7 @@ struct PostFxFrame {
   DrawTAAParams draw_params{};
   glm::mat4 projection, view, prev_view;
   bool has_camera = false;
-  std::string task_names;
+  std::string task_names, task_lanes;
 
   explicit PostFxFrame(const vkrh_config& c)
       : cfg{c}, graph{c.stream}, init{graph, c},
@@ -151,6 +151,8 @@ struct PostFxFrame {
     graph.submit();
     task_names.clear();
     for (const auto& n : graph.last_submitted_tasks()) { task_names += n; task_names += '\n'; }
+    task_lanes.clear();
+    for (uint32_t l : graph.last_submitted_lanes()) { task_lanes += std::to_string(l); task_lanes += ' '; }
   }
 
   void end_frame(bool swap_depth) {  // main.cpp:416-420
@@ -435,5 +437,7 @@ int vkrh_selftest_errors(char* buf, uint32_t buf_size) {
   return 0;
 }
 const char* vkrh_last_tasks(void* frame) { return ((PostFxFrame*)frame)->task_names.c_str(); }
+const char* vkrh_last_lanes(void* frame) { return ((PostFxFrame*)frame)->task_lanes.c_str(); }
+int vkrh_set_async(void* frame, uint32_t on) { return guarded([&] { ((PostFxFrame*)frame)->graph.set_async(on != 0); }); }
 
 }  // extern "C"

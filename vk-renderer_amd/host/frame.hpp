@@ -105,6 +105,10 @@ const char* vkrh_collect_task_times(void* frame);
 int vkrh_selftest_errors(char* buf, uint32_t buf_size);
 /* names of the tasks executed by the last vkrh_run, '\n'-separated */
 const char* vkrh_last_tasks(void* frame);
+/* the stream lane (0 = the frame's stream) each of those tasks was recorded on, space separated */
+const char* vkrh_last_lanes(void* frame);
+/* 0 (default): every task on the frame's stream; 1: independent tasks of one vkrh_run spread over up to three streams */
+int vkrh_set_async(void* frame, uint32_t on);
 
 #ifdef __cplusplus
 }
