@@ -6,7 +6,6 @@ import os
 import numpy as np
 import pytest
 
-from vk_renderer_amd import abi
 from vk_renderer_amd import scene as scn
 from vk_renderer_amd.camera import FrameSetup
 from vk_renderer_amd.chain import PostFxChain

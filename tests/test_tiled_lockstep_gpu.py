@@ -4,7 +4,6 @@ copying the packed buffers between the in-process ranks (same pack / unpack code
 replaced).  After three frames every rank's tile interior must equal the plain single-GPU frame bit for bit — this is
 the windowed addressing of every kernel, the whole-frame Hi-Z / normals / albedo path and the history halos, on the
 product."""
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
