@@ -227,10 +227,17 @@ class TiledFrame:
                     work.wait()
             self._xchg_s += time.perf_counter() - t0
 
-    @staticmethod
-    def _all_gather(parts):
+    def _host_driven_backend_fence(self):
+        """RCCL enqueues its kernels behind everything already recorded on the compute stream, so buffers handed to a
+        collective are ordered by the streams alone.  A host-driven backend (gloo with device tensors, used only by the
+        two-process rehearsal test) reads and overwrites them from the host: wait until the GPU has caught up first."""
+        if self.device is not None and torch.device(self.device).type == "cuda" and dist.get_backend() != "nccl":
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def _all_gather(self, parts):
         """One collective launch for all (send, recv) pairs of a group: every call into torch.distributed costs ~35 us of
         host time, and with strips a group is up to five surfaces."""
+        self._host_driven_backend_fence()
         if len(parts) == 1:
             return [dist.all_gather_into_tensor(parts[0][1], parts[0][0], async_op=True)]
         return [dist.group.WORLD.allgather_into_tensor_coalesced([recv for _, recv in parts], [send for send, _ in parts])]
@@ -383,6 +390,7 @@ class TiledFrame:
             plan.unpack.run()
 
     def _halo_issue(self, which):
+        self._host_driven_backend_fence()
         ops = []
         for nb, sbuf, rbuf in self.halo_peers(which):
             if sbuf is not None:
