@@ -223,21 +223,25 @@ class TiledFrame:
             elif op == "halo_start":
                 self._halo_works[arg] = self._halo_issue(arg)
             else:  # halo_wait
-                for work in self._halo_works.pop(arg, ()):
-                    work.wait()
+                self._halo_complete(arg)
             self._xchg_s += time.perf_counter() - t0
 
-    def _host_driven_backend_fence(self):
-        """RCCL enqueues its kernels behind everything already recorded on the compute stream, so buffers handed to a
-        collective are ordered by the streams alone.  A host-driven backend (gloo with device tensors, used only by the
-        two-process rehearsal test) reads and overwrites them from the host: wait until the GPU has caught up first."""
-        if self.device is not None and torch.device(self.device).type == "cuda" and dist.get_backend() != "nccl":
-            torch.cuda.current_stream(self.device).synchronize()
+    def _host_driven_backend(self):
+        """RCCL enqueues its kernels behind everything already recorded on the compute stream and writes through the
+        GPU's own memory system, so device buffers can be handed to it as they are.  A host-driven backend (gloo,
+        used by the CPU tests and by the two-process rehearsal on one GPU) must not be given device pointers: the
+        exchange is staged through host tensors instead."""
+        return self.device is not None and torch.device(self.device).type == "cuda" and dist.get_backend() != "nccl"
 
     def _all_gather(self, parts):
         """One collective launch for all (send, recv) pairs of a group: every call into torch.distributed costs ~35 us of
         host time, and with strips a group is up to five surfaces."""
-        self._host_driven_backend_fence()
+        if self._host_driven_backend():
+            for send, recv in parts:
+                staged = torch.empty(recv.numel(), dtype=torch.uint8)
+                dist.all_gather_into_tensor(staged, send.cpu())
+                recv.copy_(staged)
+            return []
         if len(parts) == 1:
             return [dist.all_gather_into_tensor(parts[0][1], parts[0][0], async_op=True)]
         return [dist.group.WORLD.allgather_into_tensor_coalesced([recv for _, recv in parts], [send for send, _ in parts])]
@@ -245,8 +249,7 @@ class TiledFrame:
     def flush(self):
         """Completes the halo exchanges the last frame left in flight (call before reading results / stopping a clock)."""
         for which in list(self._halo_packed):
-            for work in self._halo_works.pop(which, ()):
-                work.wait()
+            self._halo_complete(which)
             self.halo_unpack(which)
 
     def exchange_ms(self, steps):
@@ -390,14 +393,25 @@ class TiledFrame:
             plan.unpack.run()
 
     def _halo_issue(self, which):
-        self._host_driven_backend_fence()
-        ops = []
+        staged = self._host_driven_backend()
+        ops, landing, keep = [], [], []
         for nb, sbuf, rbuf in self.halo_peers(which):
             if sbuf is not None:
-                ops.append(dist.P2POp(dist.isend, sbuf, nb))
+                keep.append(sbuf.cpu() if staged else sbuf)  # a staged copy must outlive the send
+                ops.append(dist.P2POp(dist.isend, keep[-1], nb))
             if rbuf is not None:
-                ops.append(dist.P2POp(dist.irecv, rbuf, nb))
-        return dist.batch_isend_irecv(ops) if ops else []
+                dst = torch.empty(rbuf.numel(), dtype=torch.uint8) if staged else rbuf
+                ops.append(dist.P2POp(dist.irecv, dst, nb))
+                if staged:
+                    landing.append((rbuf, dst))
+        return (dist.batch_isend_irecv(ops) if ops else []), landing, keep
+
+    def _halo_complete(self, which):
+        works, landing, _ = self._halo_works.pop(which, ((), (), ()))
+        for work in works:
+            work.wait()
+        for rbuf, staged in landing:
+            rbuf.copy_(staged)
 
 
 HALO_SURFACES = {"taa": ("taa_target", 0), "ao": ("acc_ao", 1), "ssr": ("blurred", 1)}  # pass output, divisor
