@@ -64,7 +64,7 @@ def test_tiled_ranks_match_single_gpu_frame(grid):
     want = {n: plain.frame.download(n) for n, _ in OUTPUTS}
     plain.frame.close()
 
-    ranks = [TiledFrame(FrameSetup(W, H), r, world, cols, rows, device, halo=64) for r in range(world)]  # production halo: covers the 19 half-res px reach of GTAO main + filter
+    ranks = [TiledFrame(FrameSetup(W, H), r, world, cols, rows, device, halo=48) for r in range(world)]  # production halo: covers the 20 half-res px reach of GTAO main + filter
     for t in ranks:
         assert t.tiled and t.window != (0, 0, W, H)
         t.prepare()

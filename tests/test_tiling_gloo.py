@@ -26,7 +26,7 @@ WORKER = textwrap.dedent("""
     cols, rows = (int(v) for v in os.environ['VKR_GRID'].split('x'))
     W, H = 128 * cols, 144 * rows
     setup = FrameSetup(W, H)
-    t = TiledFrame(setup, rank, world, cols, rows, None, backend=binding.OracleBackend, halo=64)
+    t = TiledFrame(setup, rank, world, cols, rows, None, backend=binding.OracleBackend, halo=48)
     t.prepare()
     for _ in range(3):  # the third frame reuses the exchange plans cached for the first (ping-pong parity)
         t.step()

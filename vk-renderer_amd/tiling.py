@@ -35,7 +35,8 @@ import torch.distributed as dist
 
 from . import abi
 
-HALO = 64          # full-res pixels; half-res surfaces carry HALO // 2
+HALO = 48          # full-res pixels, a multiple of 16 (the gathered mips 1..4 of a window must align with the frame's); the longest
+                   # fixed reach is GTAO main + filter, 20 half-res = 40 full-res pixels.  Half-res surfaces carry HALO // 2
 GATHER_MIPS = 4    # depth image-mips 1..4 are tile-aligned for tiles divisible by 16
 
 
