@@ -3,6 +3,7 @@ and flag combinations, each pass fed the oracle's bytes and compared with the or
 tests/parity.py.  Catches what the fixed benchmark frame cannot: branches that only non-default parameters take
 (non-MIS AO, two directions, reflections-only, cleared history, disabled blur / accumulation, every render_flags
 combination, roughness cut-offs)."""
+import os
 import random
 
 import numpy as np
@@ -15,6 +16,9 @@ from parity import report
 from test_parity_gpu import ALL_IMAGES, EXACT
 
 pytestmark = pytest.mark.gpu
+
+# VKR_FUZZ_SCALE=10 runs ten times as many seeds (a one-off campaign; the default keeps the suite short)
+SCALE = int(os.environ.get("VKR_FUZZ_SCALE", "1"))
 
 
 def _case(seed):
@@ -39,7 +43,7 @@ STAGES = [("downsample", ("depth", "dn", "dv")), ("ssr_trace", ("rays", "raw")),
           ("gtao_main", ("raw",)), ("gtao_filter", ("filtered",)), ("gtao_accumulate", ("acc_ao",)), ("taa", ("taa_target",))]
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_random_parameters_stagewise(seed, oracle_lib):
     import torch
 
@@ -108,7 +112,7 @@ def _check(seed, what, ref_img, gpu_img, gpu):
     assert nbad <= max(1, int(2e-4 * ref_img.width * ref_img.height)), f"seed {seed} {what}: {nbad} texels outside tolerance"
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 * SCALE))
 def test_random_parameters_widened_rows(seed, oracle_lib):
     """The passes outside the reference's frame loop and the rows either side of the hot path, same treatment: GTAO
     graphics / reprojection / deinterleaved, ScreenSpaceTrace, simple SSR, deferred shading, tile classification +
@@ -167,7 +171,7 @@ def test_random_parameters_widened_rows(seed, oracle_lib):
     _check(seed, "trace_indirect", ref.rays, gpu.rays, gpu)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 * SCALE))
 def test_random_cameras_raster(seed, oracle_lib):
     """The raster stage under random cameras (triangles crossing the near plane, grazing views, sub-pixel and
     screen-filling triangles), sizes and tessellation: coverage and depth bit-exact, attachments within tolerance."""
