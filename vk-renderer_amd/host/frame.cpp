@@ -353,6 +353,7 @@ int vkrh_selftest_writers(const char* dir, uint32_t width, uint32_t height) {
   });
 }
 int vkrh_enable_task_timing(void* frame, uint32_t on) { return guarded([&] { ((PostFxFrame*)frame)->graph.enable_task_timing(on != 0); }); }
+int vkrh_enable_task_timing_only(void* frame, const char* task) { return guarded([&] { ((PostFxFrame*)frame)->graph.enable_task_timing(true, task ? task : ""); }); }
 const char* vkrh_collect_task_times(void* frame) {
   auto* f = (PostFxFrame*)frame;
   f->task_names.clear();

@@ -98,6 +98,8 @@ int vkrh_capture(void* frame, const char* name, uint32_t mip, uint32_t kind, con
 int vkrh_selftest_writers(const char* dir, uint32_t width, uint32_t height);
 /* per-task device timing with HIP events on the frame's stream */
 int vkrh_enable_task_timing(void* frame, uint32_t on);
+/* time only the task of that name (two event records per frame instead of two per pass) */
+int vkrh_enable_task_timing_only(void* frame, const char* task);
 /* synchronises and returns "name total_ms launches\n" lines accumulated since the last call */
 const char* vkrh_collect_task_times(void* frame);
 /* Exercises the rendergraph / pass error paths the reference signals with exceptions (no kernel is

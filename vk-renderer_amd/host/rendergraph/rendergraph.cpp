@@ -101,7 +101,7 @@ RenderGraph::~RenderGraph() {
     if (lane_streams[l]) (void)hipStreamDestroy((hipStream_t)lane_streams[l]);
 }
 
-void RenderGraph::enable_task_timing(bool on) { timing = on; }
+void RenderGraph::enable_task_timing(bool on, const std::string& only) { timing = on; timing_only = only; }
 void* RenderGraph::get_event() {
   if (!event_pool.empty()) { void* e = event_pool.back(); event_pool.pop_back(); return e; }
   hipEvent_t e;
@@ -224,7 +224,7 @@ void RenderGraph::submit() {
     submitted_names.push_back(t->get_name());
     submitted_lanes.push_back(lane);
     cmd.push_label(t->get_name().c_str());
-    if (timing) {
+    if (timing && (timing_only.empty() || timing_only == t->get_name())) {
       TimedTask tt{t->get_name(), get_event(), get_event()};
       (void)hipEventRecord((hipEvent_t)tt.start, (hipStream_t)cmd.get_stream());
       t->write_commands(res, cmd);
