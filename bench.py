@@ -133,7 +133,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    device = torch.device("cuda", local_rank)
+    # Rehearsal of the N > 1 code path on a one-GPU box (tests/test_bench_multirank_gpu.py): every rank on cuda:0 and
+    # gloo instead of RCCL, which refuses two ranks on one device.  Never set by the driver.
+    share_gpu = os.environ.get("VKR_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    device = torch.device("cuda", 0 if share_gpu else local_rank)
     torch.cuda.set_device(device)
     import torch.distributed as dist
 
@@ -143,6 +146,8 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        elif share_gpu:
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
 
