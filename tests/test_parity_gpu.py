@@ -102,6 +102,11 @@ def test_chain_stagewise(size, oracle_lib):
         _compare(ref, gpu, outs, budget=1e-4)
 
 
+def test_chain_stagewise_full_size(oracle_lib):
+    """The BASELINE.json frame itself: every pass at 3840x2160 against the oracle on the same bytes."""
+    test_chain_stagewise((3840, 2160), oracle_lib)
+
+
 def test_chain_end_to_end(oracle_lib):
     """Whole frame on the GPU with no re-synchronisation, two frames with history ping-pong."""
     ref, gpu = _pair(640, 360, oracle_lib)
