@@ -107,9 +107,10 @@ def test_chain_stagewise_full_size(oracle_lib):
     test_chain_stagewise((3840, 2160), oracle_lib)
 
 
-def test_chain_end_to_end(oracle_lib):
+@pytest.mark.parametrize("size", [(640, 360), (3840, 2160)])
+def test_chain_end_to_end(size, oracle_lib):
     """Whole frame on the GPU with no re-synchronisation, two frames with history ping-pong."""
-    ref, gpu = _pair(640, 360, oracle_lib)
+    ref, gpu = _pair(*size, oracle_lib)
     for c in (ref, gpu):
         c.synth()
         c.build_prev_hiz()
