@@ -4,9 +4,11 @@
 One "step" = one steady-state frame of the chain of main.cpp:347-391 on a resident synthetic
 G-buffer: DownsampleGbuffer, DownsampleDepth x (L-2), SSSR_trace, SSSR_filter, SSSR_blur,
 GTAO_main, GTAO_filter, GTAO_accumulate, TAA, then the history remaps of main.cpp:416-420.
-N = 1 runs BASELINE.json configs[1] (3840x2160).  N > 1 (launched by torch.distributed.run, one
-rank per GPU) tiles a larger frame, one 3840x2160 tile per GPU ("weak" scaling), exchanging the
-Hi-Z pyramid / hit-colour surfaces and history halos over RCCL every frame.
+N = 1 runs BASELINE.json configs[1] (3840x2160, the configuration the metric is quoted on).  N > 1
+(launched by torch.distributed.run, one rank per GPU) runs BASELINE.json configs[3]: the 15360x8640
+frame (16:9 camera) cut into N horizontal strips of 15360 x 8640/N, exchanging the Hi-Z pyramid /
+hit-colour surfaces and history halos over RCCL every frame.  N = 2, 4, 8 cut the SAME frame
+("strong" scaling between them); `value` is pixels per second, so it compares across N.
 
 Prints ONE JSON line on rank 0.  `value` = full-resolution pixels of the whole frame processed
 per second (all ranks), with every input resident in HBM when the timed region starts.
@@ -14,8 +16,13 @@ per second (all ranks), with every input resident in HBM when the timed region s
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
+
+# ROCr reads HSA_* once, at hsa_init: this must be in the environment before anything touches the GPU
+# (the host driver only supports dmabuf IPC; without it RCCL fails with hipIpcGetMemHandle: invalid argument).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,7 +36,8 @@ from vk_renderer_amd.camera import FrameSetup  # noqa: E402
 from vk_renderer_amd.tiling import TiledFrame, grid_for  # noqa: E402
 
 METRIC = "Mpixels/s (GTAO+Hi-Z+SSR+TAA composite) at 4K; achieved HBM GB/s vs peak"
-TILE_W, TILE_H = 3840, 2160
+TILE_W, TILE_H = 3840, 2160          # N = 1: BASELINE configs[1]
+C4_W, C4_H = 15360, 8640             # N > 1: BASELINE configs[3], cut into N strips
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 # Algorithmic bytes per FULL-RES pixel of each task: surface-compulsory model of SURVEY.md 8(d)
@@ -103,23 +111,24 @@ def main():
                          "and GbufferPass is part of every timed step")
     ap.add_argument("--rehearse-tiled", action="store_true",
                     help="N=1 only: run the multi-GPU code path (RCCL gathers, staged frame) on a one-rank group")
-    ap.add_argument("--tile", type=str, default=f"{TILE_W}x{TILE_H}", help="per-GPU tile, WxH")
+    ap.add_argument("--frame", type=str, default=None,
+                    help=f"whole frame, WxH.  Default: {TILE_W}x{TILE_H} at N = 1 (c2), {C4_W}x{C4_H} at N > 1 (c4: N strips of W x H/N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="let the rendergraph spread independent passes of a frame over several streams (measured slower: "
                          "the passes are VALU-bound, see DESIGN.md section 3)")
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c5"],
-                    help="BASELINE.json configs: c1 1920x1080 GTAO main only (non-MIS); c2 3840x2160 composite (default, the "
+    ap.add_argument("--config", default=None, choices=["c1", "c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configs: c1 1920x1080 GTAO main only (non-MIS); c2 3840x2160 composite (default at N = 1, the "
                          "metric's config); c3 7680x4320 composite (analytic scene: Sponza.bin is absent from the reference mount); "
-                         "c5 3840x2160 with 8 x (trace, filter, blur) + TAA")
+                         "c4 15360x8640 composite tiled over the ranks (default at N > 1); c5 3840x2160 with 8 x (trace, filter, blur) + TAA")
     ap.add_argument("--shading", action="store_true", help="add the deferred-shading composite (SURVEY 8(f) #1) between GTAO and TAA")
     args = ap.parse_args()
-    if args.config != "c2" and args.gpus != 1:
+    if args.config is None:
+        args.config = "c2" if args.gpus == 1 else "c4"
+    if args.config in ("c1", "c3", "c5") and args.gpus != 1:
         raise SystemExit("--config c1/c3/c5 are single-GPU configurations")
-    if args.config == "c1":
-        args.tile = "1920x1080"
-    elif args.config == "c3":
-        args.tile = "7680x4320"
+    if args.frame is None:
+        args.frame = {"c1": "1920x1080", "c2": f"{TILE_W}x{TILE_H}", "c3": "7680x4320", "c4": f"{C4_W}x{C4_H}", "c5": f"{TILE_W}x{TILE_H}"}[args.config]
 
     # Exactly ONE line may reach stdout (the JSON result): libraries print there too (RCCL writes its
     # version banner to stdout on rank 0), so fd 1 is pointed at stderr for the whole run and the
@@ -141,7 +150,6 @@ def main():
     import torch.distributed as dist
 
     if world > 1 or args.rehearse_tiled:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:  # rehearsal: a one-rank RCCL group, rendezvous on the loopback address
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
@@ -151,9 +159,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    tw, th = (int(v) for v in args.tile.lower().split("x"))
+    W, H = (int(v) for v in args.frame.lower().split("x"))
     cols, rows = grid_for(world)
-    W, H = tw * cols, th * rows
+    if W % cols or H % rows:
+        raise SystemExit(f"frame {W}x{H} does not divide into a {cols}x{rows} grid")
+    tw, th = W // cols, H // rows
     setup = FrameSetup(W, H, use_mis=0 if args.config == "c1" else 1)
     tiled = TiledFrame(setup, rank, world, cols, rows, device, force_tiled=args.rehearse_tiled)
     frame = tiled.frame
@@ -207,19 +217,27 @@ def main():
     tiled.flush()
     barrier()
     calibration = frame.collect_task_times()
-    per_pass_ms = {k: v[0] / CAL_STEPS for k, v in calibration.items()}
-    launches_per_step = {k: v[1] / CAL_STEPS for k, v in calibration.items()}
+    per_pass_ms = {k: v[0] / CAL_STEPS for k, v in calibration.items()}          # all executions of the task in one step
+    launches_per_step = {k: v[1] / CAL_STEPS for k, v in calibration.items()}    # executions of the task per step (c5: 8 x SSR)
     dominant = max(per_pass_ms, key=per_pass_ms.get)
     frame.enable_task_timing(True, only=dominant)
+    # one event per step boundary on the frame's stream (= torch's current stream): the median step time of SURVEY 8(d)
+    stream = torch.cuda.current_stream(device)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if args.steps >= 50 else []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if marks:
+            marks[i].record(stream)
         tiled.step()
+    if marks:
+        marks[-1].record(stream)
     tiled.flush()  # the halo refreshes of the last frame are still in flight: they belong to the timed work
     barrier()
     elapsed = time.perf_counter() - t0
     task_times = frame.collect_task_times()
     frame.enable_task_timing(False)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if marks else []
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -229,19 +247,30 @@ def main():
     if rank == 0:
         px = W * H
         tile_px = tiled.window[2] * tiled.window[3]  # pixels this rank's kernels actually process (tile + halo)
+        # One execution of a task processes the whole window once (the two launches of the Hi-Z chain are ONE
+        # DownsampleDepth task; the eight SSSR_blur executions of c5 each move the full bytes).
         avg_launch_ms = task_times[dominant][0] / task_times[dominant][1]  # live, over the timed region
-        algo_bytes_launch = BYTES_PER_PX[dominant] * tile_px / launches_per_step[dominant]
+        algo_bytes_launch = BYTES_PER_PX[dominant] * tile_px
         achieved = algo_bytes_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(dominant)
-        valu_busy = None
-        vpath = os.path.join(ROOT, "profiles", "valu_busy.json")
-        if os.path.exists(vpath):
-            with open(vpath) as f:
-                valu_busy = json.load(f).get(dominant)
+        measured_read = measured_read_bandwidth(device)
+
+        def from_profiles(fname):
+            path = os.path.join(ROOT, "profiles", fname)
+            if not os.path.exists(path):
+                return None, None
+            with open(path) as f:
+                d = json.load(f)
+            return d.get(dominant), f"profiles/{fname}" + (f" ({d['_source']})" if "_source" in d else "")
+
+        # HBM bytes / VALU-busy of the dominant kernel are NOT measured in this run: they are the committed rocprofv3
+        # --pmc digests of the same command at 3840x2160 (tools/profile_run.sh + tools/profile_digest.py), valid for c2 / c5 only.
+        traffic, traffic_src = from_profiles("traffic.json") if (W, H) == (TILE_W, TILE_H) else (None, None)
+        valu_busy, valu_src = from_profiles("valu_busy.json") if (W, H) == (TILE_W, TILE_H) else (None, None)
+        workload = {"c1": f"{W}x{H} synthetic G-buffer: GTAO main pass only (non-MIS)",
+                    "c5": f"{W}x{H} synthetic G-buffer: Hi-Z downsample + 8 x SSR (trace, filter, blur) + TAA"}.get(
+            args.config, f"{W}x{H} synthetic G-buffer: Hi-Z downsample + SSR (trace, filter, blur) + GTAO (main, filter, accumulate)"
+                         + (" + deferred shading" if args.shading else "") + " + TAA"
+                         + (f", tiled over {world} GPUs as {cols}x{rows} strips with RCCL halo / Hi-Z / hit-colour exchange" if world > 1 else ""))
         out = {
             "metric": METRIC,
             "value": px * args.steps / elapsed / 1e6,
@@ -251,20 +280,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            # N = 2, 4, 8 cut the same 15360x8640 frame (total work fixed); N = 1 is the 3840x2160 frame the metric is quoted on
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": {"c1": f"{W}x{H} synthetic G-buffer: GTAO main pass only (non-MIS)",
-                             "c5": f"{W}x{H} synthetic G-buffer: Hi-Z downsample + 8 x SSR (trace, filter, blur) + TAA"}.get(
-                    args.config, f"{W}x{H} synthetic G-buffer: Hi-Z downsample + SSR (trace, filter, blur) + GTAO (main, filter, accumulate)"
-                                 + (" + deferred shading" if args.shading else "") + " + TAA"),
-                "baseline_config": args.config,
+                "workload": workload,
+                "baseline_config": args.config if (W, H) == {"c1": (1920, 1080), "c2": (TILE_W, TILE_H), "c3": (7680, 4320),
+                                                             "c4": (C4_W, C4_H), "c5": (TILE_W, TILE_H)}[args.config] else None,
                 "frame": [W, H],
                 "tile_per_gpu": [tw, th],
                 "grid": [cols, rows],
                 "halo_px": tiled.halo,
+                "gathered_hiz_mips": tiled.gather_mips if tiled.tiled else 0,
                 "gbuffer": "rasterised procedural mesh scene (GbufferPass timed)" if args.raster else "analytic generator (not timed)",
             },
             "roofline": {
@@ -274,20 +303,31 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
+                "frac_of_measured": achieved / measured_read,  # against the float4 stream-read rate measured in this run
                 "traffic": traffic,
-                # fraction of the SIMD issue slots the kernel keeps busy with VALU work (profiles/valu_busy.json,
-                # from SQ_ACTIVE_INST_VALU): why the HBM fraction is low — the pass is issue-bound, not memory-bound
+                "traffic_source": traffic_src,   # committed PMC digest, not measured in this run
+                # fraction of the SIMD issue slots the kernel keeps busy with VALU work (SQ_ACTIVE_INST_VALU):
+                # why the HBM fraction is low — the pass is issue-bound, not memory-bound
                 "valu_busy": valu_busy,
+                "valu_busy_source": valu_src,
                 "avg_launch_ms": avg_launch_ms,
+                "launches_timed": task_times[dominant][1],
                 "algorithmic_bytes_per_launch": algo_bytes_launch,
             },
             "composite_gbps": sum(BYTES_PER_PX.get(k, 0.0) * n for k, n in launches_per_step.items()) * tile_px / (elapsed / args.steps) / 1e9 * world,
-            "per_pass_ms": per_pass_ms,  # calibration run (an event pair around every pass), not the timed region
-            "per_pass_gbps": {k: BYTES_PER_PX[k] * tile_px / (v * 1e-3) / 1e9 for k, v in per_pass_ms.items() if k in BYTES_PER_PX and v > 0},
+            # calibration run (CAL_STEPS steps with an event pair around every pass) just before the timed region, NOT the timed region itself
+            "per_pass_ms": per_pass_ms,
+            "per_pass_source": f"calibration run of {CAL_STEPS} steps before the timed region (event pair around every pass)",
+            "per_pass_gbps": {k: BYTES_PER_PX[k] * tile_px * launches_per_step[k] / (v * 1e-3) / 1e9
+                              for k, v in per_pass_ms.items() if k in BYTES_PER_PX and v > 0},
             "exchange_ms": tiled.exchange_ms(args.steps),
-            "measured_read_gbps": measured_read_bandwidth(device),
+            "measured_read_gbps": measured_read,
         }
-        if world == 1 and not args.no_cpu_baseline and args.config == "c2" and not args.shading:
+        if step_ms:  # median of >= 50 hipEvent-timed frames, beside the contract's wall-clock mean
+            med = statistics.median(step_ms)
+            out["ms_per_step_median"] = med
+            out["value_median"] = px / (med * 1e-3) / 1e6  # rank 0's stream only: meaningful at N = 1
+        if world == 1 and not args.no_cpu_baseline and args.config == "c2" and not args.shading and not args.rehearse_tiled:
             out["cpu_baseline"] = cpu_baseline(frame, setup)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -181,8 +181,12 @@ typedef struct vkr_raster_transform { vkr_mat4 model, normal; } vkr_raster_trans
 /* one draw_indexed of scene_renderer.cpp:196-214 with its push constants (:132-137)                 */
 typedef struct vkr_raster_draw {
   uint32_t transform_index, albedo_index, mr_index, flags;   /* PushData; 0xFFFFFFFF = no texture    */
-  uint32_t index_offset, index_count, vertex_offset, reserved;
+  uint32_t index_offset, index_count, vertex_offset, reserved;  /* reserved: VKR_RASTER_DRAW_* hints */
 } vkr_raster_draw;
+/* opaque_taa.frag:32-34 discards fragments whose filtered albedo alpha is 0 (no depth, no colour written); the stage
+ * evaluates that for every draw with an albedo texture.  Hint: the caller guarantees that no texel of any mip level of
+ * the draw's albedo texture has alpha 0, so the discard cannot fire and the test is skipped (same result, cheaper). */
+#define VKR_RASTER_DRAW_OPAQUE_ALBEDO 1u
 /* GbufConst, scene_renderer.cpp:148-153 / opaque_taa.vert:7-12                                      */
 typedef struct vkr_gbuf_const {
   vkr_mat4 view_projection, prev_view_projection;

@@ -57,6 +57,10 @@ class OracleBackend:
         self.chain = chain.PostFxChain(setup.width, setup.height, backend="oracle", setup=setup, window=window, force_tiled=tiled)
         self.frame = None
         self.device = torch.device("cpu")
+        self.gather_mips = tiling.GATHER_MIPS
+
+    def set_gather_mips(self, n):
+        self.gather_mips = n
 
     def rows(self, name, mip=0):
         img = getattr(self.chain, name)
@@ -79,7 +83,7 @@ class OracleBackend:
             c.taa()
         elif stage == "trace":
             if c.tiled:
-                c.hiz_tail(tiling.GATHER_MIPS)
+                c.hiz_tail(self.gather_mips)
             c.ssr_trace(frame_random=c.frame_index % 16)
         elif stage == "gtao":
             c.gtao_main()

@@ -188,8 +188,8 @@ extern "C" int vkr_ref_raster_gbuffer(const vkr_raster_scene* scene, const vkr_g
             const uint32_t d24 = (uint32_t)rintf(zf * 16777215.0f);
             uint32_t& stored = zbuf[(size_t)py * W + px];
             if (!(d24 <= stored)) continue;  // VK_COMPARE_OP_LESS_OR_EQUAL
-            stored = d24;
-            // fragment shader (opaque_taa.frag:26-46)
+            // fragment shader (opaque_taa.frag:26-46).  `discard` (:32-34) means the fragment writes nothing,
+            // depth included, so the depth buffer is only updated after the alpha test.
             float b[3], lx[3], ly[3], bx[3], by[3];
             i64 tmp[3];
             persp(l, b);
@@ -206,6 +206,8 @@ extern "C" int vkr_ref_raster_gbuffer(const vkr_raster_scene* scene, const vkr_g
 #undef BARY
             vec4 out_albedo(0.5f, 0.5f, 0.5f, 1.0f);
             if (dr.albedo_index != 0xFFFFFFFFu) out_albedo = sample_trilinear(textures[dr.albedo_index], in_uv, ddx, ddy);
+            if (out_albedo.w == 0.0f) continue;  // discard
+            stored = d24;
             vec4 out_material(0.5f, 0.9f, 0.5f, 0.5f);
             if (dr.mr_index != 0xFFFFFFFFu) out_material = sample_trilinear(textures[dr.mr_index], in_uv, ddx, ddy);
             const vec2 en = encode_normal(in_normal);

@@ -142,6 +142,89 @@ def test_oracle_depth_test_is_less_or_equal_and_near_clip(oracle_lib):
     assert hit.any() and not hit.all() and d[hit].min() < 0.1 * 16777215
 
 
+def _cutout_kat_scene():
+    """Front quad [4, 12) x [2, 6) at z = 0.25 textured 4x4 with alpha 0 in texel columns 0-1, in front of a
+    full-viewport triangle at z = 0.5 (normal +y)."""
+    def ndc(x, y, z):
+        return [x / 8.0 - 1.0, y / 4.0 - 1.0, z]
+    sc = scn.Scene()
+    t = sc.add_transform(np.eye(4, dtype=np.float32))
+    back = np.array([[-1, -1, 0.5], [3, -1, 0.5], [-1, 3, 0.5]], np.float32)
+    sc.add_draw(t, sc.add_mesh(back, np.array([[0, 1, 0]] * 3, np.float32), np.zeros((3, 2), np.float32), np.array([0, 1, 2], np.uint32)))
+    tex = np.zeros((4, 4, 4), np.uint8)
+    tex[..., 0], tex[..., 3] = 255, 255
+    tex[:, :2, 3] = 0
+    pos = np.array([ndc(4, 2, 0.25), ndc(12, 2, 0.25), ndc(12, 6, 0.25), ndc(4, 6, 0.25)], np.float32)
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    mesh = sc.add_mesh(pos, np.array([[0, 0, 1]] * 4, np.float32), uv, np.array([0, 1, 2, 0, 2, 3], np.uint32))
+    sc.add_draw(t, mesh, sc.add_texture(tex))
+    return sc
+
+
+def _check_cutout_kat(out):
+    d = out["depth"][..., 0] & 0xFFFFFF
+    front, back = round(0.25 * 16777215), round(0.5 * 16777215)
+    # u = (x + 0.5 - 4) / 8 magnifies the 4 texels over 8 pixels; bilinear with REPEAT: the filtered alpha is exactly 0 only
+    # where both taps lie in texel columns 0-1: pixels x = 5, 6 (x = 4 wraps to the opaque column 3, x = 7 touches column 2)
+    want = np.full(d.shape, back)
+    want[2:6, 4:12] = front
+    want[2:6, 5:7] = back
+    assert np.array_equal(d, want), "discarded fragments must leave the depth of the geometry behind"
+    hole = out["normal"][2:6, 5:7]
+    assert np.all(hole[..., 0] == 32768) and np.all(hole[..., 1] == 65535), "the back triangle's normal (+y) shows through the hole"
+    assert np.all(out["albedo"][2:6, 5:7, :3] == 188), "... and its untextured albedo"
+    kept = out["albedo"][2:6, 7:12]
+    assert np.all(kept[..., 0] == 255) and np.all(kept[..., 3] > 0)
+
+
+def test_oracle_alpha_discard_shows_what_is_behind(oracle_lib):
+    """opaque_taa.frag:32-34: `if (out_albedo.a == 0) discard;` — the fragment writes neither depth nor colour."""
+    W, H = 16, 8
+    c = PostFxChain(W, H, backend="oracle", setup=_IdentitySetup(W, H))
+    _check_cutout_kat(_raster(c, _cutout_kat_scene()))
+
+
+@pytest.mark.gpu
+def test_alpha_discard_known_answer_gpu(oracle_lib):
+    """The same known answer on the HIP rasterizer (the discard is evaluated at coverage time, before the atomicMin),
+    with and without the caller's opaque hint withheld."""
+    W, H = 16, 8
+    c = PostFxChain(W, H, backend="product", device="cuda", setup=_IdentitySetup(W, H))
+    _check_cutout_kat(_raster(c, _cutout_kat_scene()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(640, 360)])
+def test_raster_parity_cutout(size, oracle_lib):
+    """The procedural scene with a fence whose texture has alpha-0 holes, minified and magnified: coverage / depth must
+    stay bit-exact against the oracle (a wrong discard shows as a depth mismatch), and a fair share of the fence must
+    actually have been discarded."""
+    W, H = size
+    ref = PostFxChain(W, H, backend="oracle")
+    gpu = PostFxChain(W, H, backend="product", device="cuda")
+    solid, cut = scn.procedural_scene(), scn.procedural_scene(cutout=True)
+    ref.raster(solid)
+    d_solid = ref.depth.raw(0)[..., 0] & 0xFFFFFF
+    for c in (ref, gpu):
+        c.raster(cut)
+    gpu.sync()
+    a, b = gpu.depth.raw(0)[..., 0] & 0xFFFFFF, ref.depth.raw(0)[..., 0] & 0xFFFFFF
+    assert np.array_equal(a, b), f"depth: {int((a != b).sum())} texels differ"
+    fence = b != d_solid
+    print(f"[parity] cutout: fence covers {int(fence.sum())} px")
+    assert fence.sum() > 0.01 * W * H
+    # the fence's bounding box holds both fence fragments and holes showing the solid scene
+    ys, xs = np.nonzero(fence)
+    box = (slice(ys.min(), ys.max() + 1), slice(xs.min(), xs.max() + 1))
+    holes = (~fence[box]).mean()
+    print(f"[parity] cutout: holes inside the fence's box {holes:.3f}")
+    assert 0.15 < holes < 0.6
+    for name in ("albedo", "normal", "material", "velocity"):
+        r, g = getattr(ref, name), getattr(gpu, name)
+        n = int((r.raw(0) != g.raw(0)).any(axis=-1).sum())
+        assert n <= 1e-4 * W * H, f"{name}: {n} texels differ"
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("size", [(256, 144), (640, 360)])
 def test_raster_parity(size, oracle_lib):

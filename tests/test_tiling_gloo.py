@@ -24,9 +24,10 @@ WORKER = textwrap.dedent("""
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     dist.init_process_group('gloo')
     cols, rows = (int(v) for v in os.environ['VKR_GRID'].split('x'))
-    W, H = 128 * cols, 144 * rows
+    W, H = 128 * cols, int(os.environ.get('VKR_TILE_H', '144')) * rows
     setup = FrameSetup(W, H)
     t = TiledFrame(setup, rank, world, cols, rows, None, backend=binding.OracleBackend, halo=48)
+    assert t.gather_mips == int(os.environ.get('VKR_EXPECT_GATHER', '4')), t.gather_mips
     t.prepare()
     for _ in range(3):  # the third frame reuses the exchange plans cached for the first (ping-pong parity)
         t.step()
@@ -66,12 +67,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("grid", ["1x2", "2x1", "2x2"])  # strips gather in place, 2-D grids pack and scatter
-def test_tiled_frame_matches_single_process(grid, tmp_path, oracle_lib):
+# strips gather in place, 2-D grids pack and scatter; tile height 136 = 8 * 17 is divisible by 8 but not 16, like the
+# 15360x1080 strips of BASELINE config 4 on 8 GPUs: only depth mips 1..3 are gathered, mip 4.. are rebuilt locally
+@pytest.mark.parametrize("grid,tile_h,gather", [("1x2", 144, 4), ("2x1", 144, 4), ("2x2", 144, 4), ("1x2", 136, 3)])
+def test_tiled_frame_matches_single_process(grid, tile_h, gather, tmp_path, oracle_lib):
     world = int(grid[0]) * int(grid[2])
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, OMP_NUM_THREADS="2", VKR_GRID=grid)
+    env = dict(os.environ, OMP_NUM_THREADS="2", VKR_GRID=grid, VKR_TILE_H=str(tile_h), VKR_EXPECT_GATHER=str(gather))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

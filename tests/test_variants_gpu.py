@@ -172,6 +172,40 @@ def test_host_mirror_variants(oracle_lib):
     frame.close()
 
 
+def test_host_mirror_reprojection_two_frames(oracle_lib):
+    """main.cpp:417 remaps gtao.output <-> gtao.prev_frame at the end of every frame: the static-reprojection variant
+    (gtao.cpp:241-284) must read in frame 2 what it wrote in frame 1."""
+    from vk_renderer_amd import host
+    from vk_renderer_amd.camera import FrameSetup
+    from vk_renderer_amd.chain import PostFxChain
+    from parity import mismatches
+
+    W, H = 512, 288
+    setup = FrameSetup(W, H)
+    frame = host.HostFrame(setup, device="cuda")
+    frame.run(host.STAGE_GBUFFER | host.STAGE_PREV_DEPTH)
+    frame.run(host.STAGE_DOWNSAMPLE)
+    ref = PostFxChain(W, H, backend="oracle", setup=setup)
+    for name in ("depth", "prev_depth", "normal", "albedo", "material", "velocity"):
+        getattr(ref, name).upload(frame.download(name).to_host())
+    frame.pin_randoms(0.0, 0, 0)
+    for k, angle in enumerate((60.0, 300.0)):  # gtao.cpp:109: table[frame_count % 12], jitter pinned to 0
+        frame.run(host.STAGE_GTAO_GRAPHICS)
+        ref.gtao_main_graphics(angle_offset=float(np.float32(angle) / np.float32(360.0)))
+        ref.gtao_filter()
+        ref.gtao_reproject()
+        got = frame.download("ao_output")
+        bad = int(mismatches(ref.ao_output.format, got.decode(), ref.ao_output.decode()).sum())
+        print(f"[parity] reprojection frame {k}: ao_output outside-tol {bad}")
+        assert bad <= 1e-4 * ref.ao_output.width * ref.ao_output.height
+        if k == 1:  # the history actually contributed: frame 2 differs from a run without it
+            assert not np.array_equal(got.raw(0), first), "frame 2 ignored the history"
+        first = got.raw(0).copy()
+        frame.end_frame()
+        ref.ao_output, ref.ao_prev_frame = ref.ao_prev_frame, ref.ao_output
+    frame.close()
+
+
 def test_readback_captures(tmp_path, oracle_lib):
     """ReadBackSystem (image_readback.cpp) + capture writers on real device images: the CSV / PNG files hold exactly
     the bytes of the images they were read from."""

@@ -15,6 +15,13 @@
 //   k_raster_resolve  one thread per pixel: the winning triangle's record, perspective-correct attributes,
 //                     implicit LOD from forward differences, trilinear sRGB fetches, stores
 //
+// opaque_taa.frag:32-34 discards a fragment whose albedo alpha is 0: it then writes neither depth nor any
+// attachment.  A visibility buffer commits coverage before shading, so the discard is evaluated at coverage
+// time: for draws with an albedo texture the covering lane computes the fragment's uv, its forward-difference
+// LOD and the filtered alpha (the very expression the resolve evaluates again) and skips the atomicMin when
+// it is 0.  A caller that knows a texture has no alpha-0 texel in any mip level sets
+// VKR_RASTER_DRAW_OPAQUE_ALBEDO on the draw and the test is skipped (the result cannot differ).
+//
 // Coverage and depth are integer-exact functions of the snapped vertices, so they are bit-equal to
 // the oracle's immediate-mode rasterizer; colour / normal / velocity follow the frozen fp32 contract.
 #include <vector>
@@ -29,13 +36,14 @@ namespace vkr {
 struct DrawDev {  // one draw call, matrices premultiplied on the host exactly as the vertex shader does
   Mat4 mvp, prev_mvp, normal_mat;
   uint32_t albedo_index, mr_index, index_offset, vertex_offset;
-  uint32_t tri_base, tri_count, pad0, pad1;
+  uint32_t tri_base, tri_count, alpha_test, pad1;  // alpha_test: the discard of opaque_taa.frag:32 can fire for this draw
 };
 
 struct RasterArgs {
   const vkr_raster_vertex* vertices;
   const uint32_t* indices;
   const DrawDev* draws;
+  const Pyramid* tex;  // [RASTER_MAX_TEXTURES] in scratch
   uint32_t draw_count;
   unsigned long long* vis;
   struct ScreenTri* setup;  // [2 * total triangles]: sub-triangle records written by k_raster_setup
@@ -76,6 +84,7 @@ struct ScreenTri {
   float w[3], z[3];  // clip w and z / w
   long long area2;
   VsOut v[3];
+  uint32_t alpha_tex;  // albedo texture whose filtered alpha decides the discard, 0xFFFFFFFF: no test
   bool valid;
 };
 
@@ -94,6 +103,7 @@ VKR_DEV bool is_top_left(int ax, int ay, int bx, int by) {
 VKR_DEV ScreenTri setup_triangle(const RasterArgs& a, const DrawDev& d, uint32_t tri, int sub, int* count) {
   ScreenTri t;
   t.valid = false;
+  t.alpha_tex = d.alpha_test ? d.albedo_index : 0xFFFFFFFFu;
   VsOut in[3], poly[4];
   for (int k = 0; k < 3; k++) in[k] = vertex_shader(a, d, 3u * tri + (uint32_t)k);
   int n = 0;
@@ -171,11 +181,68 @@ VKR_DEV void perspective(const ScreenTri& t, const float lambda[3], float b[3]) 
 }
 #define BARY(F) ((b[0] * t.v[0].F + b[1] * t.v[1].F) + b[2] * t.v[2].F)
 
+VKR_DEV int wrap_repeat(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+// texture(sampler2D, uv) of an RGBA8_SRGB mip chain: REPEAT, bilinear, linear between the two mips of `lod`
+VKR_DEV f4 sample_level_repeat(const Tex& t, f2 uv) {
+  const float x = uv.x * (float)t.fw - 0.5f, y = uv.y * (float)t.fh - 0.5f;
+  const float x0f = floorf(x), y0f = floorf(y);
+  const float fx = x - x0f, fy = y - y0f;
+  const int x0 = wrap_repeat(f2i(x0f), t.fw), y0 = wrap_repeat(f2i(y0f), t.fh);
+  const int x1 = wrap_repeat(x0 + 1, t.fw), y1 = wrap_repeat(y0 + 1, t.fh);
+  auto dec = [&](int tx, int ty) {
+    const uint32_t v = *texel_ptr<const uint32_t>(t, tx, ty);
+    return mk4(srgb8_to_float(v & 0xFFu), srgb8_to_float((v >> 8) & 0xFFu), srgb8_to_float((v >> 16) & 0xFFu), unorm8_to_float(v >> 24));
+  };
+  return mix4(mix4(dec(x0, y0), dec(x1, y0), fx), mix4(dec(x0, y1), dec(x1, y1), fx), fy);
+}
+VKR_DEV f4 sample_trilinear(const Pyramid& p, f2 uv, f2 duvdx, f2 duvdy) {
+  const float w = (float)p.mip[0].fw, h = (float)p.mip[0].fh;
+  // rho^2 = max squared footprint; lod = log2(rho).  The level pair comes from the exponent of rho^2
+  // (exact), only the blend factor from log2f (smooth) — a libm ulp must not flip the pair.
+  const float rx2 = (duvdx.x * w) * (duvdx.x * w) + (duvdx.y * h) * (duvdx.y * h);
+  const float ry2 = (duvdy.x * w) * (duvdy.x * w) + (duvdy.y * h) * (duvdy.y * h);
+  const float r2 = vmax(rx2, ry2);
+  int l0 = 0;
+  float f = 0.0f;
+  if (r2 > 1.0f && r2 < 3.0e38f) {
+    l0 = ilogbf(r2) >> 1;  // floor(log2(rho))
+    f = vclamp(0.5f * log2f(r2) - (float)l0, 0.0f, 1.0f);
+  }
+  if (l0 >= p.count - 1) { l0 = p.count - 1; f = 0.0f; }  // sampler LOD range [0, 10] and the chain length
+  const int l1 = min(l0 + 1, p.count - 1);
+  const f4 a = sample_level_repeat(p.mip[l0], uv);
+  if (f == 0.0f || l1 == l0) return a;
+  return mix4(a, sample_level_repeat(p.mip[l1], uv), f);
+}
+
+
+// uv and its forward differences at pixel (px, py) of triangle t (lambda: its screen-space barycentrics there):
+// what the fragment shader's texture() calls see (implicit derivatives as differences to the right / lower pixel)
+struct FragUv { f2 uv, ddx, ddy; float b[3]; };
+VKR_DEV FragUv fragment_uv(const ScreenTri& t, int px, int py, const float lambda[3]) {
+  FragUv f;
+  perspective(t, lambda, f.b);
+  const float* b = f.b;
+  f.uv = mk2(BARY(uv.x), BARY(uv.y));
+  float lx1[3], ly1[3], bx1[3], by1[3];
+  lambda_at(t, px + 1, py, lx1);
+  lambda_at(t, px, py + 1, ly1);
+  perspective(t, lx1, bx1);
+  perspective(t, ly1, by1);
+  const f2 uvx = mk2((bx1[0] * t.v[0].uv.x + bx1[1] * t.v[1].uv.x) + bx1[2] * t.v[2].uv.x, (bx1[0] * t.v[0].uv.y + bx1[1] * t.v[1].uv.y) + bx1[2] * t.v[2].uv.y);
+  const f2 uvy = mk2((by1[0] * t.v[0].uv.x + by1[1] * t.v[1].uv.x) + by1[2] * t.v[2].uv.x, (by1[0] * t.v[0].uv.y + by1[1] * t.v[1].uv.y) + by1[2] * t.v[2].uv.y);
+  f.ddx = uvx - f.uv; f.ddy = uvy - f.uv;
+  return f;
+}
 // the per-draw constants travel as kernel arguments (8 per launch) into the draw table in scratch: no host
 // staging memory has to outlive the call and nothing synchronises
 struct DrawChunk { DrawDev d[8]; };
 __global__ void k_raster_store_draws(DrawChunk c, DrawDev* dst, uint32_t n) {
   if (threadIdx.x < n) dst[threadIdx.x] = c.d[threadIdx.x];
+}
+struct TexChunk { Pyramid p[4]; };
+__global__ void k_raster_store_textures(TexChunk c, Pyramid* dst, uint32_t n) {
+  if (threadIdx.x < n) dst[threadIdx.x] = c.p[threadIdx.x];
 }
 
 __global__ void k_raster_clear(unsigned long long* vis, size_t n) {
@@ -222,6 +289,10 @@ VKR_DEV void raster_block(const RasterArgs& a, const ScreenTri& t, uint32_t rec,
   float lambda[3];
   uint32_t d24;
   if (!cover(t, px, py, lambda, &d24)) return;
+  if (t.alpha_tex != 0xFFFFFFFFu) {  // opaque_taa.frag:32-34: out_albedo.a == 0 -> discard (no depth, no colour)
+    const FragUv f = fragment_uv(t, px, py, lambda);
+    if (sample_trilinear(a.tex[t.alpha_tex], f.uv, f.ddx, f.ddy).w == 0.0f) return;
+  }
   atomicMin(&a.vis[(size_t)py * a.width + px], ((unsigned long long)d24 << 32) | (0xFFFFFFFFull - (unsigned long long)rec));
 }
 
@@ -260,42 +331,7 @@ __global__ __launch_bounds__(256) void k_raster_large(RasterArgs a, const uint32
 struct ResolveArgs {
   RasterArgs r;
   Tex albedo, normal, material, velocity, depth;
-  Pyramid tex[RASTER_MAX_TEXTURES];
 };
-
-VKR_DEV int wrap_repeat(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
-// texture(sampler2D, uv) of an RGBA8_SRGB mip chain: REPEAT, bilinear, linear between the two mips of `lod`
-VKR_DEV f4 sample_level_repeat(const Tex& t, f2 uv) {
-  const float x = uv.x * (float)t.fw - 0.5f, y = uv.y * (float)t.fh - 0.5f;
-  const float x0f = floorf(x), y0f = floorf(y);
-  const float fx = x - x0f, fy = y - y0f;
-  const int x0 = wrap_repeat(f2i(x0f), t.fw), y0 = wrap_repeat(f2i(y0f), t.fh);
-  const int x1 = wrap_repeat(x0 + 1, t.fw), y1 = wrap_repeat(y0 + 1, t.fh);
-  auto dec = [&](int tx, int ty) {
-    const uint32_t v = *texel_ptr<const uint32_t>(t, tx, ty);
-    return mk4(srgb8_to_float(v & 0xFFu), srgb8_to_float((v >> 8) & 0xFFu), srgb8_to_float((v >> 16) & 0xFFu), unorm8_to_float(v >> 24));
-  };
-  return mix4(mix4(dec(x0, y0), dec(x1, y0), fx), mix4(dec(x0, y1), dec(x1, y1), fx), fy);
-}
-VKR_DEV f4 sample_trilinear(const Pyramid& p, f2 uv, f2 duvdx, f2 duvdy) {
-  const float w = (float)p.mip[0].fw, h = (float)p.mip[0].fh;
-  // rho^2 = max squared footprint; lod = log2(rho).  The level pair comes from the exponent of rho^2
-  // (exact), only the blend factor from log2f (smooth) — a libm ulp must not flip the pair.
-  const float rx2 = (duvdx.x * w) * (duvdx.x * w) + (duvdx.y * h) * (duvdx.y * h);
-  const float ry2 = (duvdy.x * w) * (duvdy.x * w) + (duvdy.y * h) * (duvdy.y * h);
-  const float r2 = vmax(rx2, ry2);
-  int l0 = 0;
-  float f = 0.0f;
-  if (r2 > 1.0f && r2 < 3.0e38f) {
-    l0 = ilogbf(r2) >> 1;  // floor(log2(rho))
-    f = vclamp(0.5f * log2f(r2) - (float)l0, 0.0f, 1.0f);
-  }
-  if (l0 >= p.count - 1) { l0 = p.count - 1; f = 0.0f; }  // sampler LOD range [0, 10] and the chain length
-  const int l1 = min(l0 + 1, p.count - 1);
-  const f4 a = sample_level_repeat(p.mip[l0], uv);
-  if (f == 0.0f || l1 == l0) return a;
-  return mix4(a, sample_level_repeat(p.mip[l1], uv), f);
-}
 
 __global__ __launch_bounds__(256) void k_raster_resolve(ResolveArgs a) {
   const int lx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -311,28 +347,21 @@ __global__ __launch_bounds__(256) void k_raster_resolve(ResolveArgs a) {
     while (di + 1 < a.r.draw_count && gid >= a.r.draws[di + 1].tri_base) di++;
     const DrawDev& d = a.r.draws[di];
     const ScreenTri& t = a.r.setup[gid2];
-    float lambda[3], b[3];
+    float lambda[3];
     uint32_t d24 = 0;
     cover(t, px, py, lambda, &d24);
-    perspective(t, lambda, b);
+    const FragUv fu = fragment_uv(t, px, py, lambda);
+    const float* b = fu.b;
     const f3 in_normal = mk3(BARY(normal.x), BARY(normal.y), BARY(normal.z));
-    const f2 in_uv = mk2(BARY(uv.x), BARY(uv.y));
+    const f2 in_uv = fu.uv;
     const f4 pa = mk4(BARY(pos_after.x), BARY(pos_after.y), BARY(pos_after.z), BARY(pos_after.w));
     const f4 pb = mk4(BARY(pos_before.x), BARY(pos_before.y), BARY(pos_before.z), BARY(pos_before.w));
-    // implicit derivatives: forward differences of the interpolated uv
-    float lx1[3], ly1[3], bx1[3], by1[3];
-    lambda_at(t, px + 1, py, lx1);
-    lambda_at(t, px, py + 1, ly1);
-    perspective(t, lx1, bx1);
-    perspective(t, ly1, by1);
-    const f2 uvx = mk2((bx1[0] * t.v[0].uv.x + bx1[1] * t.v[1].uv.x) + bx1[2] * t.v[2].uv.x, (bx1[0] * t.v[0].uv.y + bx1[1] * t.v[1].uv.y) + bx1[2] * t.v[2].uv.y);
-    const f2 uvy = mk2((by1[0] * t.v[0].uv.x + by1[1] * t.v[1].uv.x) + by1[2] * t.v[2].uv.x, (by1[0] * t.v[0].uv.y + by1[1] * t.v[1].uv.y) + by1[2] * t.v[2].uv.y);
-    const f2 ddx = uvx - in_uv, ddy = uvy - in_uv;
+    const f2 ddx = fu.ddx, ddy = fu.ddy;
     // opaque_taa.frag:26-46
     f4 out_albedo = mk4(0.5f, 0.5f, 0.5f, 1.0f);
-    if (d.albedo_index != 0xFFFFFFFFu) out_albedo = sample_trilinear(a.tex[d.albedo_index], in_uv, ddx, ddy);
+    if (d.albedo_index != 0xFFFFFFFFu) out_albedo = sample_trilinear(a.r.tex[d.albedo_index], in_uv, ddx, ddy);
     f4 out_material = mk4(0.5f, 0.9f, 0.5f, 0.5f);
-    if (d.mr_index != 0xFFFFFFFFu) out_material = sample_trilinear(a.tex[d.mr_index], in_uv, ddx, ddy);
+    if (d.mr_index != 0xFFFFFFFFu) out_material = sample_trilinear(a.r.tex[d.mr_index], in_uv, ddx, ddy);
     const f2 en = encode_normal(in_normal);
     const f2 vel = mk2(0.5f * (pb.x / pb.w - pa.x / pa.w), 0.5f * (pb.y / pb.w - pa.y / pa.w));
     o_albedo = float_to_srgb8(out_albedo.x) | (float_to_srgb8(out_albedo.y) << 8) | (float_to_srgb8(out_albedo.z) << 16) | (float_to_unorm8(out_albedo.w) << 24);
@@ -365,7 +394,7 @@ using namespace vkr;
 static uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 extern "C" uint64_t vkr_raster_scratch_bytes(uint32_t width, uint32_t height, uint32_t triangle_count) {
-  return align_up((uint64_t)width * height * 8u, 256) + align_up(sizeof(DrawDev) * 1024u, 256) +
+  return align_up((uint64_t)width * height * 8u, 256) + align_up(sizeof(DrawDev) * 1024u, 256) + align_up(sizeof(Pyramid) * RASTER_MAX_TEXTURES, 256) +
          align_up(sizeof(ScreenTri) * 2u * (uint64_t)triangle_count, 256) + align_up(4u * (2u * (uint64_t)triangle_count + 64u), 256);
 }
 
@@ -394,12 +423,13 @@ extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_
   for (uint32_t i = 0; i < scene->draw_count; i++) total_tris += scene->draws[i].index_count / 3u;
   if (total_tris >= 0x7FFFFFFFull) { set_error("gbuf_opaque_taa: too many triangles"); return VKR_ERR_EXTENT; }
   if (scratch_bytes < vkr_raster_scratch_bytes((uint32_t)W, (uint32_t)H, (uint32_t)total_tris)) { set_error("gbuf_opaque_taa: scratch too small"); return VKR_ERR_EXTENT; }
+  std::vector<Pyramid> tex(scene->texture_count);
   for (uint32_t i = 0; i < scene->texture_count; i++) {
     const vkr_img& t = scene->textures[i];
     if (t.mip_count < 1 || t.mip_count > VKR_MAX_MIPS) { set_error("gbuf_opaque_taa: texture %u: bad mip count", i); return VKR_ERR_MIPS; }
-    ra.tex[i].count = (int)t.mip_count;
-    for (int m = 0; m < (int)t.mip_count; m++) VKR_TRY(make_tex(&t, m, VKR_FMT_RGBA8_SRGB, "gbuf_opaque_taa.texture", &ra.tex[i].mip[m]));
-    for (int m = (int)t.mip_count; m < 16; m++) ra.tex[i].mip[m] = ra.tex[i].mip[0];
+    tex[i].count = (int)t.mip_count;
+    for (int m = 0; m < (int)t.mip_count; m++) VKR_TRY(make_tex(&t, m, VKR_FMT_RGBA8_SRGB, "gbuf_opaque_taa.texture", &tex[i].mip[m]));
+    for (int m = (int)t.mip_count; m < 16; m++) tex[i].mip[m] = tex[i].mip[0];
   }
   // per-draw constants: view_projection * model exactly as opaque_taa.vert:39,44 multiplies them
   std::vector<DrawDev> draws(scene->draw_count);
@@ -418,7 +448,8 @@ extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_
     d.albedo_index = s.albedo_index; d.mr_index = s.mr_index;
     d.index_offset = s.index_offset; d.vertex_offset = s.vertex_offset;
     d.tri_base = tri_base; d.tri_count = s.index_count / 3u;
-    d.pad0 = d.pad1 = 0;
+    d.alpha_test = (s.albedo_index != 0xFFFFFFFFu && !(s.reserved & VKR_RASTER_DRAW_OPAQUE_ALBEDO)) ? 1u : 0u;
+    d.pad1 = 0;
     tri_base += d.tri_count;
   }
   if (tri_base >= 0x7FFFFFFFu) { set_error("gbuf_opaque_taa: too many triangles"); return VKR_ERR_EXTENT; }
@@ -426,7 +457,8 @@ extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_
   r.vertices = scene->vertices; r.indices = scene->indices;
   r.vis = (unsigned long long*)scratch;
   r.draws = (const DrawDev*)((uint8_t*)scratch + align_up((uint64_t)W * H * 8u, 256));
-  r.setup = (ScreenTri*)((uint8_t*)r.draws + align_up(sizeof(DrawDev) * 1024u, 256));
+  r.tex = (const Pyramid*)((uint8_t*)r.draws + align_up(sizeof(DrawDev) * 1024u, 256));
+  r.setup = (ScreenTri*)((uint8_t*)r.tex + align_up(sizeof(Pyramid) * RASTER_MAX_TEXTURES, 256));
   uint32_t* large_count = (uint32_t*)((uint8_t*)r.setup + align_up(sizeof(ScreenTri) * 2u * total_tris, 256));
   uint32_t* large_list = large_count + 64;
   r.draw_count = scene->draw_count;
@@ -438,6 +470,12 @@ extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_
     for (uint32_t k = 0; k < n; k++) c.d[k] = draws[i + k];
     for (uint32_t k = n; k < 8; k++) c.d[k] = draws[i];
     hipLaunchKernelGGL(k_raster_store_draws, dim3(1), dim3(64), 0, stream, c, const_cast<DrawDev*>(r.draws) + i, n);
+  }
+  for (uint32_t i = 0; i < scene->texture_count; i += 4) {
+    TexChunk c;
+    const uint32_t n = scene->texture_count - i < 4u ? scene->texture_count - i : 4u;
+    for (uint32_t k = 0; k < 4; k++) c.p[k] = tex[i + (k < n ? k : 0)];
+    hipLaunchKernelGGL(k_raster_store_textures, dim3(1), dim3(64), 0, stream, c, const_cast<Pyramid*>(r.tex) + i, n);
   }
   const size_t npx = (size_t)W * H;
   hipLaunchKernelGGL(k_raster_clear, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, r.vis, npx);

@@ -53,6 +53,7 @@ def lib():
         l.vkrh_set_camera.argtypes = [C.c_void_p, C.POINTER(HostCamera)]
         l.vkrh_pin_randoms.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32]
         l.vkrh_set_gtao_mode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        l.vkrh_set_gathered_mips.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_run.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_end_frame.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_image.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(abi.VkrImg)]
@@ -170,6 +171,10 @@ class HostFrame:
                 tex[i].levels[m] = a.ctypes.data
         self._check(lib().vkrh_load_scene(self.h, C.c_void_p(verts.ctypes.data), len(verts), C.c_void_p(idx.ctypes.data), len(idx),
                                           draws, len(sc.draws), tex, len(sc.textures)))
+
+    def set_gathered_mips(self, n):
+        """tiled frames: how many whole-frame Hi-Z mips (image mips 1..n) arrive by all-gather; STAGE_HIZ_TAIL rebuilds the rest"""
+        self._check(lib().vkrh_set_gathered_mips(self.h, n))
 
     def pin_screen_trace(self, angle_jitter=0.0, random_offset=0.25, frame_count=0):
         self._check(lib().vkrh_pin_screen_trace(self.h, angle_jitter, random_offset, frame_count))

@@ -157,6 +157,7 @@ struct PostFxFrame {
 
   void end_frame(bool swap_depth) {  // main.cpp:416-420
     if (swap_depth) graph.remap(gbuffer.depth, gbuffer.prev_depth);
+    graph.remap(gtao.output, gtao.prev_frame);  // main.cpp:417: the reprojection variant's history (gtao.cpp:241-284)
     taa_pass.remap_targets(graph);
     ssr.remap_images(graph);
     gtao.remap(graph);
@@ -261,6 +262,12 @@ int vkrh_pin_screen_trace(void* frame, float angle_jitter, float random_offset, 
 }
 int vkrh_set_gtao_mode(void* frame, uint32_t use_mis, uint32_t two_directions) {
   return guarded([&] { auto* f = (PostFxFrame*)frame; f->gtao.set_mis(use_mis != 0); f->gtao.set_two_directions(two_directions != 0); });
+}
+int vkrh_set_gathered_mips(void* frame, uint32_t mips) {
+  return guarded([&] {
+    if (mips < 1 || mips > 4) throw std::runtime_error{"vkrh_set_gathered_mips: 1..4"};
+    ((PostFxFrame*)frame)->hiz_gathered_mips = mips;
+  });
 }
 int vkrh_run(void* frame, uint32_t stage_mask) { return guarded([&] { ((PostFxFrame*)frame)->run(stage_mask); }); }
 int vkrh_end_frame(void* frame, uint32_t swap_depth) { return guarded([&] { ((PostFxFrame*)frame)->end_frame(swap_depth != 0); }); }

@@ -375,6 +375,8 @@ void register_hot_path_programs() {
         vkr_raster_draw r{};
         std::memcpy(&r, d.push.data(), 16);
         r.index_offset = d.first_index; r.index_count = d.index_count; r.vertex_offset = (uint32_t)d.vertex_offset;
+        if (st.set1 && r.albedo_index < st.set1->image_array.size() && st.set1->image_array[r.albedo_index].image->alpha_never_zero)
+          r.reserved |= VKR_RASTER_DRAW_OPAQUE_ALBEDO;  // the discard of opaque_taa.frag:32-34 cannot fire
         draws.push_back(r);
       }
       vkr_raster_scene scene{};

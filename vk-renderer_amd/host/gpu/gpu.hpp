@@ -77,6 +77,9 @@ struct Image {
   vkr_img describe_layer(uint32_t layer) const;
   // tightly packed rows of one mip -> device (asset upload; synchronous)
   void upload_mip(uint32_t mip, const void* rows);
+  // asset knowledge the raster stage can use: no texel of any mip level has alpha 0 (set by the scene loader, which
+  // sees the host bytes), so opaque_taa.frag:32-34 can never discard a fragment textured with this image
+  bool alpha_never_zero = false;
 
  private:
   ImageInfo info;

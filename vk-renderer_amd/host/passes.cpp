@@ -638,7 +638,13 @@ CompiledScene make_scene(const Vertex *vertices, uint32_t vertex_count, const ui
   for (uint32_t i = 0; i < texture_count; i++) {  // images.cpp:32-49: RGBA8_SRGB with a full mip chain
     const TextureData &t = textures[i];
     auto img = std::make_shared<gpu::Image>(gpu::ImageInfo {VK_FORMAT_R8G8B8A8_SRGB, COLOR, t.width, t.height, 1, t.mip_levels, 1}, gpu::FrameWindow {});
-    for (uint32_t m = 0; m < t.mip_levels; m++) img->upload_mip(m, t.levels[m]);
+    bool never_zero = true;
+    for (uint32_t m = 0; m < t.mip_levels; m++) {
+      img->upload_mip(m, t.levels[m]);
+      const size_t texels = size_t(std::max(1u, t.width >> m)) * std::max(1u, t.height >> m);
+      for (size_t k = 0; k < texels && never_zero; k++) never_zero = t.levels[m][4 * k + 3] != 0;
+    }
+    img->alpha_never_zero = never_zero;
     out.images.push_back(img);
     out.textures.push_back(Texture {i, 0});
   }

@@ -121,8 +121,12 @@ class Scene:
         for i, (m, n) in enumerate(self.transforms):
             tr[i].model, tr[i].normal = abi.Mat4.from_np(m), abi.Mat4.from_np(n)
         dr = (abi.RasterDraw * max(1, len(self.draws)))()
+        # VKR_RASTER_DRAW_OPAQUE_ALBEDO: no texel of any level of the albedo texture has alpha 0, so the discard of
+        # opaque_taa.frag:32-34 cannot fire and the stage may skip the coverage-time alpha test
+        opaque = [all(int(lv[..., 3].min()) > 0 for lv in levels) for levels in self.textures]
         for i, d in enumerate(self.draws):
-            dr[i] = abi.RasterDraw(d["transform"], d["albedo"], d["mr"], d["flags"], d["index_offset"], d["index_count"], d["vertex_offset"], 0)
+            hint = 1 if (d["albedo"] != INVALID and opaque[d["albedo"]] and not d.get("force_alpha_test")) else 0
+            dr[i] = abi.RasterDraw(d["transform"], d["albedo"], d["mr"], d["flags"], d["index_offset"], d["index_count"], d["vertex_offset"], hint)
         tx = (abi.VkrImg * max(1, len(self.textures)))()
         for i, levels in enumerate(self.textures):
             h, w = levels[0].shape[:2]
@@ -265,9 +269,11 @@ def _checker(size, cells, c0, c1, seed):
     return out
 
 
-def procedural_scene(detail=24):
+def procedural_scene(detail=24, cutout=False):
     """Ground quad, a back wall and three textured spheres in front of the reference camera (eye (0, 1, -1) looking
-    along +z): exercises near/far depth ranges, both windings, shared edges, texture minification and magnification."""
+    along +z): exercises near/far depth ranges, both windings, shared edges, texture minification and magnification.
+    cutout: adds a fence (a quad stood up at z = 5 whose texture has alpha-0 holes, like Sponza's foliage and chains):
+    opaque_taa.frag:32-34 discards those fragments and the geometry behind shows through."""
     sc = Scene()
     albedo = sc.add_texture(_checker(256, 16, (200, 60, 50), (230, 220, 200), 1))
     mr = sc.add_texture(_checker(128, 8, (128, 70, 20), (128, 200, 230), 2))
@@ -287,4 +293,10 @@ def procedural_scene(detail=24):
     sc.add_draw(sc.add_transform(trs((-1.6, 0.9, 3.5), (0.9, 0.9, 0.9), 0.3)), sphere, albedo, mr)
     sc.add_draw(sc.add_transform(trs((1.2, 0.6, 2.2), (0.6, 0.6, 0.6), 1.1)), sphere, stone, mr)
     sc.add_draw(sc.add_transform(trs((0.3, 1.4, 6.0), (1.4, 1.4, 1.4), 2.0)), sphere, INVALID, INVALID)
+    if cutout:
+        fence_tex = _checker(128, 8, (40, 160, 60), (20, 110, 40), 4)
+        yy, xx = np.mgrid[0:128, 0:128]
+        fence_tex[((xx // 8) + (yy // 8)) % 3 == 0, 3] = 0  # holes of 8x8 texels
+        fence = np.array([[3, 0, 0, 0.5], [0, 0, -1.2, 1.2], [0, 1, 0, 5], [0, 0, 0, 1]], dtype=np.float32)
+        sc.add_draw(sc.add_transform(fence), quad, sc.add_texture(fence_tex), INVALID, flags=0xFF)
     return sc

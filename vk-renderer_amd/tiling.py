@@ -35,9 +35,19 @@ import torch.distributed as dist
 
 from . import abi
 
-HALO = 48          # full-res pixels, a multiple of 16 (the gathered mips 1..4 of a window must align with the frame's); the longest
+HALO = 48          # full-res pixels, a multiple of 16 (the gathered mips of a window must align with the frame's); the longest
                    # fixed reach is GTAO main + filter, 20 half-res = 40 full-res pixels.  Half-res surfaces carry HALO // 2
-GATHER_MIPS = 4    # depth image-mips 1..4 are tile-aligned for tiles divisible by 16
+GATHER_MIPS = 4    # at most: depth image-mips 1..4 are tile-aligned for tiles divisible by 16
+
+
+def gather_mips_for(tw, th, halo):
+    """How many depth image-mips (1..k) of a tile are whole texels of the frame's mips: k = the largest power of two that
+    divides the tile extent and the halo, capped at GATHER_MIPS.  The 15360x1080 strips of BASELINE config 4 on 8 GPUs
+    give 3 (1080 = 8 * 135); coarser whole-frame mips are rebuilt locally from the last gathered one."""
+    k = GATHER_MIPS
+    while k > 1 and (tw % (1 << k) or th % (1 << k) or halo % (1 << k)):
+        k -= 1
+    return k
 
 
 def grid_for(world):
@@ -84,6 +94,9 @@ class HostBackend:
             view = self._views[key] = t[off: off + h * pitch].view(h, pitch)
         return view, abi.FORMAT_BYTES[d.format], (d.origin_x, d.origin_y, d.width, d.height)
 
+    def set_gather_mips(self, n):
+        self.frame.set_gathered_mips(n)
+
     def prepare(self):
         h = self.host
         self.frame.run(h.STAGE_LUT | h.STAGE_GBUFFER | h.STAGE_PREV_DEPTH)
@@ -113,8 +126,9 @@ class TiledFrame:
         assert W % cols == 0 and H % rows == 0
         self.tw, self.th = W // cols, H // rows
         self.halo = halo if world > 1 else 0
+        self.gather_mips = gather_mips_for(self.tw, self.th, self.halo)
         if world > 1:
-            assert self.tw % (1 << GATHER_MIPS) == 0 and self.th % (1 << GATHER_MIPS) == 0, "tile must be divisible by 16"
+            assert self.tw % 2 == 0 and self.th % 2 == 0, "tile extent must be even"
             assert self.halo % 2 == 0 and self.halo <= min(self.tw, self.th)
         self.tile = tile_rect(rank, cols, rows, self.tw, self.th)
         self.window = window_rect(rank, cols, rows, self.tw, self.th, self.halo)
@@ -123,6 +137,7 @@ class TiledFrame:
         # "host": the C++ host mirror on the GPU; anything else: a class with HostBackend's interface
         cls = HostBackend if backend == "host" else backend
         self.backend = cls(setup, self.window, self.tiled, device)
+        self.backend.set_gather_mips(self.gather_mips)
         self.frame = self.backend.frame
         self.device = self.backend.device
         self._xchg_s = 0.0
@@ -261,7 +276,7 @@ class TiledFrame:
     def _gather_plan(self, group):
         """[(src image, src mip, dst image, dst mip, divisor)]: tile interior at full-res >> divisor"""
         if group == "hiz":
-            return [("depth", m, "frame_hiz", m - 1, m) for m in range(1, GATHER_MIPS + 1)] + [("dn", 0, "frame_normals", 0, 1)]
+            return [("depth", m, "frame_hiz", m - 1, m) for m in range(1, self.gather_mips + 1)] + [("dn", 0, "frame_normals", 0, 1)]
         return [("albedo", 0, "frame_albedo", 0, 0)]
 
     def gather_pack(self, group):
