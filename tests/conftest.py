@@ -30,3 +30,24 @@ def oracle_lib():
 @pytest.fixture(scope="session", autouse=True)
 def _oracle_backend_registered():
     _oracle()
+
+
+@pytest.fixture
+def parity_table(request):
+    """Collects every [parity] row of the test and writes it to gpurun_out/parity_<test>.json (gpurun merges that
+    directory back; the tables quoted in DESIGN.md are copied from there into profiles/)."""
+    import json
+    import re
+
+    import parity
+
+    parity.ROWS.clear()
+    yield parity.ROWS
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        name = re.sub(r"[^A-Za-z0-9_.-]+", "_", request.node.name)
+        with open(os.path.join(out, f"parity_{name}.json"), "w") as f:
+            json.dump({"test": request.node.nodeid, "rows": list(parity.ROWS)}, f, indent=1)
+    except OSError:
+        pass

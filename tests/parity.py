@@ -12,6 +12,15 @@ from vk_renderer_amd import abi
 
 REL_TOL = 1e-3
 
+# every comparison made through report() / record() since the last reset: tests at BASELINE sizes dump this table
+# (tests/conftest.py: parity_table fixture -> gpurun_out/parity_<test>.json, copied to profiles/ when judged)
+ROWS = []
+
+
+def record(name, texels, bit_equal, outside_tol, max_abs_diff, rule):
+    ROWS.append({"image": name, "texels": int(texels), "bit_equal": int(bit_equal), "outside_tolerance": int(outside_tol),
+                 "max_abs_diff": float(max_abs_diff), "rule": rule})
+
 
 def storage_step(fmt, ref):
     if fmt in (abi.FMT_RGBA8_UNORM, abi.FMT_RGBA8_SRGB, abi.FMT_R8_UNORM):
@@ -46,4 +55,5 @@ def report(name, fmt, got, ref):
         maxabs = float(np.nanmax(np.abs(got.astype(np.float64) - ref.astype(np.float64)))) if got.size else 0.0
     exact = int((got == ref).all(axis=-1).sum()) if got.size else 0
     print(f"[parity] {name:14s} texels {bad.size:9d}  bit-equal {exact:9d}  outside-tol {n:6d}  max|diff| {maxabs:.3e}")
+    record(name, bad.size, exact, n, maxabs, f"|d| <= {REL_TOL} |ref| or one storage step")
     return n, bad

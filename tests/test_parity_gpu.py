@@ -6,7 +6,7 @@ import pytest
 from vk_renderer_amd import abi
 from vk_renderer_amd.chain import PostFxChain
 
-from parity import report
+from parity import record, report
 
 pytestmark = pytest.mark.gpu
 
@@ -54,6 +54,7 @@ def _compare(ref, gpu, names, budget):
                     a, b = a & 0xFFFFFF, b & 0xFFFFFF
                 nbad = int((a != b).any(axis=-1).sum())
                 print(f"[parity] {name + '.' + str(mip):14s} texels {a.shape[0] * a.shape[1]:9d}  bit-exact mismatches {nbad}")
+                record(f"{name}.{mip}", a.shape[0] * a.shape[1], a.shape[0] * a.shape[1] - nbad, nbad, 0.0, "bit-exact")
                 assert nbad == 0, f"{name} mip {mip}: {nbad} texels differ (integer path must be bit-exact)"
             else:
                 nbad, _ = report(f"{name}.{mip}", r.format, g.decode(mip, hg), r.decode(mip))
@@ -102,13 +103,14 @@ def test_chain_stagewise(size, oracle_lib):
         _compare(ref, gpu, outs, budget=1e-4)
 
 
-def test_chain_stagewise_full_size(oracle_lib):
-    """The BASELINE.json frame itself: every pass at 3840x2160 against the oracle on the same bytes."""
+def test_chain_stagewise_full_size(oracle_lib, parity_table):
+    """The BASELINE.json frame itself (c2): every pass at 3840x2160 against the oracle on the same bytes.  The table
+    of counts goes to gpurun_out/parity_test_chain_stagewise_full_size.json (-> profiles/parity_c2.json)."""
     test_chain_stagewise((3840, 2160), oracle_lib)
 
 
 @pytest.mark.parametrize("size", [(640, 360), (3840, 2160)])
-def test_chain_end_to_end(size, oracle_lib):
+def test_chain_end_to_end(size, oracle_lib, parity_table):
     """Whole frame on the GPU with no re-synchronisation, two frames with history ping-pong."""
     ref, gpu = _pair(*size, oracle_lib)
     for c in (ref, gpu):

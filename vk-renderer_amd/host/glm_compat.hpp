@@ -23,6 +23,10 @@ inline vec3 operator*(vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 inline float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline vec3 cross(vec3 a, vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline vec3 normalize(vec3 a) { float l = std::sqrt(dot(a, a)); return {a.x / l, a.y / l, a.z / l}; }
+inline float length(vec3 a) { return std::sqrt(dot(a, a)); }
+inline float length(vec4 a) { return std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w); }
+inline float floor(float a) { return std::floor(a); }
+inline vec4& operator/=(vec4& a, float s) { a.x /= s; a.y /= s; a.z /= s; a.w /= s; return a; }
 inline float radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
 struct mat4 {
   vec4 c[4];  // columns

@@ -150,6 +150,9 @@ static const ImageViewObject& view_of(VkImageView v) {
   if (!v) throw std::runtime_error{"write_set: null image view"};
   return *(const ImageViewObject*)v;
 }
+void write_binding(VkDescriptorSet, const AccelerationStructBinding&) {
+  throw std::runtime_error{"Acceleration structures are not supported on the post-process path (ray-query AO is out of scope)"};
+}
 void write_binding(VkDescriptorSet set, const TextureBinding& b) {
   auto& s = slot_of(set, b.binding);
   s = SetSlot{};

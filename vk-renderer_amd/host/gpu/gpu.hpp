@@ -188,6 +188,13 @@ struct SSBOBinding : BaseBinding {
   SSBOBinding(uint32_t b, const BufferPtr& buf) : BaseBinding{b}, buffer{buf} {}
   BufferPtr buffer;
 };
+// gpu/descriptors.hpp:168-183: named by GTAO::add_main_rt_pass only.  No program on this path can read an
+// acceleration structure, so writing one into a set is an error, not a silent no-op.
+struct AccelerationStructBinding : BaseBinding {
+  AccelerationStructBinding(uint32_t b, VkAccelerationStructureKHR t) : BaseBinding{b}, tlas{t} {}
+  VkAccelerationStructureKHR tlas;
+};
+void write_binding(VkDescriptorSet set, const AccelerationStructBinding& b);
 void write_binding(VkDescriptorSet set, const TextureBinding& b);
 void write_binding(VkDescriptorSet set, const StorageTextureBinding& b);
 void write_binding(VkDescriptorSet set, const UBOBinding& b);
@@ -232,7 +239,13 @@ struct BasePipeline {
   std::optional<std::string> program;
 };
 struct ComputePipeline : BasePipeline {};
-struct RenderSubpassDesc { bool use_depth = false; std::vector<VkFormat> formats{}; };
+struct RenderSubpassDesc {  // gpu/pipelines.hpp: {use_depth, {formats}}; the reference writes set_rendersubpass({false, {format}})
+  RenderSubpassDesc() {}
+  RenderSubpassDesc(bool depth, std::initializer_list<VkFormat> f) : use_depth{depth}, formats{f} {}
+  RenderSubpassDesc(bool depth, std::vector<VkFormat> f) : use_depth{depth}, formats{std::move(f)} {}
+  bool use_depth = false;
+  std::vector<VkFormat> formats{};
+};
 struct VertexInput {};
 struct Registers {
   struct { VkBool32 depthTestEnable = VK_FALSE; VkCompareOp depthCompareOp = VK_COMPARE_OP_LESS; VkBool32 depthWriteEnable = VK_FALSE; } depth_stencil;
@@ -242,6 +255,7 @@ struct GraphicsPipeline : BasePipeline {
   void set_registers(const Registers& r) { regs = r; }
   void set_rendersubpass(const RenderSubpassDesc& d) { subpass = d; }
   const RenderSubpassDesc& get_renderpass_desc() const { return subpass; }
+  VkRenderPass get_renderpass() const { return nullptr; }  // no render-pass objects on this path (only the UI consumed it)
  private:
   Registers regs;
   RenderSubpassDesc subpass;

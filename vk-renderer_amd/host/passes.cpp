@@ -2,6 +2,7 @@
 // uploads (file:line given per method), lists its bindings in the shader's binding order and hands them to
 // pass_recorder.hpp; the bound program (gpu/gpu.cpp program table) turns that into one C-ABI call.
 #include "passes.hpp"
+#include "imgui_pass.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -215,6 +216,22 @@ void GTAO::add_main_pass_graphics(RenderGraph &graph, const GTAOParams &params, 
   rec::fullscreen(graph, "GTAO", main_pipeline_gfx,
     {rec::sampled_mips(0, depth, sampler, DEPTH, depth_lod, 1), rec::uniform(1, params), rec::sampled(2, normal, sampler), rec::color_target(raw)},
     rec::push(pc), ext.width, ext.height);
+}
+
+// :150-196 (VK_KHR_ray_query against the scene's TLAS): not part of this path
+void GTAO::add_main_rt_pass(RenderGraph &, const GTAORTParams &, VkAccelerationStructureKHR, ImageResourceId, ImageResourceId) {
+  throw std::runtime_error {"GTAO::add_main_rt_pass: the ray-query pass needs a scene acceleration structure (out of scope: SURVEY.md section 2b)"};
+}
+
+// :528-536, the panel as the reference draws it; the ImGui names are inert in this headless build (imgui_pass.hpp)
+void GTAO::draw_ui() {
+  ImGui::Begin("GTAO");
+  ImGui::Checkbox("Enable MIS", &mis_gtao);
+  ImGui::Checkbox("Use 2 directions", &two_directions);
+  ImGui::Checkbox("Only reflections ao", &only_reflections);
+  ImGui::SliderFloat("Weight ratio", &weight_ratio, 1.0, 5.0);
+  clear_history = ImGui::Button("Clear history") || clear_history;  // a headless request_clear_history() stays pending
+  ImGui::End();
 }
 
 // :241-284: filtered + prev_frame -> output
@@ -550,6 +567,34 @@ void ScreenSpaceTrace::add_accumulate_pass(RenderGraph &graph, const ScreenTrace
 }
 
 // ==== DeferedShadingPass (defered_shading.cpp) ======================================================================
+// advanced_ssr.cpp:497-545: the program "tile_regression" is not in the table (out of scope)
+void AdvancedSSR::run_tile_regression_pass(RenderGraph &, const AdvancedSSRParams &, const Gbuffer &) {
+  tile_regression = gpu::create_compute_pipeline("tile_regression");  // throws "Program not found"
+}
+
+// advanced_ssr.cpp:556-567
+void AdvancedSSR::render_ui() {
+  ImGui::Begin("SSSR");
+  ImGui::SliderFloat("Max Roughness", &settings.max_rougness, 0.f, 1.f);
+  ImGui::SliderFloat("Min glossy roughness", &settings.glossy_roughness_value, 0.f, 1.f);
+  ImGui::SliderInt("Temporal rays", &settings.max_accumulated_rays, 1, 128);
+  ImGui::Checkbox("Enable normalization", &settings.normalize_reflections);
+  ImGui::Checkbox("Enable accumulation", &settings.accumulate_reflections);
+  ImGui::Checkbox("Enable random rays", &settings.update_random);
+  ImGui::Checkbox("Enable blur", &settings.use_blur);
+  ImGui::Checkbox("Enable bilateral filter", &settings.bilateral_filter);
+  ImGui::End();
+}
+
+// defered_shading.cpp:120-126
+void DeferedShadingPass::draw_ui() {
+  ImGui::Begin("DeferedShading");
+  ImGui::SliderFloat("Max Roughness", &min_max_roughness.y, min_max_roughness.x, 1.f);
+  ImGui::SliderFloat("Min Roughness", &min_max_roughness.x, 0.f, min_max_roughness.y);
+  ImGui::Checkbox("Show AO only", &only_ao);
+  ImGui::End();
+}
+
 DeferedShadingPass::DeferedShadingPass(RenderGraph &graph, SDL_Window *) {  // :14-31
   pipeline = fullscreen_pipeline("defered_shading");
   sampler = default_sampler();

@@ -233,6 +233,14 @@ struct GTAOParams {
   float zfar;
 };
 
+struct GTAORTParams {  // gtao.hpp:20-26 (ray-query pass; named by add_main_rt_pass only)
+  glm::mat4 camera_to_world;
+  float fovy;
+  float aspect;
+  float znear;
+  float zfar;
+};
+
 struct GTAOReprojection {
   glm::mat4 camera_to_prev_frame;
   float fovy;
@@ -251,6 +259,15 @@ struct GTAO {
     rendergraph::ImageResourceId normal,
     rendergraph::ImageResourceId material,
     rendergraph::ImageResourceId preintegrated_pdf);
+
+  // gtao.cpp:150-196: needs VK_KHR_ray_query and the scene's TLAS (compiled out of the reference's own frame loop,
+  // main.cpp:40 USE_RAY_QUERY 0; SURVEY.md section 2b: out of scope).  Declared for source compatibility; throws.
+  void add_main_rt_pass(
+    rendergraph::RenderGraph &graph,
+    const GTAORTParams &params,
+    VkAccelerationStructureKHR tlas,
+    rendergraph::ImageResourceId depth,
+    rendergraph::ImageResourceId normal);
 
   void add_main_pass_graphics(
     rendergraph::RenderGraph &graph,
@@ -280,6 +297,8 @@ struct GTAO {
     const GTAOParams &params,
     rendergraph::ImageResourceId normal);
 
+  void draw_ui();  // gtao.cpp:528-536; headless: the ImGui names are inert (imgui_pass.hpp), use the setters below
+
   void remap(rendergraph::RenderGraph &graph) {
     graph.remap(accumulated_history, accumulated_ao);
   }
@@ -307,6 +326,8 @@ private:
   float next_base_angle();
 
   gpu::GraphicsPipeline main_pipeline_gfx;
+  gpu::GraphicsPipeline rt_main_pipeline;  // never bound: the ray-query program is not part of this path
+  gpu::BufferPtr random_vectors;           // gtao.cpp:35: consumed by the ray-query pass only
   gpu::ComputePipeline reproject_pipeline;
   gpu::ComputePipeline deinterleave_pipeline;
   gpu::ComputePipeline main_deinterleaved_pipeline;
@@ -352,6 +373,8 @@ struct AdvancedSSRParams {
 std::vector<glm::vec4> halton23_seq(uint32_t count);
 
 struct AdvancedSSR {
+  void render_ui();  // advanced_ssr.cpp:556-567; headless: the ImGui names are inert (imgui_pass.hpp), use get_settings()
+
   AdvancedSSR(rendergraph::RenderGraph &graph, uint32_t w, uint32_t h);
   void run(
     rendergraph::RenderGraph &graph,
@@ -400,9 +423,15 @@ struct AdvancedSSR {
   rendergraph::BufferResourceId get_glossy_tiles() const { return glossy_tiles; }
   rendergraph::BufferResourceId get_reflective_indirect() const { return reflective_indirect; }
   rendergraph::BufferResourceId get_glossy_indirect() const { return glossy_indirect; }
+  // advanced_ssr.cpp:497-545 "tile_regression" (per-tile plane fit; commented out of run() in the reference and out of
+  // scope here).  Declared for source compatibility; throws "Program not found" like any program
+  // the table does not hold.
+  void run_tile_regression_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff);
 
 private:
   gpu::BufferPtr halton_buffer;
+  gpu::ComputePipeline tile_regression;        // never bound (see run_tile_regression_pass)
+  rendergraph::ImageResourceId tile_planes;    // advanced_ssr.cpp:85-86: output of the regression pass (RGBA32F; never allocated here)
 
   gpu::ComputePipeline trace_pass;
   gpu::ComputePipeline filter_pass;
@@ -564,6 +593,8 @@ struct DeferedShadingPass {
     rendergraph::ImageResourceId brdf_tex,
     rendergraph::ImageResourceId reflections,
     rendergraph::ImageResourceId out_image);
+
+  void draw_ui();  // defered_shading.cpp:120-126; headless: the ImGui names are inert (imgui_pass.hpp)
 
   // headless equivalents of the ImGui sliders (defered_shading.cpp:120-126)
   void set_roughness_range(float lo, float hi) { min_max_roughness = glm::vec2 {lo, hi}; }

@@ -93,6 +93,14 @@ VkImageView RenderResources::get_view(const ImageViewId& ref) {
 
 // ---- graph ---------------------------------------------------------------------------------------------
 RenderGraph::RenderGraph(void* stream) : cmd{stream}, main_stream{stream} { gpu::register_hot_path_programs(); }
+ImageResourceId RenderGraph::get_backbuffer() {
+  if (!has_backbuffer) {
+    backbuffer = create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R8G8B8A8_SRGB, VK_IMAGE_ASPECT_COLOR_BIT, win_w ? win_w : 1u, win_h ? win_h : 1u},
+                              VK_IMAGE_TILING_OPTIMAL, VK_IMAGE_USAGE_COLOR_ATTACHMENT_BIT | VK_IMAGE_USAGE_TRANSFER_SRC_BIT);
+    has_backbuffer = true;
+  }
+  return backbuffer;
+}
 RenderGraph::~RenderGraph() {
   for (auto& t : timed) { event_pool.push_back(t.start); event_pool.push_back(t.stop); }
   for (void* e : event_pool) (void)hipEventDestroy((hipEvent_t)e);

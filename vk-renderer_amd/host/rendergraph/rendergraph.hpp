@@ -102,6 +102,10 @@ struct RenderGraphBuilder {  // rendergraph.hpp:17-55
   void transfer_read(ImageResourceId id, uint32_t base_mip, uint32_t mip_count, uint32_t base_layer, uint32_t layer_count);
   void transfer_write(ImageResourceId id, uint32_t base_mip, uint32_t mip_count, uint32_t base_layer, uint32_t layer_count);
   gpu::ImageInfo get_image_info(ImageResourceId id);
+  // rendergraph.hpp:139: the swapchain image of the current frame.  Headless: an RGBA8_SRGB image of the window's
+  // extent, created the first time somebody asks (only DeferedShadingPass's constructor does, for its format).
+  ImageResourceId get_backbuffer();
+
   uint32_t get_frames_count() const { return 1; }
  private:
   GraphResources& resources;
@@ -118,6 +122,10 @@ struct RenderResources {  // rendergraph.hpp:57-83
   VkDescriptorSet allocate_set(VkDescriptorSetLayout) { return cmd.allocate_set(); }
   VkDescriptorSet allocate_set(const gpu::GraphicsPipeline&, uint32_t) { return cmd.allocate_set(); }
   VkDescriptorSet allocate_set(const gpu::ComputePipeline&, uint32_t) { return cmd.allocate_set(); }
+  // rendergraph.hpp:139: the swapchain image of the current frame.  Headless: an RGBA8_SRGB image of the window's
+  // extent, created the first time somebody asks (only DeferedShadingPass's constructor does, for its format).
+  ImageResourceId get_backbuffer();
+
   uint32_t get_frames_count() const { return 1; }
   uint32_t get_frame_index() const { return 0; }
   void reset() { views.clear(); }
@@ -164,6 +172,10 @@ struct RenderGraph {  // rendergraph.hpp:112-158
   BufferResourceId create_buffer(VmaMemoryUsage mem, uint64_t size, VkBufferUsageFlags usage) { return resources.create_buffer(mem, size, usage); }
   gpu::ImageInfo get_descriptor(ImageResourceId id) const { return resources.get_image(id)->get_info(); }
   void remap(ImageResourceId src, ImageResourceId dst) { resources.remap(src, dst); }
+
+  // rendergraph.hpp:139: the swapchain image of the current frame.  Headless: an RGBA8_SRGB image of the window's
+  // extent, created the first time somebody asks (only DeferedShadingPass's constructor does, for its format).
+  ImageResourceId get_backbuffer();
 
   uint32_t get_frames_count() const { return 1; }
   uint32_t get_frame_index() const { return 0; }
@@ -213,6 +225,8 @@ struct RenderGraph {  // rendergraph.hpp:112-158
   std::vector<uint32_t> submitted_lanes;
   bool has_window = false;
   uint32_t full_w = 0, full_h = 0, win_w = 0, win_h = 0;
+  ImageResourceId backbuffer;
+  bool has_backbuffer = false;
   int32_t org_x = 0, org_y = 0;
 };
 

@@ -19,7 +19,7 @@ typedef uint64_t VkDeviceSize;
 enum VkFormat {
   VK_FORMAT_UNDEFINED = 0, VK_FORMAT_R8_UNORM = 9, VK_FORMAT_R8G8B8A8_UNORM = 37, VK_FORMAT_R8G8B8A8_SRGB = 43,
   VK_FORMAT_R16_SFLOAT = 76, VK_FORMAT_R16G16_UNORM = 77, VK_FORMAT_R16G16_SFLOAT = 83,
-  VK_FORMAT_R16G16B16A16_UNORM = 91, VK_FORMAT_R16G16B16A16_SFLOAT = 97, VK_FORMAT_R32_SFLOAT = 100,
+  VK_FORMAT_R16G16B16A16_UNORM = 91, VK_FORMAT_R16G16B16A16_SFLOAT = 97, VK_FORMAT_R32_UINT = 98, VK_FORMAT_R32_SFLOAT = 100,
   VK_FORMAT_R32G32B32A32_SFLOAT = 109, VK_FORMAT_D24_UNORM_S8_UINT = 129
 };
 enum { VK_IMAGE_ASPECT_COLOR_BIT = 1, VK_IMAGE_ASPECT_DEPTH_BIT = 2, VK_IMAGE_ASPECT_STENCIL_BIT = 4 };
@@ -55,6 +55,9 @@ typedef struct VkSampler_T* VkSampler;
 typedef struct VkImageView_T* VkImageView;
 typedef struct VkDescriptorSet_T* VkDescriptorSet;
 typedef struct VkDescriptorSetLayout_T* VkDescriptorSetLayout;
+typedef struct VkRenderPass_T* VkRenderPass;
+typedef struct VkCommandBuffer_T* VkCommandBuffer;
+typedef struct VkAccelerationStructureKHR_T* VkAccelerationStructureKHR;  // named by GTAO::add_main_rt_pass only
 #endif
 
 #if __has_include(<vk_mem_alloc.h>) && !defined(VKR_FORCE_VK_COMPAT)
