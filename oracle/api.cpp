@@ -7,7 +7,22 @@
 
 using namespace oracle;
 
+namespace oracle {
+thread_local uint32_t ub_flags = 0;
+int ub_oob_mode = 0;
+static uint64_t g_ub_counts[UB_PASS_COUNT][2];  // [pass][0: out of frame, 1: beyond the last mip] output pixels
+void ub_count(int pass, uint32_t flags) {
+  if (flags & UB_OUT_OF_FRAME) __atomic_fetch_add(&g_ub_counts[pass][0], 1, __ATOMIC_RELAXED);
+  if (flags & UB_BEYOND_LAST_MIP) __atomic_fetch_add(&g_ub_counts[pass][1], 1, __ATOMIC_RELAXED);
+}
+}  // namespace oracle
+
 extern "C" {
+
+// undefined-behaviour accounting (formats.hpp): counts of output pixels whose value went through the frozen OOB rule
+void vkr_ref_ub_reset(void) { std::memset(g_ub_counts, 0, sizeof(g_ub_counts)); }
+void vkr_ref_ub_counts(uint64_t* out /* [UB_PASS_COUNT][2] */) { std::memcpy(out, g_ub_counts, sizeof(g_ub_counts)); }
+void vkr_ref_ub_set_oob_mode(int mode) { ub_oob_mode = mode; }
 
 uint32_t vkr_format_bytes(uint32_t format) {
   switch (format) {

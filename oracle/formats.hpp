@@ -99,6 +99,23 @@ inline uint8_t float_to_srgb8(float x) {
   return (uint8_t)lo;
 }
 
+// ---- accounting of the frozen undefined behaviour ------------------------------
+// A texelFetch outside the frame or beyond the view's last mip is undefined in the reference (no robust image access,
+// gpu/driver.cpp:185-189); the restatement freezes "returns 0".  To bound what that choice is worth, Image::fetch marks
+// the calling thread when the rule produced the value, a UbPixel guard around one output pixel turns the mark into a
+// per-pass count, and ub_oob_mode switches the rule to the other plausible hardware behaviour (clamp to the edge texel /
+// the last mip) so that a second run shows which outputs actually change.  tools/ub_masks.py drives this.
+enum UbPass { UB_SSSR_TRACE = 0, UB_SSSR_FILTER, UB_SSSR_BLUR, UB_GTAO_MAIN, UB_GTAO_FILTER, UB_GTAO_ACCUMULATE, UB_TAA, UB_PASS_COUNT };
+enum { UB_OUT_OF_FRAME = 1u, UB_BEYOND_LAST_MIP = 2u };
+extern thread_local uint32_t ub_flags;
+extern int ub_oob_mode;  // 0: frozen rule (fetch returns 0); 1: clamp to the frame edge / last mip (sensitivity runs only)
+void ub_count(int pass, uint32_t flags);
+struct UbPixel {
+  int pass;
+  explicit UbPixel(int p) : pass(p) { ub_flags = 0; }
+  ~UbPixel() { if (ub_flags) ub_count(pass, ub_flags); }
+};
+
 // ---- image view --------------------------------------------------------------------
 struct Image {
   vkr_img d;
@@ -141,8 +158,18 @@ struct Image {
   // mip range -> 0.  Inside the frame but outside the window held in memory (only
   // possible when tiled with too small a halo): clamped to the window.
   vec4 fetch(int gx, int gy, int mip) const {
-    if (mip < 0 || mip >= mips()) return vec4();
-    if (gx < 0 || gy < 0 || gx >= fw(mip) || gy >= fh(mip)) return vec4();
+    if (mip < 0 || mip >= mips()) {
+      ub_flags |= UB_BEYOND_LAST_MIP;
+      if (ub_oob_mode == 0 || mip < 0) return vec4();
+      // sensitivity run: the coordinate was computed for `mip`; rescale it to the last mip that exists
+      const int last = mips() - 1;
+      return fetch_clamped(gx << (mip - last), gy << (mip - last), last);
+    }
+    if (gx < 0 || gy < 0 || gx >= fw(mip) || gy >= fh(mip)) {
+      ub_flags |= UB_OUT_OF_FRAME;
+      if (ub_oob_mode == 0) return vec4();
+      return fetch_clamped(gx, gy, mip);
+    }
     int lx = clamp(gx - ox(mip), 0, w(mip) - 1);
     int ly = clamp(gy - oy(mip), 0, h(mip) - 1);
     return load_local(lx, ly, mip);

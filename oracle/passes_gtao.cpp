@@ -135,6 +135,7 @@ extern "C" int vkr_ref_gtao_main(const vkr_img* depth, const vkr_gtao_params* pa
     for (int lx = 0; lx < out.w(); lx++) {
       int gx = x0 + lx;
       if (gx >= tw) continue;
+      UbPixel ub(UB_GTAO_MAIN);
       ivec2 pixel_pos(gx, gy);
       vec2 screen_uv(((float)gx + 0.5f) / (float)tw, ((float)gy + 0.5f) / (float)th);
       vec2 occlusion(0.0f, 1.0f / (2.0f * PI));
@@ -162,6 +163,7 @@ extern "C" int vkr_ref_gtao_filter(const vkr_img* depth, const vkr_img* raw_gtao
     for (int lx = 0; lx < out.w(); lx++) {
       int gx = out.ox() + lx;
       if (gx >= tw) continue;
+      UbPixel ub(UB_GTAO_FILTER);
       float pixel_depth = d.fetch(gx, gy, 0).x;
       float linear_depth = linearize_depth2(pixel_depth, znear, zfar);
       float weight_sum = 0.0f, ao = 0.0f;

@@ -133,6 +133,7 @@ extern "C" int vkr_ref_sssr_trace(const vkr_img* depth, const vkr_img* normal, c
     int gy = OUT_RAY.oy() + ly;
     for (int lx = 0; lx < OUT_RAY.w(); lx++) {
       int gx = OUT_RAY.ox() + lx;
+      UbPixel ub(UB_SSSR_TRACE);
       vec2 tex_size((float)tw, (float)th);
       vec2 screen_uv(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
       vec3 material_v = MATERIAL.sample(screen_uv).xyz();
@@ -240,6 +241,7 @@ extern "C" int vkr_ref_sssr_filter(const vkr_img* rays, const vkr_img* depth, co
     int gy = OUT.oy() + ly;
     for (int lx = 0; lx < OUT.w(); lx++) {
       int gx = OUT.ox() + lx;
+      UbPixel ub(UB_SSSR_FILTER);
       vec2 tex_size((float)tw, (float)th);
       vec2 screen_uv((float)gx / tex_size.x, (float)gy / tex_size.y);
       vec4 material_v = MATERIAL.sample(screen_uv);
@@ -306,6 +308,7 @@ extern "C" int vkr_ref_sssr_blur(const vkr_img* depth, const vkr_img* normal, co
     int gy = OUT.oy() + ly;
     for (int lx = 0; lx < OUT.w(); lx++) {
       int gx = OUT.ox() + lx;
+      UbPixel ub(UB_SSSR_BLUR);
       vec2 tex_size((float)tw, (float)th);
       vec2 screen_uv(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
       float roughness = MATERIAL.sample(screen_uv).y;

@@ -43,7 +43,7 @@ def test_c3_8k_synthetic_stagewise(oracle_lib, parity_table):
         _sync_inputs(ref, gpu)
         getattr(ref, stage)()
         getattr(gpu, stage)()
-        _compare(ref, gpu, outs, budget=1e-4)
+        _compare(ref, gpu, outs, budget=0)  # measured: zero outside tolerance in every pass (profiles/parity_c3.json)
 
 
 def test_c3_8k_rasterised_through_scene_renderer(oracle_lib, parity_table):

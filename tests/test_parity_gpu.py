@@ -87,7 +87,7 @@ def test_pdf_lut(oracle_lib):
 
 
 @pytest.mark.parametrize("size", [(256, 144), (640, 360), (1920, 1080), (500, 282), (70, 38), (206, 226)])  # 206x226: half-res 103x113, floor-dispatch extent 96x112 (uv -> texel map stretched by 7 %)
-def test_chain_stagewise(size, oracle_lib):
+def test_chain_stagewise(size, oracle_lib, budget=1e-4):
     """Each pass gets bit-identical inputs (the oracle's), so a failure names the pass."""
     ref, gpu = _pair(*size, oracle_lib)
     ref.synth()
@@ -99,14 +99,15 @@ def test_chain_stagewise(size, oracle_lib):
         getattr(ref, stage)()
         getattr(gpu, stage)()
         # a handful of texels may flip a hit / break decision through libm-vs-ocml ulps in the
-        # smooth part; the budget is 1e-4 of the image and the count is printed
-        _compare(ref, gpu, outs, budget=1e-4)
+        # smooth part; the budget is 1e-4 of the image at the small / ragged sizes and the count is printed
+        _compare(ref, gpu, outs, budget=budget)
 
 
 def test_chain_stagewise_full_size(oracle_lib, parity_table):
     """The BASELINE.json frame itself (c2): every pass at 3840x2160 against the oracle on the same bytes.  The table
     of counts goes to gpurun_out/parity_test_chain_stagewise_full_size.json (-> profiles/parity_c2.json)."""
-    test_chain_stagewise((3840, 2160), oracle_lib)
+    # measured: zero texels outside tolerance in every pass (profiles/parity_c2.json), so the budget here is zero
+    test_chain_stagewise((3840, 2160), oracle_lib, budget=0)
 
 
 @pytest.mark.parametrize("size", [(640, 360), (3840, 2160)])
@@ -122,10 +123,12 @@ def test_chain_end_to_end(size, oracle_lib, parity_table):
         for c in (ref, gpu):
             c.frame()
             c.swap_histories()
-    # after swap the freshest outputs sit in the *_hist slots
+    # after swap the freshest outputs sit in the *_hist slots.  With no resynchronisation a one-code difference of an
+    # intermediate can push a downstream texel over the line: measured 2 of 2 073 600 texels of raw at 4K
+    # (profiles/parity_c2.json); the budget is 1e-5 of the image.
     _compare(ref, gpu, ("dn", "dv", "depth"), budget=0)
-    _compare(ref, gpu, ("rays", "raw", "reflections", "filtered"), budget=2e-4)
-    _compare(ref, gpu, ("blurred_hist", "acc_hist", "taa_hist"), budget=2e-4)
+    _compare(ref, gpu, ("rays", "raw", "reflections", "filtered"), budget=1e-5 if size[0] >= 3840 else 2e-4)
+    _compare(ref, gpu, ("blurred_hist", "acc_hist", "taa_hist"), budget=1e-5 if size[0] >= 3840 else 2e-4)
 
 
 def test_gtao_only_config1(oracle_lib):
