@@ -149,15 +149,47 @@ def main():
     torch.cuda.set_device(device)
     import torch.distributed as dist
 
+    # Control plane (barrier, max-reduction of the clock, handing the RCCL id around): torch.distributed over gloo.
+    # Data plane: the C++ tiled frame issues grouped RCCL launches itself (vkr_all_gather / vkr_halo_exchange through the
+    # communicator made here).  VKR_EXCHANGE=torch selects the older path where tiling.py issues the exchanges through
+    # torch.distributed's RCCL backend; it is also the fallback when the native communicator cannot be made.
+    comm, exchange = None, "none"
     if world > 1 or args.rehearse_tiled:
-        if world == 1:  # rehearsal: a one-rank RCCL group, rendezvous on the loopback address
+        if world == 1:  # rehearsal: one-rank groups, rendezvous on the loopback address
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-        elif share_gpu:
-            dist.init_process_group("gloo")
+        want_torch = os.environ.get("VKR_EXCHANGE") == "torch"
+        if share_gpu:  # RCCL refuses two ranks on one device: host-staged gloo exchange through tiling.py
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            exchange = "torch.distributed gloo, host-staged (one-GPU rehearsal)"
+        elif want_torch:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            exchange = "torch.distributed RCCL (VKR_EXCHANGE=torch)"
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+            def share(ident):
+                box = [ident]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+
+            why = ""
+            try:
+                comm = abi.Comm(rank, world, share)
+            except Exception as e:  # noqa: BLE001 — whatever went wrong, every rank must take the same branch
+                why = f"{type(e).__name__}: {e}"
+            ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                exchange = "native RCCL (C++ tiled frame: vkr_all_gather / vkr_halo_exchange)"
+            else:
+                print(f"[bench] native RCCL communicator unavailable ({why or 'failed on another rank'}): falling back to torch.distributed", file=sys.stderr)
+                if comm is not None:
+                    comm.close()
+                    comm = None
+                dist.destroy_process_group()
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+                exchange = "torch.distributed RCCL (fallback: " + (why or "native communicator failed on another rank") + ")"
 
     W, H = (int(v) for v in args.frame.lower().split("x"))
     cols, rows = grid_for(world)
@@ -165,7 +197,7 @@ def main():
         raise SystemExit(f"frame {W}x{H} does not divide into a {cols}x{rows} grid")
     tw, th = W // cols, H // rows
     setup = FrameSetup(W, H, use_mis=0 if args.config == "c1" else 1)
-    tiled = TiledFrame(setup, rank, world, cols, rows, device, force_tiled=args.rehearse_tiled)
+    tiled = TiledFrame(setup, rank, world, cols, rows, device, force_tiled=args.rehearse_tiled, native=comm is not None, comm=comm)
     frame = tiled.frame
     frame.set_async(args.overlap)
     if args.config == "c1":      # GTAO main pass only (BASELINE configs[0]); non-MIS: 1+4 read, 2 written = 7 B/px
@@ -240,7 +272,7 @@ def main():
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if marks else []
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -294,6 +326,7 @@ def main():
                 "grid": [cols, rows],
                 "halo_px": tiled.halo,
                 "gathered_hiz_mips": tiled.gather_mips if tiled.tiled else 0,
+                "exchange": exchange,
                 "gbuffer": "rasterised procedural mesh scene (GbufferPass timed)" if args.raster else "analytic generator (not timed)",
             },
             "roofline": {
@@ -333,6 +366,10 @@ def main():
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
+    if comm is not None:
+        torch.cuda.synchronize(device)
+        frame.close()
+        comm.close()
     if dist.is_initialized():
         dist.destroy_process_group()
 

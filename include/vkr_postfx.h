@@ -256,6 +256,16 @@ int vkr_sssr_blur(const vkr_img* depth, const vkr_img* normal, const vkr_img* re
                   const vkr_img* material, const vkr_img* history, const vkr_img* velocity,
                   const vkr_img* history_depth, const vkr_img* out_blurred,
                   const vkr_reproject_params* params, const vkr_blur_push* push, void* stream);
+/* The same pass with a caller-provided scratch of vkr_sssr_blur_scratch_bytes(out_blurred) bytes (16 per half-res pixel,
+ * 16-byte aligned device memory): a prepare launch decodes {normal, depth} of every pixel once instead of once per tile
+ * that stages it (2.85 x).  Output identical to vkr_sssr_blur; no reference counterpart (the scratch is not a binding
+ * of blur.comp), so hosts that mirror the reference bindings call vkr_sssr_blur and hosts that own scratch call this. */
+uint64_t vkr_sssr_blur_scratch_bytes(const vkr_img* out_blurred);
+int vkr_sssr_blur_staged(const vkr_img* depth, const vkr_img* normal, const vkr_img* reflections,
+                         const vkr_img* material, const vkr_img* history, const vkr_img* velocity,
+                         const vkr_img* history_depth, const vkr_img* out_blurred,
+                         const vkr_reproject_params* params, const vkr_blur_push* push,
+                         void* scratch, uint64_t scratch_bytes, void* stream);
 
 /* program "gtao_compute_main": gtao.cpp:84-148 + gtao/main.comp (bindings 0..5)          */
 int vkr_gtao_main(const vkr_img* depth, const vkr_gtao_params* params, const vkr_img* normal,
@@ -393,6 +403,26 @@ typedef struct vkr_rect_copy {
   uint32_t row_bytes, rows;
 } vkr_rect_copy;
 int vkr_copy_rects(const vkr_rect_copy* rects, uint32_t count, void* stream);
+
+/* ---- the wire of the multi-GPU frame: RCCL over xGMI (SURVEY.md 8(b) "vkr_halo_exchange", 8(e)) -------------
+ * One process per GPU.  Rank 0 makes an id (vkr_comm_unique_id) and hands its bytes to every rank out of band (a
+ * file, a TCP store, MPI ...); every rank then calls vkr_comm_create, collectively, with its device current.  RCCL is
+ * loaded with dlopen on first use (librccl.so.1, or $VKR_RCCL_LIBRARY): the library does not link against it.
+ * Both exchanges are ONE grouped RCCL launch on `stream` and return at once; buffers are device memory.          */
+#define VKR_COMM_ID_BYTES 128
+typedef struct vkr_comm vkr_comm;
+int vkr_comm_unique_id(uint8_t* id_bytes /* [VKR_COMM_ID_BYTES] */);
+int vkr_comm_create(const uint8_t* id_bytes, int rank, int world, vkr_comm** out);
+int vkr_comm_destroy(vkr_comm* comm);
+int vkr_comm_rank(const vkr_comm* comm, int* rank, int* world);
+/* all-gather of several surfaces at once: recv receives [rank][bytes] from every rank's send (out of place; with
+ * horizontal strips a tile's rows of a surface are contiguous, so recv can be the whole-frame image itself)       */
+typedef struct vkr_gather_part { const void* send; void* recv; uint64_t bytes; } vkr_gather_part;
+int vkr_all_gather(vkr_comm* comm, const vkr_gather_part* parts, uint32_t count, void* stream);
+/* halo refresh of one history surface: per neighbour the packed slice to send and the buffer to receive into
+ * (either may be empty); pack / unpack with vkr_copy_rects around it                                               */
+typedef struct vkr_halo_peer { int32_t peer; uint32_t reserved; const void* send; uint64_t send_bytes; void* recv; uint64_t recv_bytes; } vkr_halo_peer;
+int vkr_halo_exchange(vkr_comm* comm, const vkr_halo_peer* peers, uint32_t count, void* stream);
 
 /* float4 streaming-read microbenchmark: the measured-roofline denominator of
  * SURVEY.md 8(d).  Reads `bytes` from `src`, writes one float per block to `sink`.      */

@@ -150,14 +150,16 @@ def test_c5_eight_rays_per_pixel_loop(oracle_lib, parity_table):
 
 
 def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame():
-    """BASELINE configs[3] exactly as bench.py --gpus 8 cuts it: eight 15360x1080 strips (+ 48 px halo, Hi-Z mips 1..3
-    gathered), every rank in-process on the one GPU with the wire played by copies.  Two frames; tile interiors against
-    the plain 15360x8640 frame.  Surfaces no history feeds must be bit-identical; the three history surfaces may deviate
-    where a velocity-driven history read leaves the 48 px halo (clamped to the window): that count is
-    the deviation mask of SURVEY.md 8(e), written to gpurun_out/deviation_c4.json."""
+    """BASELINE configs[3] exactly as bench.py --gpus 8 cuts and drives it: eight 15360x1080 strips (+ 48 px halo, Hi-Z
+    mips 1..3 gathered) through the C++ tiled frame (host/frame.cpp: the frame order, pack / unpack launches and exchange
+    points of the production path), every rank in-process on the one GPU with the wire played by copies of the very
+    buffers the RCCL calls would move.  Two frames; tile interiors against the plain 15360x8640 frame.  Surfaces no
+    history feeds must be bit-identical; the three history surfaces may deviate where a velocity-driven history read
+    leaves the 48 px halo (clamped to the window): that count is the deviation mask of SURVEY.md
+    8(e), written to gpurun_out/deviation_c4.json."""
     import torch
 
-    from test_tiled_lockstep_gpu import OUTPUTS, _lockstep_frame, _move_halos
+    from test_tiled_native_gpu import OUTPUTS, lockstep_frame
     from vk_renderer_amd.tiling import TiledFrame, grid_for
 
     W, H, world = 15360, 8640, 8
@@ -186,14 +188,12 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame():
     del plain
     torch.cuda.empty_cache()
 
-    ranks = [TiledFrame(FrameSetup(W, H), r, world, cols, rows, device) for r in range(world)]
+    ranks = [TiledFrame(FrameSetup(W, H), r, world, cols, rows, device, native=True, comm=None) for r in range(world)]
     for t in ranks:
-        assert t.tiled and t.halo == 48 and t.gather_mips == 3 and t.window[2:] in ((W, th + 48), (W, th + 96))
+        assert t.tiled and t.native and t.halo == 48 and t.gather_mips == 3 and t.window[2:] in ((W, th + 48), (W, th + 96))
         t.prepare()
     for _ in range(frames):
-        _lockstep_frame(ranks)
-    for which in ("taa", "ao", "ssr"):
-        _move_halos(ranks, which)
+        lockstep_frame(ranks)
     for t in ranks:
         t.flush()
     torch.cuda.synchronize()

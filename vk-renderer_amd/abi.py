@@ -255,6 +255,13 @@ def product():
         lib.vkr_stream_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.vkr_stream_read.restype = C.c_int
         lib.vkr_copy_rects.argtypes = [P(RectCopy), C.c_uint32, C.c_void_p]
+        lib.vkr_sssr_blur_scratch_bytes.argtypes = [_IMG]
+        lib.vkr_sssr_blur_scratch_bytes.restype = C.c_uint64
+        lib.vkr_sssr_blur_staged.argtypes = ENTRY_ARGS["sssr_blur"] + [C.c_void_p, C.c_uint64, C.c_void_p]
+        lib.vkr_sssr_blur_staged.restype = C.c_int
+        lib.vkr_comm_unique_id.argtypes = [C.c_void_p]
+        lib.vkr_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
+        lib.vkr_comm_destroy.argtypes = [C.c_void_p]
         lib.vkr_copy_rects.restype = C.c_int
         lib.vkr_raster_scratch_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         lib.vkr_raster_scratch_bytes.restype = C.c_uint64
@@ -274,3 +281,30 @@ def check(rc, lib=None):
         if lib is not None and hasattr(lib, "vkr_last_error"):
             msg = (lib.vkr_last_error() or b"").decode()
         raise RuntimeError(f"vkr call failed with code {rc}: {msg}")
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """RCCL communicator of the C-ABI (include/vkr_postfx.h vkr_comm_*): the wire of the multi-GPU frame.  Rank 0 makes
+    the id, `share` hands its bytes to every rank out of band (e.g. torch.distributed.broadcast_object_list over gloo),
+    then every rank creates the communicator collectively with its device current."""
+
+    def __init__(self, rank, world, share):
+        lib = product()
+        ident = bytes(COMM_ID_BYTES)
+        if rank == 0:
+            buf = (C.c_uint8 * COMM_ID_BYTES)()
+            check(lib.vkr_comm_unique_id(buf), lib)
+            ident = bytes(buf)
+        ident = share(ident)
+        assert len(ident) == COMM_ID_BYTES
+        h = C.c_void_p(0)
+        check(lib.vkr_comm_create((C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(ident), rank, world, C.byref(h)), lib)
+        self.handle, self.rank, self.world = h.value, rank, world
+
+    def close(self):
+        if self.handle:
+            check(product().vkr_comm_destroy(C.c_void_p(self.handle)), product())
+            self.handle = None

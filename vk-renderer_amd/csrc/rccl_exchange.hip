@@ -1,0 +1,148 @@
+// rccl_exchange.hip — the wire of the multi-GPU frame (SURVEY.md 8(b) "vkr_halo_exchange", 8(e); no reference
+// counterpart: the reference is single-queue, gpu/driver.hpp:84).  Host code only.
+//
+//   vkr_all_gather     one grouped ncclAllGather launch for several surfaces (the Hi-Z mips + downsampled normals, or
+//                      the albedo): recv = [rank][bytes], out of place, so a strip's rows land in the whole-frame image
+//   vkr_halo_exchange  one grouped ncclSend / ncclRecv launch refreshing the halo rings of a history surface
+//
+// Both enqueue on the caller's stream and return; nothing blocks the host.  RCCL is loaded with dlopen the first
+// time a communicator is made (librccl.so.1 of the ROCm installation, private namespace), so the library has no
+// link-time dependency on it: a single-GPU process never touches RCCL, and a process that also uses
+// torch.distributed keeps torch's own copy apart from this one.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+#include "vkr_host.hpp"
+
+namespace {
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl g_rccl;
+std::once_flag g_once;
+const char* g_load_error = nullptr;
+
+void load_rccl() {
+  static const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+  const char* forced = getenv("VKR_RCCL_LIBRARY");
+  void* h = forced ? dlopen(forced, RTLD_NOW | RTLD_LOCAL) : nullptr;
+  for (size_t i = 0; !h && !forced && i < sizeof(names) / sizeof(names[0]); i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+  if (!h) { g_load_error = "librccl.so.1 not found (set VKR_RCCL_LIBRARY)"; return; }
+  g_rccl.handle = h;
+#define VKR_SYM(field, name) \
+  *(void**)(&g_rccl.field) = dlsym(h, name); \
+  if (!g_rccl.field) { g_load_error = "RCCL symbol missing: " name; return; }
+  VKR_SYM(GetUniqueId, "ncclGetUniqueId")
+  VKR_SYM(CommInitRank, "ncclCommInitRank")
+  VKR_SYM(CommDestroy, "ncclCommDestroy")
+  VKR_SYM(AllGather, "ncclAllGather")
+  VKR_SYM(Send, "ncclSend")
+  VKR_SYM(Recv, "ncclRecv")
+  VKR_SYM(GroupStart, "ncclGroupStart")
+  VKR_SYM(GroupEnd, "ncclGroupEnd")
+  VKR_SYM(GetErrorString, "ncclGetErrorString")
+#undef VKR_SYM
+}
+
+bool rccl_ready(const char* what) {
+  std::call_once(g_once, load_rccl);
+  if (g_load_error) { vkr::set_error("%s: %s", what, g_load_error); return false; }
+  return true;
+}
+
+int fail(const char* what, ncclResult_t r) {
+  vkr::set_error("%s: RCCL error %d: %s", what, (int)r, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+  return 2000 + (int)r;
+}
+
+}  // namespace
+
+struct vkr_comm {
+  ncclComm_t comm;
+  int rank, world;
+};
+
+static_assert(sizeof(ncclUniqueId) == VKR_COMM_ID_BYTES, "VKR_COMM_ID_BYTES must hold an ncclUniqueId");
+
+extern "C" int vkr_comm_unique_id(uint8_t* id_bytes) {
+  if (!id_bytes) { vkr::set_error("comm_unique_id: NULL argument"); return vkr::VKR_ERR_NULL; }
+  if (!rccl_ready("comm_unique_id")) return vkr::VKR_ERR_LAYOUT;
+  ncclUniqueId id;
+  const ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) return fail("comm_unique_id", r);
+  std::memcpy(id_bytes, &id, sizeof(id));
+  return vkr::VKR_OK;
+}
+
+extern "C" int vkr_comm_create(const uint8_t* id_bytes, int rank, int world, vkr_comm** out) {
+  if (!id_bytes || !out) { vkr::set_error("comm_create: NULL argument"); return vkr::VKR_ERR_NULL; }
+  if (world < 1 || rank < 0 || rank >= world) { vkr::set_error("comm_create: rank %d of %d", rank, world); return vkr::VKR_ERR_EXTENT; }
+  if (!rccl_ready("comm_create")) return vkr::VKR_ERR_LAYOUT;
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes, sizeof(id));
+  ncclComm_t c = nullptr;
+  const ncclResult_t r = g_rccl.CommInitRank(&c, world, id, rank);  // collective over the current device of every rank
+  if (r != ncclSuccess) return fail("comm_create", r);
+  *out = new vkr_comm{c, rank, world};
+  return vkr::VKR_OK;
+}
+
+extern "C" int vkr_comm_destroy(vkr_comm* comm) {
+  if (!comm) return vkr::VKR_OK;
+  const ncclResult_t r = g_rccl.CommDestroy(comm->comm);
+  delete comm;
+  return r == ncclSuccess ? vkr::VKR_OK : fail("comm_destroy", r);
+}
+
+extern "C" int vkr_comm_rank(const vkr_comm* comm, int* rank, int* world) {
+  if (!comm) { vkr::set_error("comm_rank: NULL communicator"); return vkr::VKR_ERR_NULL; }
+  if (rank) *rank = comm->rank;
+  if (world) *world = comm->world;
+  return vkr::VKR_OK;
+}
+
+extern "C" int vkr_all_gather(vkr_comm* comm, const vkr_gather_part* parts, uint32_t count, void* stream) {
+  if (count == 0) return vkr::VKR_OK;
+  if (!comm || !parts) { vkr::set_error("all_gather: NULL argument"); return vkr::VKR_ERR_NULL; }
+  for (uint32_t i = 0; i < count; i++)
+    if (!parts[i].send || !parts[i].recv || parts[i].bytes == 0) { vkr::set_error("all_gather: part %u is empty", i); return vkr::VKR_ERR_NULL; }
+  ncclResult_t r = g_rccl.GroupStart();
+  for (uint32_t i = 0; r == ncclSuccess && i < count; i++)
+    r = g_rccl.AllGather(parts[i].send, parts[i].recv, (size_t)parts[i].bytes, ncclUint8, comm->comm, (hipStream_t)stream);
+  const ncclResult_t e = g_rccl.GroupEnd();
+  if (r != ncclSuccess) return fail("all_gather", r);
+  return e == ncclSuccess ? vkr::VKR_OK : fail("all_gather", e);
+}
+
+extern "C" int vkr_halo_exchange(vkr_comm* comm, const vkr_halo_peer* peers, uint32_t count, void* stream) {
+  if (count == 0) return vkr::VKR_OK;
+  if (!comm || !peers) { vkr::set_error("halo_exchange: NULL argument"); return vkr::VKR_ERR_NULL; }
+  for (uint32_t i = 0; i < count; i++) {
+    const vkr_halo_peer& p = peers[i];
+    if (p.peer < 0 || p.peer >= comm->world || p.peer == comm->rank) { vkr::set_error("halo_exchange: peer %d of rank %d / %d", p.peer, comm->rank, comm->world); return vkr::VKR_ERR_EXTENT; }
+    if ((p.send_bytes && !p.send) || (p.recv_bytes && !p.recv)) { vkr::set_error("halo_exchange: peer %d has a NULL buffer", p.peer); return vkr::VKR_ERR_NULL; }
+  }
+  // every send and receive of the surface in one group: RCCL fuses them into one launch and cannot deadlock on their order
+  ncclResult_t r = g_rccl.GroupStart();
+  for (uint32_t i = 0; r == ncclSuccess && i < count; i++) {
+    const vkr_halo_peer& p = peers[i];
+    if (p.send_bytes) r = g_rccl.Send(p.send, (size_t)p.send_bytes, ncclUint8, p.peer, comm->comm, (hipStream_t)stream);
+    if (r == ncclSuccess && p.recv_bytes) r = g_rccl.Recv(p.recv, (size_t)p.recv_bytes, ncclUint8, p.peer, comm->comm, (hipStream_t)stream);
+  }
+  const ncclResult_t e = g_rccl.GroupEnd();
+  if (r != ncclSuccess) return fail("halo_exchange", r);
+  return e == ncclSuccess ? vkr::VKR_OK : fail("halo_exchange", e);
+}

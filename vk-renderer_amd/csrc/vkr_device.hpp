@@ -94,13 +94,11 @@ VKR_DEV uint32_t f2u(float f) {
 // per XCD) keep the per-XCD load balanced: tile cost varies 10x across the frame (sky vs. rough
 // surfaces).  Ids past the last full group of 8 chunks, and tiles outside the chunked region, map in
 // plain order.  A bijection for every grid size; pure speed — any placement gives the same result.
-template <int CW, int CH> VKR_DEV i2 xcd_block() {
-  const unsigned GW = gridDim.x, GH = gridDim.y;
+template <int CW, int CH> VKR_DEV i2 xcd_tile(unsigned id, unsigned GW, unsigned GH) {
   const unsigned T = CW * CH;
   const unsigned ncx = GW / CW, ncy = GH / CH;
   const unsigned R = ncx * ncy * T;             // tiles inside whole chunks
   const unsigned R8 = (ncx * ncy / 8u) * 8u * T;  // ... inside whole groups of 8 chunks
-  const unsigned id = blockIdx.y * GW + blockIdx.x;
   unsigned chunk, n;
   i2 b;
   if (id < R8) {
@@ -120,6 +118,7 @@ template <int CW, int CH> VKR_DEV i2 xcd_block() {
   b.y = (int)((chunk / ncx) * CH + n / CW);
   return b;
 }
+template <int CW, int CH> VKR_DEV i2 xcd_block() { return xcd_tile<CW, CH>(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y); }
 
 #define VKR_PI 3.1415926535897932384626433832795f
 

@@ -22,6 +22,21 @@ class HostConfig(C.Structure):
                 ("width", C.c_uint32), ("height", C.c_uint32), ("tiled", C.c_uint32), ("stream", C.c_void_p)]
 
 
+class TiledConfig(C.Structure):
+    _fields_ = [("full_width", C.c_uint32), ("full_height", C.c_uint32), ("rank", C.c_uint32), ("world", C.c_uint32),
+                ("halo", C.c_uint32), ("gathered_mips", C.c_uint32), ("force_tiled", C.c_uint32), ("reserved", C.c_uint32),
+                ("stream", C.c_void_p), ("comm", C.c_void_p)]
+
+
+class GatherPart(C.Structure):
+    _fields_ = [("send", C.c_void_p), ("recv", C.c_void_p), ("bytes", C.c_uint64)]
+
+
+class HaloPeer(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("reserved", C.c_uint32), ("send", C.c_void_p), ("send_bytes", C.c_uint64),
+                ("recv", C.c_void_p), ("recv_bytes", C.c_uint64)]
+
+
 class HostCamera(C.Structure):
     _fields_ = [("view", C.c_float * 16), ("prev_view", C.c_float * 16), ("projection", C.c_float * 16),
                 ("fovy", C.c_float), ("aspect", C.c_float), ("znear", C.c_float), ("zfar", C.c_float)]
@@ -73,6 +88,16 @@ def lib():
         l.vkrh_collect_task_times.argtypes = [C.c_void_p]
         l.vkrh_collect_task_times.restype = C.c_char_p
         l.vkrh_set_allocator.argtypes = [_ALLOC, _FREE, C.c_void_p]
+        l.vkrh_tiled_create.argtypes = [C.POINTER(TiledConfig)]
+        l.vkrh_tiled_create.restype = C.c_void_p
+        l.vkrh_tiled_destroy.argtypes = [C.c_void_p]
+        l.vkrh_tiled_frame.argtypes = [C.c_void_p]
+        l.vkrh_tiled_frame.restype = C.c_void_p
+        l.vkrh_tiled_step.argtypes = [C.c_void_p]
+        l.vkrh_tiled_flush.argtypes = [C.c_void_p]
+        l.vkrh_tiled_phase.argtypes = [C.c_void_p, C.c_uint32]
+        l.vkrh_tiled_gather_parts.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(GatherPart), C.c_uint32, C.POINTER(C.c_uint32)]
+        l.vkrh_tiled_halo_peers.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(HaloPeer), C.c_uint32, C.POINTER(C.c_uint32)]
         _lib = l
     return _lib
 
@@ -117,7 +142,10 @@ def _mat16(m):
 
 
 class HostFrame:
-    def __init__(self, setup, device="cuda", window=None, tiled=False, stream=None):
+    def __init__(self, setup, device="cuda", window=None, tiled=False, stream=None, native_tiled=None):
+        """native_tiled: None, or dict(rank, world, halo, gathered_mips, force_tiled, comm) — the frame then lives inside
+        the C++ tiled frame (frame.hpp vkrh_tiled_*: strips, exchanges issued from C++ on their own stream); `window` is
+        derived there."""
         import torch
 
         self.setup = setup
@@ -127,10 +155,22 @@ class HostFrame:
         self.allocator.install()
         if stream is None:
             stream = torch.cuda.current_stream(device).cuda_stream
-        cfg = HostConfig(W, H, ox, oy, ww, wh, 1 if tiled else 0, C.c_void_p(stream))
-        self.h = lib().vkrh_create(C.byref(cfg))
-        if not self.h:
-            raise RuntimeError("vkrh_create failed: " + lib().vkrh_last_error().decode())
+        self.tiled_handle = None
+        if native_tiled is not None:
+            nt = native_tiled
+            comm = nt.get("comm")
+            tc = TiledConfig(W, H, nt["rank"], nt["world"], nt["halo"], nt["gathered_mips"], 1 if nt.get("force_tiled") else 0, 0,
+                             C.c_void_p(stream), C.c_void_p(comm.handle if comm is not None else None))
+            self.comm = comm  # keep the communicator alive as long as the frame
+            self.tiled_handle = lib().vkrh_tiled_create(C.byref(tc))
+            if not self.tiled_handle:
+                raise RuntimeError("vkrh_tiled_create failed: " + lib().vkrh_last_error().decode())
+            self.h = lib().vkrh_tiled_frame(self.tiled_handle)
+        else:
+            cfg = HostConfig(W, H, ox, oy, ww, wh, 1 if tiled else 0, C.c_void_p(stream))
+            self.h = lib().vkrh_create(C.byref(cfg))
+            if not self.h:
+                raise RuntimeError("vkrh_create failed: " + lib().vkrh_last_error().decode())
         cam = HostCamera()
         cam.view, cam.prev_view, cam.projection = _mat16(setup.view), _mat16(setup.prev_view), _mat16(setup.proj)
         cam.fovy, cam.aspect, cam.znear, cam.zfar = [float(v) for v in setup.fazz]
@@ -257,7 +297,34 @@ class HostFrame:
         src = torch.from_numpy(np.ascontiguousarray(host_bytes, dtype=np.uint8).reshape(-1))
         t[off: off + src.numel()].copy_(src)
 
+    # ---- the C++ tiled frame (native_tiled) ---------------------------------------------------------------
+    def tiled_step(self):
+        self._check(lib().vkrh_tiled_step(self.tiled_handle))
+
+    def tiled_flush(self):
+        self._check(lib().vkrh_tiled_flush(self.tiled_handle))
+
+    def tiled_phase(self, p):
+        self._check(lib().vkrh_tiled_phase(self.tiled_handle, p))
+
+    def tiled_gather_parts(self, which):
+        """[(send address, recv address, bytes)] of all-gather `which` (0: Hi-Z mips + normals, 1: albedo)"""
+        out = (GatherPart * 8)()
+        n = C.c_uint32(0)
+        self._check(lib().vkrh_tiled_gather_parts(self.tiled_handle, which, out, 8, C.byref(n)))
+        return [(out[i].send, out[i].recv, out[i].bytes) for i in range(n.value)]
+
+    def tiled_halo_peers(self, surface):
+        """[(peer rank, send address, recv address, bytes)] of halo refresh `surface` (0: TAA, 1: AO, 2: SSR)"""
+        out = (HaloPeer * 2)()
+        n = C.c_uint32(0)
+        self._check(lib().vkrh_tiled_halo_peers(self.tiled_handle, surface, out, 2, C.byref(n)))
+        return [(out[i].peer, out[i].send, out[i].recv, out[i].send_bytes) for i in range(n.value)]
+
     def close(self):
+        if self.tiled_handle:
+            lib().vkrh_tiled_destroy(self.tiled_handle)
+            self.tiled_handle, self.h = None, None
         if self.h:
             lib().vkrh_destroy(self.h)
             self.h = None

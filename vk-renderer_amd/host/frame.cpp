@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -187,6 +188,202 @@ struct PostFxFrame {
       case 28: return screen_trace.filtered; default: return screen_trace.accumulated;
     }
   }
+};
+
+
+// ---- the tiled frame: strips + RCCL (frame.hpp) ----------------------------------------------------------------------
+struct TiledFrame {
+  vkrh_tiled_config cfg;
+  uint32_t W, H, th, y0, wy0, wh;  // tile rows [y0, y0 + th), window rows [wy0, wy0 + wh)
+  bool tiled;
+  std::unique_ptr<PostFxFrame> frame;
+  hipStream_t compute = nullptr, xchg = nullptr;
+  hipEvent_t ev_ready[5] {}, ev_done[5] {};  // 0 hiz, 1 albedo, 2 taa, 3 ao, 4 ssr
+  bool halo_in_flight[3] {false, false, false};
+  struct HaloBuf { void* send = nullptr; void* recv = nullptr; uint64_t bytes = 0; };
+  HaloBuf halo[3][2];  // [surface][0: neighbour above, 1: neighbour below]
+
+  static void check(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error {std::string {what} + ": " + hipGetErrorString(e)}; }
+
+  explicit TiledFrame(const vkrh_tiled_config& c) : cfg {c} {
+    W = c.full_width; H = c.full_height;
+    if (c.world == 0 || c.rank >= c.world || H % c.world) throw std::runtime_error {"vkrh_tiled_create: the frame height must divide by the number of ranks"};
+    th = H / c.world; y0 = c.rank * th;
+    tiled = c.world > 1 || c.force_tiled;
+    const uint32_t k = c.gathered_mips;
+    if (tiled && (k < 1 || k > 4 || th % (1u << k) || W % (1u << k) || (c.world > 1 && c.halo % (1u << k))))
+      throw std::runtime_error {"vkrh_tiled_create: tile extent and halo must be multiples of 2^gathered_mips (1..4)"};
+    if (c.world > 1 && (c.halo > th || (c.halo & 1u))) throw std::runtime_error {"vkrh_tiled_create: halo must be even and no larger than a strip"};
+    const uint32_t halo_px = c.world > 1 ? c.halo : 0;
+    wy0 = y0 >= halo_px ? y0 - halo_px : 0;
+    const uint32_t wy1 = std::min(H, y0 + th + halo_px);
+    wh = wy1 - wy0;
+    compute = (hipStream_t)c.stream;
+    vkrh_config fc {W, H, 0, (int32_t)wy0, W, wh, tiled ? 1u : 0u, c.stream};
+    frame.reset(new PostFxFrame(fc));
+    frame->hiz_gathered_mips = tiled ? k : 4;
+    if (tiled) {
+      check(hipStreamCreateWithFlags(&xchg, hipStreamNonBlocking), "exchange stream");
+      for (auto& e : ev_ready) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
+      for (auto& e : ev_done) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
+      for (int s = 0; s < 3; s++)
+        for (int n = 0; n < 2; n++) {
+          if (!neighbour(n, nullptr)) continue;
+          const vkr_img d = surface(s);
+          halo[s][n].bytes = uint64_t(halo_px >> halo_dv(s)) * d.width * vkr_format_bytes(d.format);
+          halo[s][n].send = gpu::device_alloc(halo[s][n].bytes);
+          halo[s][n].recv = gpu::device_alloc(halo[s][n].bytes);
+        }
+    }
+  }
+  ~TiledFrame() {
+    if (xchg) { (void)hipStreamSynchronize(xchg); (void)hipStreamDestroy(xchg); }
+    for (auto e : ev_ready) if (e) (void)hipEventDestroy(e);
+    for (auto e : ev_done) if (e) (void)hipEventDestroy(e);
+    for (auto& s : halo) for (auto& b : s) { gpu::device_free(b.send); gpu::device_free(b.recv); }
+  }
+
+  // ---- geometry -------------------------------------------------------------------------------------------------
+  bool neighbour(int n, int* rank) const {  // 0: the strip above, 1: the strip below
+    if (cfg.world < 2) return false;
+    if (n == 0 ? cfg.rank == 0 : cfg.rank + 1 == cfg.world) return false;
+    if (rank) *rank = n == 0 ? int(cfg.rank) - 1 : int(cfg.rank) + 1;
+    return true;
+  }
+  static uint32_t halo_dv(int s) { return s == VKRH_HALO_TAA ? 0u : 1u; }
+  // the pass OUTPUT of each history surface (it becomes the history at the end-of-frame remap)
+  vkr_img surface(int s) {
+    const auto id = s == VKRH_HALO_TAA ? frame->taa_pass.get_output() : s == VKRH_HALO_AO ? frame->gtao.accumulated_ao : frame->ssr.get_blurred();
+    return frame->graph.get_image(id)->describe(0, 1);
+  }
+  // pack (to_buffers) / unpack the halo rows of surface s: one vkr_copy_rects launch on the compute stream
+  void copy_halo(int s, bool to_buffers) {
+    const vkr_img d = surface(s);
+    const uint32_t dv = halo_dv(s), bpp = vkr_format_bytes(d.format), rows = cfg.halo >> dv, row_bytes = d.width * bpp;
+    const uint32_t ty0 = (y0 >> dv) - uint32_t(d.origin_y), tth = th >> dv;  // the tile's first row inside the window image
+    vkr_rect_copy rc[2];
+    uint32_t n = 0;
+    for (int nb = 0; nb < 2; nb++) {
+      if (!neighbour(nb, nullptr)) continue;
+      // send: my first / last `rows` tile rows (they lie in that neighbour's halo); receive: the rows just outside my tile
+      const uint32_t send_row = nb == 0 ? ty0 : ty0 + tth - rows, recv_row = nb == 0 ? ty0 - rows : ty0 + tth;
+      const uint64_t img = (uint64_t)(uintptr_t)d.base;
+      if (to_buffers) rc[n++] = vkr_rect_copy {img + uint64_t(send_row) * d.pitch_bytes[0], (uint64_t)(uintptr_t)halo[s][nb].send, d.pitch_bytes[0], row_bytes, row_bytes, rows};
+      else rc[n++] = vkr_rect_copy {(uint64_t)(uintptr_t)halo[s][nb].recv, img + uint64_t(recv_row) * d.pitch_bytes[0], row_bytes, d.pitch_bytes[0], row_bytes, rows};
+    }
+    if (n && vkr_copy_rects(rc, n, compute) != 0) throw std::runtime_error {std::string {"copy_rects: "} + vkr_last_error()};
+  }
+  uint32_t halo_peers(int s, vkr_halo_peer* out) {
+    uint32_t n = 0;
+    for (int nb = 0; nb < 2; nb++) {
+      int peer;
+      if (!neighbour(nb, &peer)) continue;
+      out[n++] = vkr_halo_peer {peer, 0u, halo[s][nb].send, halo[s][nb].bytes, halo[s][nb].recv, halo[s][nb].bytes};
+    }
+    return n;
+  }
+  // A strip's rows of a whole-frame surface are contiguous in the window image AND in the frame image (same width, same
+  // pitch), so every surface is gathered in place: send = the tile's rows where they lie, recv = the frame image.
+  uint32_t gather_parts(int which, vkr_gather_part* out) {
+    auto part = [&](rendergraph::ImageResourceId src, uint32_t src_mip, rendergraph::ImageResourceId dst, uint32_t dst_mip, uint32_t dv) {
+      const vkr_img s = frame->graph.get_image(src)->describe(src_mip, 1), d = frame->graph.get_image(dst)->describe(dst_mip, 1);
+      const uint32_t rows = th >> dv;
+      if (s.pitch_bytes[0] != d.pitch_bytes[0] || d.height != rows * cfg.world || s.width != d.width || d.origin_y != 0)
+        throw std::runtime_error {"tiled frame: window and whole-frame images must share width and row pitch"};
+      const uint32_t ly = (y0 >> dv) - uint32_t(s.origin_y);
+      return vkr_gather_part {(const uint8_t*)s.base + uint64_t(ly) * s.pitch_bytes[0], d.base, uint64_t(rows) * s.pitch_bytes[0]};
+    };
+    uint32_t n = 0;
+    auto& g = frame->gbuffer;
+    if (which == VKRH_GATHER_HIZ) {
+      for (uint32_t m = 1; m <= cfg.gathered_mips; m++) out[n++] = part(g.depth, m, g.frame_hiz, m - 1, m);
+      out[n++] = part(g.downsampled_normals, 0, g.frame_normals, 0, 1);
+    } else {
+      out[n++] = part(g.albedo, 0, g.frame_albedo, 0, 0);
+    }
+    return n;
+  }
+
+  // ---- ordering between the compute and the exchange stream ----------------------------------------------------------
+  void start(int slot, const std::function<int()>& issue) {
+    if (!cfg.comm) return;  // harness mode: the caller moves the bytes between phases
+    check(hipEventRecord(ev_ready[slot], compute), "event record");
+    check(hipStreamWaitEvent(xchg, ev_ready[slot], 0), "stream wait");
+    if (issue() != 0) throw std::runtime_error {std::string {"exchange: "} + vkr_last_error()};
+    check(hipEventRecord(ev_done[slot], xchg), "event record");
+  }
+  void wait(int slot) {
+    if (cfg.comm) check(hipStreamWaitEvent(compute, ev_done[slot], 0), "stream wait");
+  }
+  void start_gather(int which) {
+    start(which, [&] { vkr_gather_part p[8]; const uint32_t n = gather_parts(which, p); return vkr_all_gather(cfg.comm, p, n, xchg); });
+  }
+  void start_halo(int s) {
+    halo_in_flight[s] = true;
+    start(2 + s, [&] { vkr_halo_peer p[2]; const uint32_t n = halo_peers(s, p); return vkr_halo_exchange(cfg.comm, p, n, xchg); });
+  }
+  void finish_halo(int s) {  // the refresh of surface s started in the previous frame: wait for it, then scatter it into the ring
+    if (!halo_in_flight[s]) return;
+    wait(2 + s);
+    copy_halo(s, false);
+    halo_in_flight[s] = false;
+  }
+
+  // ---- the frame, in phases (an exchange may only start / must be complete at a phase boundary) ------------------------
+  void phase(uint32_t p) {
+    PostFxFrame& f = *frame;
+    switch (p) {
+      case 0:
+        f.run(VKRH_STAGE_DOWNSAMPLE);
+        start_gather(VKRH_GATHER_HIZ);
+        start_gather(VKRH_GATHER_ALBEDO);
+        break;
+      case 1:
+        finish_halo(VKRH_HALO_TAA);
+        f.run(VKRH_STAGE_TAA);
+        copy_halo(VKRH_HALO_TAA, true);
+        start_halo(VKRH_HALO_TAA);
+        break;
+      case 2:
+        wait(VKRH_GATHER_HIZ);
+        f.run(VKRH_STAGE_HIZ_TAIL | VKRH_STAGE_SSR_TRACE);
+        break;
+      case 3:  // GTAO needs the trace's (occlusion, pdf) but not the albedo: it runs ahead of the reference's order to hide the second gather
+        finish_halo(VKRH_HALO_AO);
+        f.run(VKRH_STAGE_GTAO);
+        copy_halo(VKRH_HALO_AO, true);
+        start_halo(VKRH_HALO_AO);
+        break;
+      case 4:
+        wait(VKRH_GATHER_ALBEDO);
+        finish_halo(VKRH_HALO_SSR);
+        f.run(VKRH_STAGE_SSR_RESOLVE);
+        copy_halo(VKRH_HALO_SSR, true);
+        start_halo(VKRH_HALO_SSR);
+        f.end_frame(false);
+        break;
+      default: throw std::runtime_error {"vkrh_tiled_phase: phases are 0..4"};
+    }
+  }
+  void step() {
+    if (!tiled) { frame->run(VKRH_STAGE_CHAIN); frame->end_frame(false); return; }
+    if (!cfg.comm && cfg.world > 1) throw std::runtime_error {"vkrh_tiled_step: no communicator (drive vkrh_tiled_phase from a harness instead)"};
+    if (!cfg.comm) {  // one rank, no wire: the gathers degenerate to copies of the tile into the frame images
+      for (uint32_t p = 0; p < VKRH_TILED_PHASES; p++) {
+        if (p == 2) local_gather(VKRH_GATHER_HIZ);
+        if (p == 4) local_gather(VKRH_GATHER_ALBEDO);
+        phase(p);
+      }
+      return;
+    }
+    for (uint32_t p = 0; p < VKRH_TILED_PHASES; p++) phase(p);
+  }
+  void local_gather(int which) {
+    vkr_gather_part p[8];
+    const uint32_t n = gather_parts(which, p);
+    for (uint32_t i = 0; i < n; i++) check(hipMemcpyAsync(p[i].recv, p[i].send, p[i].bytes, hipMemcpyDeviceToDevice, compute), "local gather");
+  }
+  void flush() { for (int s = 0; s < 3; s++) finish_halo(s); }
 };
 
 template <typename F> int guarded(F&& f) {
@@ -443,6 +640,33 @@ int vkrh_selftest_errors(char* buf, uint32_t buf_size) {
   });
   if (buf && buf_size) { std::snprintf(buf, buf_size, "%s", out.c_str()); }
   return 0;
+}
+
+// ---- tiled frame ----------------------------------------------------------------------------------------------------
+void* vkrh_tiled_create(const vkrh_tiled_config* cfg) {
+  TiledFrame* t = nullptr;
+  int rc = guarded([&] {
+    if (!cfg) throw std::runtime_error{"vkrh_tiled_create: NULL config"};
+    t = new TiledFrame(*cfg);
+  });
+  return rc == 0 ? t : nullptr;
+}
+void vkrh_tiled_destroy(void* tiled) { delete (TiledFrame*)tiled; }
+void* vkrh_tiled_frame(void* tiled) { return tiled ? ((TiledFrame*)tiled)->frame.get() : nullptr; }
+int vkrh_tiled_step(void* tiled) { return guarded([&] { ((TiledFrame*)tiled)->step(); }); }
+int vkrh_tiled_flush(void* tiled) { return guarded([&] { ((TiledFrame*)tiled)->flush(); }); }
+int vkrh_tiled_phase(void* tiled, uint32_t phase) { return guarded([&] { ((TiledFrame*)tiled)->phase(phase); }); }
+int vkrh_tiled_gather_parts(void* tiled, uint32_t which, vkr_gather_part* out, uint32_t capacity, uint32_t* count) {
+  return guarded([&] {
+    if (!tiled || !out || !count || capacity < 8 || which > 1) throw std::runtime_error{"vkrh_tiled_gather_parts: bad arguments (capacity >= 8)"};
+    *count = ((TiledFrame*)tiled)->gather_parts((int)which, out);
+  });
+}
+int vkrh_tiled_halo_peers(void* tiled, uint32_t surface, vkr_halo_peer* out, uint32_t capacity, uint32_t* count) {
+  return guarded([&] {
+    if (!tiled || !out || !count || capacity < 2 || surface > 2) throw std::runtime_error{"vkrh_tiled_halo_peers: bad arguments (capacity >= 2)"};
+    *count = ((TiledFrame*)tiled)->halo_peers((int)surface, out);
+  });
 }
 const char* vkrh_last_tasks(void* frame) { return ((PostFxFrame*)frame)->task_names.c_str(); }
 const char* vkrh_last_lanes(void* frame) { return ((PostFxFrame*)frame)->task_lanes.c_str(); }

@@ -115,6 +115,42 @@ const char* vkrh_last_lanes(void* frame);
 /* 0 (default): every task on the frame's stream; 1: independent tasks of one vkrh_run spread over up to three streams */
 int vkrh_set_async(void* frame, uint32_t on);
 
+/* ---- the tiled frame: one process per GPU, horizontal strips, RCCL over xGMI -----------------
+ * Rank r of `world` owns rows [r * H / world, (r + 1) * H / world) of the full_width x full_height frame and holds
+ * them plus `halo` rows above / below (clipped to the frame).  One vkrh_tiled_step() is one frame:
+ *
+ *   downsample | all-gather(depth mips 1..k + downsampled normals) and all-gather(albedo) start on the exchange stream
+ *   TAA (needs neither)            | its halo refresh starts
+ *   Hi-Z tail + SSR trace          (after the first gather)
+ *   GTAO main, filter, accumulate  | its halo refresh starts
+ *   SSR filter + blur              (after the second gather) | its halo refresh starts; history remaps
+ *
+ * Every exchange is one grouped RCCL launch (vkr_all_gather / vkr_halo_exchange) on the frame's own exchange stream,
+ * ordered against the compute stream with events only: the host never blocks, and a halo refresh issued after the
+ * pass that produces a surface is awaited right before the pass that consumes it in the NEXT frame.
+ * comm == NULL builds the same object without a wire: a test harness then advances it phase by phase
+ * (vkrh_tiled_phase) and moves the bytes between in-process ranks itself (vkrh_tiled_gather_parts / _halo_peers). */
+typedef struct vkrh_tiled_config {
+  uint32_t full_width, full_height;
+  uint32_t rank, world;
+  uint32_t halo;            /* full-res pixels, even, a multiple of 2^gathered_mips                          */
+  uint32_t gathered_mips;   /* depth image-mips 1..k travel by all-gather (the tile extent must divide by 2^k) */
+  uint32_t force_tiled;     /* world == 1: still run the gathers and the staged frame (rehearsal)              */
+  uint32_t reserved;
+  void*    stream;          /* compute stream                                                                */
+  vkr_comm* comm;           /* RCCL communicator of include/vkr_postfx.h, or NULL (no wire: lockstep harness) */
+} vkrh_tiled_config;
+enum { VKRH_TILED_PHASES = 5, VKRH_GATHER_HIZ = 0, VKRH_GATHER_ALBEDO = 1, VKRH_HALO_TAA = 0, VKRH_HALO_AO = 1, VKRH_HALO_SSR = 2 };
+void* vkrh_tiled_create(const vkrh_tiled_config* cfg);
+void  vkrh_tiled_destroy(void* tiled);
+void* vkrh_tiled_frame(void* tiled);                 /* the frame inside: every vkrh_* call above works on it       */
+int   vkrh_tiled_step(void* tiled);                  /* one frame, exchanges included (comm != NULL or world == 1)  */
+int   vkrh_tiled_flush(void* tiled);                 /* completes the halo refreshes the last frame left in flight  */
+/* lockstep harness: phase p of the frame without the wire; what must cross ranks between phases is exposed below */
+int   vkrh_tiled_phase(void* tiled, uint32_t phase);
+int   vkrh_tiled_gather_parts(void* tiled, uint32_t which, vkr_gather_part* out, uint32_t capacity, uint32_t* count);
+int   vkrh_tiled_halo_peers(void* tiled, uint32_t surface, vkr_halo_peer* out, uint32_t capacity, uint32_t* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,13 +72,15 @@ def window_rect(rank, cols, rows, tw, th, halo):
 
 
 class HostBackend:
-    """Compute through the C++ host mirror on the GPU (host.HostFrame); images live in torch tensors."""
+    """Compute through the C++ host mirror on the GPU (host.HostFrame); images live in torch tensors.
+    native: dict(rank, world, halo, gathered_mips, force_tiled, comm) -> the frame lives inside the C++ tiled frame
+    (host/frame.hpp vkrh_tiled_*), which also issues the exchanges."""
 
-    def __init__(self, setup, window, tiled, device):
+    def __init__(self, setup, window, tiled, device, native=None):
         from . import host
 
         self.host = host
-        self.frame = host.HostFrame(setup, device=device, window=window, tiled=tiled)
+        self.frame = host.HostFrame(setup, device=device, window=window, tiled=tiled, native_tiled=native)
         self.device = device
         self._views = {}
 
@@ -95,7 +97,8 @@ class HostBackend:
         return view, abi.FORMAT_BYTES[d.format], (d.origin_x, d.origin_y, d.width, d.height)
 
     def set_gather_mips(self, n):
-        self.frame.set_gathered_mips(n)
+        if self.frame.tiled_handle is None:  # the C++ tiled frame was created with it
+            self.frame.set_gathered_mips(n)
 
     def prepare(self):
         h = self.host
@@ -119,7 +122,10 @@ class HostBackend:
 
 
 class TiledFrame:
-    def __init__(self, setup, rank, world, cols, rows, device, backend="host", halo=HALO, force_tiled=False):
+    def __init__(self, setup, rank, world, cols, rows, device, backend="host", halo=HALO, force_tiled=False, native=False, comm=None):
+        """native (strips on the host backend only): the frame order, the pack / unpack launches and the exchanges run in
+        C++ (host/frame.cpp TiledFrame: grouped RCCL launches on its own stream, ordered with events) — step() is one
+        call.  comm: abi.Comm, or None to drive the C++ phases from a harness (tests) / to rehearse on one rank."""
         assert cols * rows == world
         self.setup, self.rank, self.world, self.cols, self.rows_n = setup, rank, world, cols, rows
         W, H = setup.width, setup.height
@@ -135,8 +141,15 @@ class TiledFrame:
         # force_tiled: run the multi-GPU code path (gathers, whole-frame Hi-Z, staged frame) on one rank
         self.tiled = world > 1 or force_tiled
         # "host": the C++ host mirror on the GPU; anything else: a class with HostBackend's interface
-        cls = HostBackend if backend == "host" else backend
-        self.backend = cls(setup, self.window, self.tiled, device)
+        self.native = bool(native) and self.tiled
+        if self.native:
+            assert backend == "host" and cols == 1, "the C++ tiled frame cuts horizontal strips"
+            self.backend = HostBackend(setup, self.window, self.tiled, device,
+                                       native=dict(rank=rank, world=world, halo=self.halo, gathered_mips=self.gather_mips,
+                                                   force_tiled=force_tiled, comm=comm))
+        else:
+            cls = HostBackend if backend == "host" else backend
+            self.backend = cls(setup, self.window, self.tiled, device)
         self.backend.set_gather_mips(self.gather_mips)
         self.frame = self.backend.frame
         self.device = self.backend.device
@@ -219,6 +232,12 @@ class TiledFrame:
         self._frame_no += 1
 
     def step(self):
+        if self.native:
+            t0 = time.perf_counter()
+            self.frame.tiled_step()
+            self._xchg_s += 0.0 * (time.perf_counter() - t0)  # exchanges are issued inside the C++ step: no separate host cost
+            self._frame_no += 1
+            return
         if not self.tiled:
             if self.stage_plan:
                 for mask in self.stage_plan:
@@ -264,6 +283,9 @@ class TiledFrame:
 
     def flush(self):
         """Completes the halo exchanges the last frame left in flight (call before reading results / stopping a clock)."""
+        if self.native:
+            self.frame.tiled_flush()
+            return
         for which in list(self._halo_packed):
             self._halo_complete(which)
             self.halo_unpack(which)
