@@ -256,16 +256,7 @@ int vkr_sssr_blur(const vkr_img* depth, const vkr_img* normal, const vkr_img* re
                   const vkr_img* material, const vkr_img* history, const vkr_img* velocity,
                   const vkr_img* history_depth, const vkr_img* out_blurred,
                   const vkr_reproject_params* params, const vkr_blur_push* push, void* stream);
-/* The same pass with a caller-provided scratch of vkr_sssr_blur_scratch_bytes(out_blurred) bytes (16 per half-res pixel,
- * 16-byte aligned device memory): a prepare launch decodes {normal, depth} of every pixel once instead of once per tile
- * that stages it (2.85 x).  Output identical to vkr_sssr_blur; no reference counterpart (the scratch is not a binding
- * of blur.comp), so hosts that mirror the reference bindings call vkr_sssr_blur and hosts that own scratch call this. */
-uint64_t vkr_sssr_blur_scratch_bytes(const vkr_img* out_blurred);
-int vkr_sssr_blur_staged(const vkr_img* depth, const vkr_img* normal, const vkr_img* reflections,
-                         const vkr_img* material, const vkr_img* history, const vkr_img* velocity,
-                         const vkr_img* history_depth, const vkr_img* out_blurred,
-                         const vkr_reproject_params* params, const vkr_blur_push* push,
-                         void* scratch, uint64_t scratch_bytes, void* stream);
+
 
 /* program "gtao_compute_main": gtao.cpp:84-148 + gtao/main.comp (bindings 0..5)          */
 int vkr_gtao_main(const vkr_img* depth, const vkr_gtao_params* params, const vkr_img* normal,

@@ -231,23 +231,3 @@ def test_host_mirror_frame_with_shading(size, oracle_lib):
         print(f"[parity] host {hname:13s} outside-tol {bad}")
         assert bad <= 2e-4 * rimg.width * rimg.height, f"host frame {hname}: {bad} texels outside tolerance"
     frame.close()
-
-
-@pytest.mark.parametrize("size", [(640, 360), (206, 226), (1920, 1080)])
-def test_staged_blur_equals_reference_shaped_blur(size, oracle_lib):
-    """vkr_sssr_blur_staged (prepare pass + tiles staging decoded pixels; what the host mirror records) writes the
-    same bytes as vkr_sssr_blur (the entry with exactly the shader's bindings), with and without accumulation."""
-    ref, gpu = _pair(*size, oracle_lib)
-    ref.synth(); ref.build_prev_hiz(); ref.init_histories(); ref.preintegrate_pdf()
-    ref.frame()
-    _sync_inputs(ref, gpu)
-    for kw in ({}, {"accumulate": 0}, {"disable_blur": 1}, {"max_roughness": 0.5}):
-        gpu.ssr_blur(**kw)
-        gpu.sync()
-        plain = gpu.blurred.raw(0).copy()
-        gpu.ssr_blur(staged=True, **kw)
-        gpu.sync()
-        staged = gpu.blurred.raw(0)
-        n = int((plain != staged).any(axis=-1).sum())
-        print(f"[parity] staged blur {kw}: {n} texels differ")
-        assert n == 0

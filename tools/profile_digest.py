@@ -104,8 +104,9 @@ def main():
                 f_kb, cnt = fe[k]["FETCH_SIZE"]
                 w_kb, _ = wr[k]["WRITE_SIZE"]
                 b = (2.0 * f_kb + w_kb) * 1024.0 * n
-                traffic[task] = b
+                traffic[task] = traffic.get(task, 0.0) + b  # a task of several kernels: their sum
                 g.write(f"{task},{k},{cnt},{f_kb:.1f},{w_kb:.1f},{n},{b:.0f}\n")
+        traffic["_source"] = f"{a.tag}_pmc_traffic.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py` at 3840x2160, bytes = 2 x FETCH_SIZE KB + WRITE_SIZE KB per task"
         with open("profiles/traffic.json", "w") as g:
             json.dump(traffic, g, indent=1)
         print("wrote", f"profiles/{a.tag}_pmc_traffic.csv", "profiles/traffic.json")
@@ -130,11 +131,15 @@ def main():
                     ratio = f"{4.0 * cs['SQ_ACTIVE_INST_VALU'] / 1024.0 / (cs['_duration_ns'] * 2.4):.2f}"
                 g.write(f"| {k} | " + " | ".join(f"{cs.get(c, float('nan')):.4g}" for c in names) + f" | {ratio} |\n")
         print("wrote", f"profiles/{a.tag}_sq_counters.md")
-        busy = {}
+        busy, weight = {}, {}
         for k, (task, _) in TASK_OF.items():
             cs = merged.get(k, {})
             if "SQ_ACTIVE_INST_VALU" in cs and cs.get("_duration_ns"):
-                busy[task] = 4.0 * cs["SQ_ACTIVE_INST_VALU"] / 1024.0 / (cs["_duration_ns"] * 2.4)
+                # a task of several kernels: duration-weighted
+                busy[task] = busy.get(task, 0.0) + 4.0 * cs["SQ_ACTIVE_INST_VALU"] / 1024.0 / 2.4
+                weight[task] = weight.get(task, 0.0) + cs["_duration_ns"]
+        busy = {t: v / weight[t] for t, v in busy.items()}
+        busy["_source"] = f"{a.tag}_sq_counters.md: rocprofv3 --pmc SQ_ACTIVE_INST_VALU of `bench.py` at 3840x2160, 4 x count / 1024 SIMDs / (duration x 2.4 GHz)"
         with open("profiles/valu_busy.json", "w") as g:
             json.dump(busy, g, indent=1)
         print("wrote profiles/valu_busy.json")

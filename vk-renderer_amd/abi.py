@@ -255,10 +255,6 @@ def product():
         lib.vkr_stream_read.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.vkr_stream_read.restype = C.c_int
         lib.vkr_copy_rects.argtypes = [P(RectCopy), C.c_uint32, C.c_void_p]
-        lib.vkr_sssr_blur_scratch_bytes.argtypes = [_IMG]
-        lib.vkr_sssr_blur_scratch_bytes.restype = C.c_uint64
-        lib.vkr_sssr_blur_staged.argtypes = ENTRY_ARGS["sssr_blur"] + [C.c_void_p, C.c_uint64, C.c_void_p]
-        lib.vkr_sssr_blur_staged.restype = C.c_int
         lib.vkr_comm_unique_id.argtypes = [C.c_void_p]
         lib.vkr_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
         lib.vkr_comm_destroy.argtypes = [C.c_void_p]

@@ -252,24 +252,10 @@ class PostFxChain:
                   C.byref(self.normal.desc()), C.byref(self.material.desc()), C.byref(self.reflections.desc()),
                   C.byref(tp), C.byref(push))
 
-    def ssr_blur(self, max_roughness=1.0, accumulate=1, disable_blur=0, staged=False):
-        """staged (product backend only): vkr_sssr_blur_staged with caller-owned scratch — same image, the per-pixel
-        decode done once instead of once per staging tile."""
+    def ssr_blur(self, max_roughness=1.0, accumulate=1, disable_blur=0):
         rp = self.setup.reproject_params()
         push = abi.BlurPush(max_roughness, accumulate, disable_blur)
         nm = min(10, self.depth.mips)
-        if staged:
-            import torch
-
-            out = self.blurred.desc()
-            need = int(self.lib.vkr_sssr_blur_scratch_bytes(C.byref(out)))
-            if getattr(self, "_blur_scratch", None) is None or self._blur_scratch.numel() < need:
-                self._blur_scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
-            abi.check(self.lib.vkr_sssr_blur_staged(
-                C.byref(self.depth.desc(0, nm)), C.byref(self.normal.desc()), C.byref(self.reflections.desc()), C.byref(self.material.desc()),
-                C.byref(self.blurred_hist.desc()), C.byref(self.dv.desc()), C.byref(self.prev_depth.desc(0, nm)), C.byref(out), C.byref(rp),
-                C.byref(push), C.c_void_p(self._blur_scratch.data_ptr()), need, self.stream), self.lib)
-            return
         self.call("sssr_blur", C.byref(self.depth.desc(0, nm)), C.byref(self.normal.desc()), C.byref(self.reflections.desc()),
                   C.byref(self.material.desc()), C.byref(self.blurred_hist.desc()), C.byref(self.dv.desc()),
                   C.byref(self.prev_depth.desc(0, nm)), C.byref(self.blurred.desc()), C.byref(rp), C.byref(push))

@@ -6,8 +6,6 @@
 // Roofline: HBM in the compulsory-bytes model (10.3 / 16 / 14 B per full-res pixel), but the
 // march is a chain of <= 80 dependent texel fetches per ray and the blur up to 23x23 taps,
 // so trace is latency-bound and blur ALU/LDS-bound.
-#include <atomic>
-#include <cstdlib>
 #include "vkr_host.hpp"
 #include "hiz_march.hpp"
 #include "ssr_sampling.hpp"
@@ -107,7 +105,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
 
     // trace.comp:61-63,156-158: rand() -> Halton index; sin evaluated in double
     const float rdot = dot(screen_uv, mk2(12.9898f, 78.233f));
-    const float rnd01 = fractf((float)sin((double)rdot) * 43758.5453f);
+    const float rnd01 = fractf(sin_hash_arg(rdot) * 43758.5453f);
     const uint32_t base_index = f2u(rnd01 * (float)VKR_HALTON_SEQ_SIZE);
     const uint32_t index = (base_index + a.frame_random) & (VKR_HALTON_SEQ_SIZE - 1);
     const float4 hv = a.halton[index];
@@ -413,8 +411,7 @@ VKR_DEV f4 blur_single(const float4* s_nd, const uint32_t* s_refl, const BlurCen
 
 // one BLUR_BX x BLUR_BY tile of the output; s_nd / s_refl: the staged tile, one float4 {normal.xyz, depth} + one packed
 // RGBA8 reflection texel per pixel; s_lut: the sRGB decode table (staged by the caller, visible after the barrier below)
-template <bool STAGED>
-VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* s_refl, const float* s_lut, const int tid, const float4* geo = nullptr) {
+VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* s_refl, const float* s_lut, const int tid) {
   const int bx0 = a.out.ox + blk.x * BLUR_BX - BLUR_R;  // frame coordinates of the tile origin
   const int by0 = a.out.oy + blk.y * BLUR_BY - BLUR_R;
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
@@ -437,30 +434,6 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
   }
 
   constexpr int STAGE_ITERS = (BLUR_TW * BLUR_TH + BLUR_THREADS - 1) / BLUR_THREADS;
-  if (STAGED) {
-    // k_blur_prepare decoded {normal, depth} of every pixel of the window once: a staged pixel is one float4 and one
-    // packed reflection texel.  Out of the frame the shader's texelFetch reads depth 0, which makes the bilateral
-    // factor — and with it the whole tap weight — exactly 0 whatever the normal is, so those slots are simply zero.
-    float4 stage_nd[STAGE_ITERS];
-    uint32_t stage_c[STAGE_ITERS];
-#pragma unroll
-    for (int k = 0; k < STAGE_ITERS; k++) {
-      const int t = min(tid + k * BLUR_THREADS, BLUR_TW * BLUR_TH - 1);  // the last batch re-stages the last pixel
-      const int px = bx0 + t % BLUR_TW, py = by0 + t / BLUR_TW;
-      const bool in_frame = px >= 0 && py >= 0 && px < a.out.fw && py < a.out.fh;
-      const int wx = iclamp(px - a.out.ox, 0, a.out.w - 1), wy = iclamp(py - a.out.oy, 0, a.out.h - 1);
-      const float4 g = geo[(size_t)wy * a.out.w + wx];
-      const uint32_t c = load_u32_clamped(a.refl, px, py);
-      stage_nd[k] = in_frame ? g : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      stage_c[k] = in_frame ? c : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < STAGE_ITERS; k++) {
-      const int t = min(tid + k * BLUR_THREADS, BLUR_TW * BLUR_TH - 1);
-      s_nd[t] = stage_nd[k];
-      s_refl[t] = stage_c[k];
-    }
-  } else {
   BilinearTaps stage_normal[STAGE_ITERS];
   uint32_t stage_depth[STAGE_ITERS], stage_refl[STAGE_ITERS];
 #pragma unroll
@@ -483,7 +456,6 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
     const f3 n = decode_normal_fast(taps_resolve<FmtRG16U>(stage_normal[k]));  // only enters the normal weight
     s_nd[t] = make_float4(n.x, n.y, n.z, FmtD24::decode(stage_depth[k]));
     s_refl[t] = stage_refl[k];
-  }
   }
 
   // (3): prev_uv needs the velocity, which has arrived by now
@@ -620,132 +592,12 @@ __global__ __launch_bounds__(BLUR_THREADS, 4) void k_sssr_blur(BlurArgs a) {
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   const int tid = threadIdx.y * BLUR_BX + threadIdx.x;
   srgb_lut_stage(s_lut, tid, BLUR_THREADS);
-  blur_tile<false>(a, xcd_block<4, 2>(), s_nd, s_refl, s_lut, tid);  // chunks of 128 x 64 output pixels
-}
-
-// ---- staged variant ------------------------------------------------------------------------------------------------
-// A 32 x 32 tile stages (32 + 22)^2 pixels: every pixel of the image is decoded by 2.85 tiles, and that decode — four
-// normal texels, the octahedral decode, a normalisation — is a third of the plain kernel's instructions (the fixed
-// ~2700 instructions per wave against 18 per tap pair).  Here k_blur_prepare does it once per pixel into caller-provided
-// scratch (16 B per half-res pixel) and the tiles stage plain float4 loads.  Same values, same tap loop, same image.
-__global__ __launch_bounds__(256) void k_blur_prepare(BlurArgs a, float4* geo) {
-  const int lx = blockIdx.x * 64 + (threadIdx.x & 63), ly = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (lx >= a.out.w || ly >= a.out.h) return;
-  const int px = a.out.ox + lx, py = a.out.oy + ly;
-  const f2 uv = mk2((float)px / (float)a.out.fw, (float)py / (float)a.out.fh);
-  const f3 n = decode_normal_fast(taps_resolve<FmtRG16U>(bilinear_taps_u32(a.normal, uv)));
-  geo[(size_t)ly * a.out.w + lx] = make_float4(n.x, n.y, n.z, FmtD24::decode(load_u32_clamped(a.depth1, px, py)));
-}
-
-__global__ __launch_bounds__(BLUR_THREADS, 4) void k_sssr_blur_staged(BlurArgs a, const float4* geo, const uint32_t* order, int tiles_x) {
-  i2 blk;
-  if (order) {  // cost-ordered launch (below)
-    const uint32_t t = order[blockIdx.x];
-    if (t == 0xFFFFFFFFu) return;
-    blk.x = (int)(t % (uint32_t)tiles_x); blk.y = (int)(t / (uint32_t)tiles_x);
-  } else {
-    blk = xcd_block<4, 2>();
-  }
-  __shared__ float4 s_nd[BLUR_TH * BLUR_TW];
-  __shared__ uint32_t s_refl[BLUR_TH * BLUR_TW];
-  __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
-  const int tid = threadIdx.y * BLUR_BX + threadIdx.x;
-  srgb_lut_stage(s_lut, tid, BLUR_THREADS);
-  blur_tile<true>(a, blk, s_nd, s_refl, s_lut, tid, geo);
-}
-
-// ---- cost-ordered launch --------------------------------------------------------------------------------------
-// A tile costs between 15 and 180 us depending on the blur radius of its pixels (sigma follows the roughness), and
-// the plain launch runs its last ~70 us at falling occupancy: 2040 tiles over 512 resident blocks, heavy tiles started
-// late finish alone.  The dispatcher hands out workgroups in id order as slots free up — it is a work queue — so
-// the remedy is the order of the list: k_blur_classify estimates every tile's cost (sum of (2r+1)^2 over an 8 x 8
-// sample of its pixels), k_blur_order sorts the tiles per XCD (ids are dealt round-robin over the 8 XCDs; a tile
-// stays on the XCD its 128 x 64 chunk belongs to, so neighbours still share an L2) and the blur takes
-// tile = order[block id].  Pure scheduling: any order gives the same image.
-struct BlurOrder {
-  uint32_t* order;   // [8 * per_xcd]: tile id (y * tiles_x + x) or 0xFFFFFFFF (hole: the lists of the XCDs differ in length)
-  uint32_t* cost;    // [tiles]
-  int tiles_x, tiles_y, per_xcd;
-  int mode;          // 1: heaviest first; 2: heaviest / lightest interleaved
-};
-
-__global__ __launch_bounds__(256) void k_blur_classify(BlurArgs a, BlurOrder q) {
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (tile >= q.tiles_x * q.tiles_y) return;
-  const int lx = (tile % q.tiles_x) * BLUR_BX + (lane & 7) * 4 + 2, ly = (tile / q.tiles_x) * BLUR_BY + (lane >> 3) * 4 + 2;
-  int taps = 0;
-  if (lx < a.out.w && ly < a.out.h) {
-    const f2 uv = mk2(((float)(a.out.ox + lx) + 0.5f) / (float)a.out.fw, ((float)(a.out.oy + ly) + 0.5f) / (float)a.out.fh);
-    const BilinearTaps b = bilinear_taps_u32(a.material, uv);
-    const float t00 = srgb8_to_float((b.t00 >> 8) & 0xFFu), t10 = srgb8_to_float((b.t10 >> 8) & 0xFFu);
-    const float t01 = srgb8_to_float((b.t01 >> 8) & 0xFFu), t11 = srgb8_to_float((b.t11 >> 8) & 0xFFu);
-    const float roughness = mixf(0.0f, a.max_roughness, mixf(mixf(t00, t10, b.fx), mixf(t01, t11, b.fx), b.fy));
-    float sigma = mixf(0.4f, 4.0f, roughness);
-    if (a.disable_blur != 0) sigma = 0.35f;
-    const int r = min(f2i(floorf(3.0f * sigma - 0.01f)), BLUR_R);
-    taps = (2 * r + 1) * (2 * r + 1);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) taps += __shfl_down(taps, off, 64);
-  if (lane == 0) q.cost[tile] = (uint32_t)taps;
-}
-
-#define BLUR_COST_BUCKETS 68  // cost <= 64 * 529 = 33856; bucket = cost >> 9
-VKR_DEV int blur_home_xcd(int tile, int tiles_x) {  // the 128 x 64 pixel chunk (4 x 2 tiles) a tile lies in, dealt over the XCDs
-  const int cx = (tile % tiles_x) >> 2, cy = (tile / tiles_x) >> 1, ncx = (tiles_x + 3) >> 2;
-  return (cy * ncx + cx) & 7;
-}
-__global__ __launch_bounds__(1024) void k_blur_order(BlurOrder q) {
-  __shared__ uint32_t s_count[8][BLUR_COST_BUCKETS], s_base[8][BLUR_COST_BUCKETS], s_len[8];
-  const int n = q.tiles_x * q.tiles_y;
-  for (int i = threadIdx.x; i < 8 * BLUR_COST_BUCKETS; i += 1024) (&s_count[0][0])[i] = 0;
-  for (int i = threadIdx.x; i < 8 * q.per_xcd; i += 1024) q.order[i] = 0xFFFFFFFFu;
-  __syncthreads();
-  for (int t = threadIdx.x; t < n; t += 1024)
-    atomicAdd(&s_count[blur_home_xcd(t, q.tiles_x)][min(q.cost[t] >> 9, (uint32_t)BLUR_COST_BUCKETS - 1u)], 1u);
-  __syncthreads();
-  if (threadIdx.x < 8) {  // heaviest bucket first
-    uint32_t run = 0;
-    for (int b = BLUR_COST_BUCKETS - 1; b >= 0; b--) { s_base[threadIdx.x][b] = run; run += s_count[threadIdx.x][b]; }
-    s_len[threadIdx.x] = run;
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < n; t += 1024) {
-    const int x = blur_home_xcd(t, q.tiles_x);
-    const uint32_t rank = atomicAdd(&s_base[x][min(q.cost[t] >> 9, (uint32_t)BLUR_COST_BUCKETS - 1u)], 1u);  // in descending cost
-    uint32_t at = rank;
-    if (q.mode == 2) { const uint32_t len = s_len[x]; at = rank < (len + 1u) / 2u ? 2u * rank : 2u * (len - 1u - rank) + 1u; }
-    q.order[at * 8u + (uint32_t)x] = (uint32_t)t;  // block id = at * 8 + x runs on XCD x
-  }
+  blur_tile(a, xcd_block<4, 2>(), s_nd, s_refl, s_lut, tid);  // chunks of 128 x 64 output pixels
 }
 
 }  // namespace vkr
 
 using namespace vkr;
-
-// ---- blur work queue: storage and launch shape ----------------------------------------------------------------------
-#define BLUR_QUEUE_TILES 65536u  // 32 x 32 tiles: up to 67 M half-res pixels per launch (the 15360x8640 frame has 32 400)
-#define BLUR_ORDER_WORDS (BLUR_QUEUE_TILES + 4096u)  // per-XCD lists are padded to a common length
-#define BLUR_SLOT_WORDS (BLUR_ORDER_WORDS + BLUR_QUEUE_TILES)
-#define BLUR_QUEUE_SLOTS 8u
-__device__ uint32_t g_blur_queue[BLUR_QUEUE_SLOTS * BLUR_SLOT_WORDS];  // per slot: order[], cost[]
-
-// blocks the device keeps resident: LDS allows two 512-thread blocks per CU
-static int resident_blur_blocks() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    n = 2 * cus;
-  }
-  return n;
-}
-// 0 (default): plain launch in XCD-chunked raster order; 1: cost-ordered, heaviest first per XCD; 2: heaviest / lightest interleaved per XCD
-static int blur_variant() {
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("VKR_BLUR_QUEUE"); v = e ? atoi(e) : 0; }
-  return v;
-}
 
 extern "C" int vkr_pdf_preintegrate(const vkr_img* out_pdf, void* stream) {
   Tex out;
@@ -853,45 +705,3 @@ extern "C" int vkr_sssr_blur(const vkr_img* depth, const vkr_img* normal, const 
   return launch_status("sssr_blur");
 }
 
-extern "C" uint64_t vkr_sssr_blur_scratch_bytes(const vkr_img* out_blurred) {
-  return out_blurred ? (uint64_t)out_blurred->width * out_blurred->height * 16u : 0u;
-}
-
-extern "C" int vkr_sssr_blur_staged(const vkr_img* depth, const vkr_img* normal, const vkr_img* reflections,
-                                    const vkr_img* material, const vkr_img* history, const vkr_img* velocity,
-                                    const vkr_img* history_depth, const vkr_img* out_blurred,
-                                    const vkr_reproject_params* params, const vkr_blur_push* push,
-                                    void* scratch, uint64_t scratch_bytes, void* stream) {
-  BlurArgs a;
-  VKR_TRY(make_blur_args(a, depth, normal, reflections, material, history, velocity, history_depth, out_blurred, params, push));
-  if (!scratch || ((uintptr_t)scratch % 16) != 0 || scratch_bytes < vkr_sssr_blur_scratch_bytes(out_blurred)) {
-    set_error("sssr_blur_staged: scratch must be 16-byte aligned device memory of vkr_sssr_blur_scratch_bytes()");
-    return VKR_ERR_LAYOUT;
-  }
-  if (!same_window(a.out, a.depth1) || !same_window(a.out, a.refl)) { set_error("sssr_blur_staged: depth level 1, reflections and output must share one window"); return VKR_ERR_EXTENT; }
-  float4* geo = (float4*)scratch;
-  hipLaunchKernelGGL(k_blur_prepare, dim3((a.out.w + 63) / 64, (a.out.h + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, geo);
-  dim3 block(BLUR_BX, BLUR_BY / 2);
-  dim3 grid((a.out.w + BLUR_BX - 1) / BLUR_BX, (a.out.h + BLUR_BY - 1) / BLUR_BY);
-  const int variant = blur_variant();
-  const uint32_t tiles = grid.x * grid.y;
-  if (variant <= 0 || tiles <= (uint32_t)resident_blur_blocks() || tiles > BLUR_QUEUE_TILES) {
-    hipLaunchKernelGGL(k_sssr_blur_staged, grid, block, 0, (hipStream_t)stream, a, (const float4*)geo, (const uint32_t*)nullptr, 0);
-    return launch_status("sssr_blur_staged");
-  }
-  // cost-ordered launch (experiment switch VKR_BLUR_QUEUE): the order list lives in a ring of library-owned device slots
-  static std::atomic<uint32_t> next_slot{0};
-  uint32_t* slot = nullptr;
-  if (hipGetSymbolAddress((void**)&slot, HIP_SYMBOL(g_blur_queue)) != hipSuccess) { set_error("sssr_blur: order storage unavailable"); return VKR_ERR_LAYOUT; }
-  slot += (size_t)(next_slot.fetch_add(1) % BLUR_QUEUE_SLOTS) * BLUR_SLOT_WORDS;
-  BlurOrder q;
-  q.order = slot; q.cost = slot + BLUR_ORDER_WORDS;
-  q.tiles_x = (int)grid.x; q.tiles_y = (int)grid.y; q.mode = variant;
-  // the longest per-XCD list: chunks are dealt round-robin, so no XCD owns more than ceil(chunks / 8) chunks of 8 tiles
-  const uint32_t chunks = ((grid.x + 3) / 4) * ((grid.y + 1) / 2);
-  q.per_xcd = (int)(((chunks + 7) / 8) * 8);
-  hipLaunchKernelGGL(k_blur_classify, dim3((tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, q);
-  hipLaunchKernelGGL(k_blur_order, dim3(1), dim3(1024), 0, (hipStream_t)stream, q);
-  hipLaunchKernelGGL(k_sssr_blur_staged, dim3(8u * (uint32_t)q.per_xcd), block, 0, (hipStream_t)stream, a, (const float4*)geo, (const uint32_t*)q.order, q.tiles_x);
-  return launch_status("sssr_blur_staged");
-}

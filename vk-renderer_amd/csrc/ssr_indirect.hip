@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64) void k_sssr_trace_indirect(TraceIndirectArgs a)
   const f3 view_vec = reconstruct_view_vec(screen_uv, pixel_depth, pr);
 
   const float rdot = dot(screen_uv, mk2(12.9898f, 78.233f));
-  const float rnd01 = fractf((float)sin((double)rdot) * 43758.5453f);  // sin in double: it picks the Halton entry
+  const float rnd01 = fractf(sin_hash_arg(rdot) * 43758.5453f);  // sin in double: it picks the Halton entry
   const uint32_t index = (f2u(rnd01 * (float)VKR_HALTON_SEQ_SIZE) + a.frame_random) & (VKR_HALTON_SEQ_SIZE - 1);
   const float4 hv = a.halton[index];
 

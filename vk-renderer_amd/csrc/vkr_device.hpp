@@ -410,6 +410,37 @@ VKR_DEV float sampleGGXdirPDF(const Tex& pdf_tex, f3 V, f3 N, f3 L, float alpha)
   return alpha2 / ((2.0f * VKR_PI) * coef) * sample<FmtR32F>(pdf_tex, mk2(a, b));
 }
 
+// (float)sin((double)x) for the argument of the shaders' rand() hash (trace.comp:156-158: x = dot(uv, (12.9898, 78.233)),
+// 0 <= x < 92; valid for |x| < 1e5).  The contract evaluates that sine in double and rounds once, because its low bits pick the
+// Halton entry.  The generic double sin of the device library spends several hundred instructions (it also handles huge
+// arguments); here: Cody-Waite reduction by pi/2 in two exact steps (k < 2^17 keeps k * PIO2_HI exact: 33 significant
+// bits) and the fdlibm kernel polynomials on |r| <= pi/4, ~25 double operations, < 1 ulp in double — rounding that to
+// float gives the same float as any other < 1-ulp double sine except on a ~1e-9 sliver around float rounding ties.
+VKR_DEV float sin_hash_arg(float x) {
+  const double xd = (double)x;
+  const double kd = __builtin_rint(xd * 0.63661977236758138243);  // 2 / pi
+  const int k = (int)kd;
+  double r = __builtin_fma(-kd, 1.57079632673412561417e+00, xd);  // pi/2, first 33 bits
+  r = __builtin_fma(-kd, 6.07710050650619224932e-11, r);          // pi/2 - the above
+  const double z = r * r;
+  // __kernel_sin: r + r^3 (S1 + z (S2 + z (S3 + z (S4 + z (S5 + z S6)))))
+  double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+  ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+  ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+  ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+  const double sn = __builtin_fma(z * r, ps, r);
+  // __kernel_cos: 1 - z/2 + z^2 (C1 + z (C2 + z (C3 + z (C4 + z (C5 + z C6)))))
+  double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+  pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+  pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+  pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+  const double cs = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+  const double v = (k & 1) ? cs : sn;
+  return (float)((k & 2) ? -v : v);
+}
+
 // the cosine-weighted horizon arc shared by main.comp:246-248 and trace.comp:127-134
 VKR_DEV float arc_occlusion(float h, float n, float len_np) {
   return (((1.0f / VKR_PI) * len_np) * 0.25f) * vmax((-cosf(2.0f * h - n) + cosf(n)) + (2.0f * h) * sinf(n), 0.0f);

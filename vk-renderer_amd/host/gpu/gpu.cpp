@@ -281,11 +281,8 @@ void register_hot_path_programs() {
       const char* P = "sssr_blur";
       vkr_img depth = tex(st, 0, T, P), normal = tex(st, 1, T, P), refl = tex(st, 2, T, P), material = tex(st, 3, T, P);
       vkr_img history = tex(st, 4, T, P), velocity = tex(st, 5, T, P), hdepth = tex(st, 6, T, P), out = tex(st, 7, S, P);
-      // the staged entry: {normal, depth} of every pixel decoded once into the context's scratch instead of once per tile
-      const uint64_t need = vkr_sssr_blur_scratch_bytes(&out);
-      void* scratch = st.grow_scratch(need);
-      return vkr_sssr_blur_staged(&depth, &normal, &refl, &material, &history, &velocity, &hdepth, &out,
-                                  ubo<vkr_reproject_params>(st, 8, P), push<vkr_blur_push>(st, P), scratch, need, st.stream);
+      return vkr_sssr_blur(&depth, &normal, &refl, &material, &history, &velocity, &hdepth, &out,
+                           ubo<vkr_reproject_params>(st, 8, P), push<vkr_blur_push>(st, P), st.stream);
     });
     create_program("gtao_compute_main", [=](LaunchState& st) {
       const char* P = "gtao_compute_main";
