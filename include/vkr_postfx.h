@@ -220,6 +220,11 @@ typedef struct vkr_synth_params {
 
 const char* vkr_version(void);
 const char* vkr_last_error(void);
+/* Version of the numeric contract the library was built with (csrc/vkr_device.hpp): 2 = the accumulation steps of the
+ * shared helpers (dot, mix, mat4*vec4, cross, madd, texel coordinates ...) are fused multiply-adds, which GLSL without
+ * `precise` allows every Vulkan driver to do; 1 = nothing fused (`make CONTRACT=1`).  Results of the two contracts
+ * differ in the last bits; a checker must be built with the same one.                                              */
+uint32_t vkr_numeric_contract(void);
 
 /* program "downsample_gbuffer": downsample_pass.cpp:25-92 + downsample_gbuffer.frag:12-37.
  * depth: full image (view mip 0 = image mip 0, >=2 mips); writes depth mip 1.           */

@@ -35,6 +35,7 @@ uint32_t vkr_format_bytes(uint32_t format) {
   }
 }
 
+uint32_t vkr_ref_numeric_contract(void) { return VKR_CONTRACT; }
 int vkr_ref_threads(void) { return omp_get_max_threads(); }
 void vkr_ref_set_threads(int n) { omp_set_num_threads(n); }
 

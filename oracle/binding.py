@@ -36,6 +36,7 @@ def load(build_if_missing=False):
         lib.vkr_ref_halton23.argtypes = [C.c_void_p, C.c_uint32]
         lib.vkr_ref_halton23.restype = None
         lib.vkr_ref_threads.restype = C.c_int
+        lib.vkr_ref_numeric_contract.restype = C.c_uint32
         lib.vkr_ref_set_threads.argtypes = [C.c_int]
         _lib = lib
     return _lib

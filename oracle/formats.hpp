@@ -188,8 +188,8 @@ struct Image {
   // texture()/textureLod() with an integral lod, optional textureOffset texel offset
   vec4 sample(vec2 uv, int mip = 0, ivec2 offset = ivec2(0, 0)) const {
     if (mip >= mips()) mip = mips() - 1;
-    float x = uv.x * (float)fw(mip) - 0.5f;
-    float y = uv.y * (float)fh(mip) - 0.5f;
+    float x = cfma(uv.x, (float)fw(mip), -0.5f);
+    float y = cfma(uv.y, (float)fh(mip), -0.5f);
     float x0f = floorf(x), y0f = floorf(y);
     float fx = x - x0f, fy = y - y0f;
     int x0 = f2i(x0f) + offset.x, y0 = f2i(y0f) + offset.y;

@@ -6,11 +6,20 @@
 // one IEEE-754 binary32 operation sequence so that a GPU implementation following
 // the same sequence is bit-identical for everything that feeds a branch.
 //
+// NUMERIC CONTRACT, version VKR_CONTRACT (default 2; build with CONTRACT=1 for the first contract, to bisect).
+//   GLSL without `precise` lets every Vulkan driver contract a*b+c into one fused multiply-add, so a restatement that
+//   fuses is as faithful to the reference as one that does not — but oracle and kernels must fuse the SAME expressions.
+//   Contract 1 fused nothing.  Contract 2 fuses exactly the accumulation steps of the helpers below, written with
+//   cfma(a,b,c) (one IEEE fma under contract 2, round(a*b)+c under contract 1, same association order either way):
+//   dot, mix, mat4*vec4, cross, reflect, madd(a,s,b) = a + s*b, the texel coordinate uv*size - 0.5 of the sampler,
+//   2x-1 / 0.5x+0.5 range maps, d*(f-n)-f of linearize_depth2.  Everything else keeps one rounding per operation.
+//   The compilers never contract on their own: -ffp-contract=off on both sides.
+//
 // Frozen choices (GLSL leaves them implementation-defined):
-//   dot(a,b)       = ((a.x*b.x + a.y*b.y) + a.z*b.z) [+ a.w*b.w], no FMA contraction
+//   dot(a,b)       = cfma(a.z,b.z, cfma(a.y,b.y, a.x*b.x)) [then a.w*b.w]
 //   normalize(v)   = v * (1.0f / sqrtf(dot(v,v)))
 //   length(v)      = sqrtf(dot(v,v))
-//   mix(a,b,t)     = a*(1-t) + b*t            (GLSL spec formula)
+//   mix(a,b,t)     = cfma(b, t, a*(1-t))      (GLSL spec formula a*(1-t) + b*t)
 //   min/max        = IEEE minNum/maxNum (fminf/fmaxf; what v_min_f32/v_max_f32 do)
 //   clamp(x,lo,hi) = min(max(x,lo),hi)
 //   reflect(I,N)   = I - (2*dot(N,I))*N
@@ -22,7 +31,20 @@
 #include <cstdint>
 #include <cstring>
 
+#ifndef VKR_CONTRACT
+#define VKR_CONTRACT 2
+#endif
+
 namespace glsl {
+
+// the one place where the two numeric contracts differ
+inline float cfma(float a, float b, float c) {
+#if VKR_CONTRACT >= 2
+  return __builtin_fmaf(a, b, c);
+#else
+  return a * b + c;
+#endif
+}
 
 struct vec2 { float x, y; vec2() : x(0), y(0) {} vec2(float a, float b) : x(a), y(b) {} explicit vec2(float a) : x(a), y(a) {} };
 struct vec3 {
@@ -98,22 +120,25 @@ inline vec3  clamp(vec3 v, vec3 lo, vec3 hi) { return min(max(v, lo), hi); }
 inline float floor(float a) { return floorf(a); }
 inline vec2  floor(vec2 a) { return vec2(floorf(a.x), floorf(a.y)); }
 inline float fract(float a) { return a - floorf(a); }
-inline float mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+inline float mix(float a, float b, float t) { return cfma(b, t, a * (1.0f - t)); }
 inline vec2  mix(vec2 a, vec2 b, float t) { return vec2(mix(a.x, b.x, t), mix(a.y, b.y, t)); }
 inline vec3  mix(vec3 a, vec3 b, float t) { return vec3(mix(a.x, b.x, t), mix(a.y, b.y, t), mix(a.z, b.z, t)); }
 inline vec4  mix(vec4 a, vec4 b, float t) { return vec4(mix(a.x, b.x, t), mix(a.y, b.y, t), mix(a.z, b.z, t), mix(a.w, b.w, t)); }
 
-inline float dot(vec2 a, vec2 b) { return a.x * b.x + a.y * b.y; }
-inline float dot(vec3 a, vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-inline float dot(vec4 a, vec4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+inline float dot(vec2 a, vec2 b) { return cfma(a.y, b.y, a.x * b.x); }
+inline float dot(vec3 a, vec3 b) { return cfma(a.z, b.z, cfma(a.y, b.y, a.x * b.x)); }
+inline float dot(vec4 a, vec4 b) { return cfma(a.w, b.w, cfma(a.z, b.z, cfma(a.y, b.y, a.x * b.x))); }
 inline float length(vec2 a) { return sqrtf(dot(a, a)); }
 inline float length(vec3 a) { return sqrtf(dot(a, a)); }
 inline vec2  normalize(vec2 a) { return a * (1.0f / sqrtf(dot(a, a))); }
 inline vec3  normalize(vec3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
 inline vec3  cross(vec3 a, vec3 b) {
-  return vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+  return vec3(cfma(a.y, b.z, -(a.z * b.y)), cfma(a.z, b.x, -(a.x * b.z)), cfma(a.x, b.y, -(a.y * b.x)));
 }
-inline vec3 reflect(vec3 I, vec3 N) { return I - (2.0f * dot(N, I)) * N; }
+// a + s * b, the "advance along a direction" shape (ray positions, sample positions, projections off a normal)
+inline vec2 madd(vec2 a, float s, vec2 b) { return vec2(cfma(s, b.x, a.x), cfma(s, b.y, a.y)); }
+inline vec3 madd(vec3 a, float s, vec3 b) { return vec3(cfma(s, b.x, a.x), cfma(s, b.y, a.y), cfma(s, b.z, a.z)); }
+inline vec3 reflect(vec3 I, vec3 N) { return madd(I, -(2.0f * dot(N, I)), N); }
 inline bool isnan(float a) { return a != a; }
 
 // float -> int conversion: truncation toward zero, NaN -> 0, saturating at +-2^30 (so that
@@ -134,10 +159,10 @@ struct mat4 {
 };
 inline vec4 operator*(const mat4& M, vec4 v) {
   vec4 r;
-  r.x = ((M.m[0] * v.x + M.m[4] * v.y) + M.m[8] * v.z) + M.m[12] * v.w;
-  r.y = ((M.m[1] * v.x + M.m[5] * v.y) + M.m[9] * v.z) + M.m[13] * v.w;
-  r.z = ((M.m[2] * v.x + M.m[6] * v.y) + M.m[10] * v.z) + M.m[14] * v.w;
-  r.w = ((M.m[3] * v.x + M.m[7] * v.y) + M.m[11] * v.z) + M.m[15] * v.w;
+  r.x = cfma(M.m[12], v.w, cfma(M.m[8], v.z, cfma(M.m[4], v.y, M.m[0] * v.x)));
+  r.y = cfma(M.m[13], v.w, cfma(M.m[9], v.z, cfma(M.m[5], v.y, M.m[1] * v.x)));
+  r.z = cfma(M.m[14], v.w, cfma(M.m[10], v.z, cfma(M.m[6], v.y, M.m[2] * v.x)));
+  r.w = cfma(M.m[15], v.w, cfma(M.m[11], v.z, cfma(M.m[7], v.y, M.m[3] * v.x)));
   return r;
 }
 

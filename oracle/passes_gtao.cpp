@@ -29,7 +29,7 @@ float find_horizon(const GtaoCtx& c, vec2 start, vec3 camera_start, vec2 dir, in
   float h_cos = -1.0f;
   float previous_z = camera_start.z;
   for (int i = 1; i <= samples_count; i++) {
-    vec2 tc = start + ((float)i / (float)samples_count) * dir;
+    vec2 tc = madd(start, (float)i / (float)samples_count, dir);
     float sample_depth = c.depth.sample(tc, 0).x;
     vec3 sample_pos = reconstruct_view_vec(tc, sample_depth, c.p.fovy, c.p.aspect, c.p.znear, c.p.zfar);
     if (sample_pos.z > previous_z + MAX_THIKNESS) break;
@@ -63,7 +63,7 @@ float gtao_camera_space(const GtaoCtx& c, ivec2 pos, vec2 screen_uv, uint32_t di
     vec2 sample_direction = dir_radius * slice_dir(angle);
     vec3 sample_end_pos = reconstruct_view_vec(screen_uv + sample_direction, frag_depth, c.p.fovy, c.p.aspect, c.p.znear, c.p.zfar);
     vec3 slice_normal = normalize(cross(w0, -sample_end_pos));
-    vec3 normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
+    vec3 normal_projected = madd(camera_normal, -dot(camera_normal, slice_normal), slice_normal);
     vec3 X = -normalize(cross(slice_normal, w0));
     float n = PI / 2.0f - acosf(dot(normalize(normal_projected), X));
     float h_cos = find_horizon(c, screen_uv, camera_pos, sample_direction, 16, w0);
@@ -91,7 +91,7 @@ vec2 mis_gtao(const GtaoCtx& c, ivec2 pos, vec2 screen_uv) {
   vec3 sample_end_pos = reconstruct_view_vec(screen_uv + sample_direction, frag_depth, c.p.fovy, c.p.aspect, c.p.znear, c.p.zfar);
   vec3 L = normalize(sample_end_pos - camera_pos);
   vec3 slice_normal = normalize(cross(w0, -sample_end_pos));
-  vec3 normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
+  vec3 normal_projected = madd(camera_normal, -dot(camera_normal, slice_normal), slice_normal);
   vec3 X = -normalize(cross(slice_normal, w0));
   float n = PI / 2.0f - acosf(dot(normalize(normal_projected), X));
   float h_cos = find_horizon(c, screen_uv, camera_pos, sample_direction, 16, w0);

@@ -55,7 +55,7 @@ int wrap_repeat(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
 // texture(): REPEAT, bilinear inside a level, linear between levels
 vec4 sample_level_repeat(const Image& t, int mip, vec2 uv) {
   const int w = t.fw(mip), h = t.fh(mip);
-  const float x = uv.x * (float)w - 0.5f, y = uv.y * (float)h - 0.5f;
+  const float x = cfma(uv.x, (float)w, -0.5f), y = cfma(uv.y, (float)h, -0.5f);
   const float x0f = floorf(x), y0f = floorf(y);
   const float fx = x - x0f, fy = y - y0f;
   const int x0 = wrap_repeat(f2i(x0f), w), y0 = wrap_repeat(f2i(y0f), h);

@@ -20,12 +20,12 @@ inline vec2 encode_normal(vec3 v) {
     vec2 r2((1.0f - abs(result.y)) * sign_nz(result.x), (1.0f - abs(result.x)) * sign_nz(result.y));
     result = r2;
   }
-  return vec2(0.5f * result.x + 0.5f, 0.5f * result.y + 0.5f);
+  return vec2(cfma(0.5f, result.x, 0.5f), cfma(0.5f, result.y, 0.5f));
 }
 
 // gbuffer_encode.glsl:29-37
 inline vec3 decode_normal(vec2 uv) {
-  uv = vec2(2.0f * uv.x - 1.0f, 2.0f * uv.y - 1.0f);
+  uv = vec2(cfma(2.0f, uv.x, -1.0f), cfma(2.0f, uv.y, -1.0f));
   vec3 v(uv.x, uv.y, (1.0f - abs(uv.x)) - abs(uv.y));
   if (v.z < 0.0f) {
     float nx = (1.0f - abs(v.y)) * sign_nz(v.x);
@@ -43,14 +43,14 @@ inline vec3 sample_gbuffer_normal(const Image& normal_tex, vec2 uv) {
 }
 
 // gbuffer_encode.glsl:53-56
-inline float linearize_depth2(float d, float n, float f) { return (n * f) / (d * (f - n) - f); }
+inline float linearize_depth2(float d, float n, float f) { return (n * f) / cfma(d, f - n, -f); }
 
 // gbuffer_encode.glsl:58-69.  tan(fovy/2) is evaluated with the host libm (tanf).
 inline vec3 reconstruct_view_vec(vec2 uv, float d, float fovy, float aspect, float z_near, float z_far) {
   float tg_alpha = tanf(fovy / 2.0f);
   float z = linearize_depth2(d, z_near, z_far);
-  float xd = 2.0f * uv.x - 1.0f;
-  float yd = 2.0f * uv.y - 1.0f;
+  float xd = cfma(2.0f, uv.x, -1.0f);
+  float yd = cfma(2.0f, uv.y, -1.0f);
   float x = -(xd) * ((z * aspect) * tg_alpha);
   float y = -(yd) * (z * tg_alpha);
   return vec3(x, y, z);
@@ -66,7 +66,7 @@ inline vec3 project_view_vec(vec3 v, float fovy, float aspect, float n, float f)
   float depth = f / (f - n) + (f * n) / (z * (f - n));
   float pu = v.x / ((-v.z * tg_alpha) * aspect);
   float pv = v.y / (-z * tg_alpha);
-  return vec3(0.5f * pu + 0.5f, 0.5f * pv + 0.5f, depth);
+  return vec3(cfma(0.5f, pu, 0.5f), cfma(0.5f, pv, 0.5f), depth);
 }
 
 // ---- brdf.glsl ---------------------------------------------------------------------
@@ -145,10 +145,10 @@ inline void initial_advance_ray(vec3 origin, vec3 dir, vec3 inv_dir, vec2 mip_re
                                 vec2 floor_offset, vec2 uv_offset, vec3& pos, float& current_t) {
   vec2 cur_pos = mip_res * origin.xy();
   vec2 xy_plane = floor(cur_pos) + floor_offset;
-  xy_plane = xy_plane * inv_mip_res + uv_offset;
+  xy_plane = vec2(cfma(xy_plane.x, inv_mip_res.x, uv_offset.x), cfma(xy_plane.y, inv_mip_res.y, uv_offset.y));
   vec2 t = (xy_plane - origin.xy()) * inv_dir.xy();
   current_t = min(t.x, t.y);
-  pos = origin + current_t * dir;
+  pos = madd(origin, current_t, dir);
 }
 
 // screen_trace.glsl:17-45
@@ -156,7 +156,7 @@ inline bool advance_ray(vec3 origin, vec3 direction, vec3 inv_direction, vec2 cu
                         vec2 current_mip_resolution_inv, vec2 floor_offset, vec2 uv_offset, float surface_z,
                         vec3& position, float& current_t) {
   vec2 xy_plane = floor(current_mip_position) + floor_offset;
-  xy_plane = xy_plane * current_mip_resolution_inv + uv_offset;
+  xy_plane = vec2(cfma(xy_plane.x, current_mip_resolution_inv.x, uv_offset.x), cfma(xy_plane.y, current_mip_resolution_inv.y, uv_offset.y));
   vec3 boundary_planes(xy_plane, surface_z);
   vec3 t = (boundary_planes - origin) * inv_direction;
   t.z = direction.z > 0.0f ? t.z : MAX_T_FLOAT;
@@ -164,7 +164,7 @@ inline bool advance_ray(vec3 origin, vec3 direction, vec3 inv_direction, vec2 cu
   bool above_surface = surface_z > position.z;
   bool skipped_tile = t_min != t.z && above_surface;
   current_t = above_surface ? t_min : current_t;
-  position = origin + current_t * direction;
+  position = madd(origin, current_t, direction);
   return skipped_tile;
 }
 

@@ -7,6 +7,9 @@ Content: for the frozen frame setup (camera.FrameSetup defaults, SEED 0x5EED0001
 two frames of the chain with history ping-pong; per image a SHA-256 of the raw storage bytes of
 every mip and a 24x16 crop of raw storage values around the image centre.
 
+One pair of fixtures per numeric contract (oracle/glsl.hpp VKR_CONTRACT): chain_256x144_contract<N>.npz and
+extras_256x144_contract<N>.npz, N = what the oracle library on disk was built with (`make -C oracle CONTRACT=1|2`).
+
 Run from the repository root:  python tests/golden/make_golden.py
 """
 import hashlib
@@ -23,6 +26,18 @@ from vk_renderer_amd.chain import PostFxChain  # noqa: E402
 W, H = 256, 144
 IMAGES = ("depth", "prev_depth", "normal", "albedo", "material", "velocity", "dn", "dv", "rays", "raw", "reflections", "filtered",
           "blurred_hist", "acc_hist", "taa_hist")
+
+
+def contract():
+    """numeric contract of the oracle library on disk"""
+    from oracle import binding
+
+    lib = binding.install(build_if_missing=True)
+    return int(lib.vkr_ref_numeric_contract())
+
+
+def fixture(stem):
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{stem}_contract{contract()}.npz")
 
 
 def _ensure_backend(backend):
@@ -119,7 +134,7 @@ def main():
         data[name + "__sha256"] = np.array(digest(img))
         data[name + "__crop"] = crop(img)
     data["pdf__spot"] = c.pdf.decode()[[100, 512, 900], :, 0][:, [100, 512, 900]]
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "chain_256x144.npz")
+    out = fixture("chain_256x144")
     np.savez_compressed(out, **data)
     print("wrote", out, os.path.getsize(out), "bytes")
 
@@ -128,7 +143,7 @@ def main():
     for name in EXTRA_IMAGES:
         data[name + "__sha256"] = np.array(digest(extras[name]))
         data[name + "__crop"] = crop(extras[name]) if extras[name].height >= 16 and extras[name].width >= 24 else extras[name].raw(0)
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "extras_256x144.npz")
+    out = fixture("extras_256x144")
     np.savez_compressed(out, **data)
     print("wrote", out, os.path.getsize(out), "bytes")
 

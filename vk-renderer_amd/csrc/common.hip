@@ -12,7 +12,8 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace vkr
 
-extern "C" const char* vkr_version(void) { return "vkr_postfx 0.1 (gfx950)"; }
+extern "C" const char* vkr_version(void) { return "vkr_postfx 0.2 (gfx950)"; }
+extern "C" uint32_t vkr_numeric_contract(void) { return VKR_CONTRACT; }
 extern "C" const char* vkr_last_error(void) { return vkr::g_error; }
 
 extern "C" uint32_t vkr_format_bytes(uint32_t format) {

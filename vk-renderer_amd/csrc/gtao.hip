@@ -37,7 +37,7 @@ struct DepthTile {
 };
 // texture(depth, uv): same arithmetic as sample<FmtD24>, texels served from the tile
 VKR_DEV float tile_sample(const DepthTile& t, f2 uv) {
-  float x = uv.x * t.fw - 0.5f, y = uv.y * t.fh - 0.5f;
+  float x = cfma(uv.x, t.fw, -0.5f), y = cfma(uv.y, t.fh, -0.5f);
   float x0f = floorf(x), y0f = floorf(y);
   float fx = x - x0f, fy = y - y0f;
   int tx = iclamp(f2i(x0f) - t.x0, 0, GT_TW - 2), ty = iclamp(f2i(y0f) - t.y0, 0, GT_TH - 2);
@@ -61,7 +61,7 @@ VKR_DEV float find_horizon(const DepthTile& depth, const Tex& depth_tex, const P
   float previous_z = camera_start.z;
 #pragma unroll 1
   for (int i = 1; i <= 16; i++) {
-    f2 tc = start + ((float)i / 16.0f) * dir;
+    f2 tc = madd(start, (float)i / 16.0f, dir);
     float sample_depth = depth_sample<TILED>(depth, depth_tex, tc);
     f3 sample_pos = reconstruct_view_vec(tc, sample_depth, pr);
     if (sample_pos.z > previous_z + 0.1f) break;  // MAX_THIKNESS, main.comp:82
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
       const f2 sample_direction = dir_radius * cs;
       const f3 sample_end_pos = reconstruct_view_vec(screen_uv + sample_direction, frag_depth, a.pr);
       f3 slice_normal = normalize_fast(cross(w0, -sample_end_pos));
-      f3 normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
+      f3 normal_projected = madd(camera_normal, -dot(camera_normal, slice_normal), slice_normal);
       f3 X = -normalize_fast(cross(slice_normal, w0));
       const float np_len2 = dot(normal_projected, normal_projected);
       float np_len = fast_sqrt(np_len2);
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
         // acos cliff (surface seen edge-on in this slice): whether the argument rounds past +-1 — NaN in the shader,
         // which zeroes the slice's arc — is decided by its last bit, so this rare case takes the exact sequence
         slice_normal = normalize(cross(w0, -sample_end_pos));
-        normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
+        normal_projected = madd(camera_normal, -dot(camera_normal, slice_normal), slice_normal);
         X = -normalize(cross(slice_normal, w0));
         n_cos = dot(normalize(normal_projected), X);
         np_len = length(normal_projected);
@@ -236,14 +236,14 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main_lanes(GtaoArgs a) {
       const f2 sample_direction = dir_radius * cs;
       sample_end_pos = reconstruct_view_vec(screen_uv + sample_direction, frag_depth, a.pr);
       f3 slice_normal = normalize_fast(cross(w0, -sample_end_pos));
-      f3 normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
+      f3 normal_projected = madd(camera_normal, -dot(camera_normal, slice_normal), slice_normal);
       f3 X = -normalize_fast(cross(slice_normal, w0));
       const float np_len2 = dot(normal_projected, normal_projected);
       np_len = fast_sqrt(np_len2);
       float n_cos = dot(normal_projected, X) * fast_rsq(np_len2);
       if (!(fabsf(n_cos) <= 0.9999f)) {  // acos cliff: the exact sequence (see k_gtao_main)
         slice_normal = normalize(cross(w0, -sample_end_pos));
-        normal_projected = camera_normal - dot(camera_normal, slice_normal) * slice_normal;
+        normal_projected = madd(camera_normal, -dot(camera_normal, slice_normal), slice_normal);
         X = -normalize(cross(slice_normal, w0));
         n_cos = dot(normalize(normal_projected), X);
         np_len = length(normal_projected);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main_lanes(GtaoArgs a) {
       const f3 camera_start = mk3(s_ray[2][p], s_ray[3][p], start_z);
       const f2 dir = mk2(s_ray[5][p], s_ray[6][p]);
       const f3 v = mk3(s_ray[7][p], s_ray[8][p], s_ray[9][p]);
-      const f2 tc = start + ((float)(sub + 1) / 16.0f) * dir;
+      const f2 tc = madd(start, (float)(sub + 1) / 16.0f, dir);
       const float sample_depth = tile_sample(tile, tc);
       const f3 sample_pos = reconstruct_view_vec(tc, sample_depth, a.pr);
       z = sample_pos.z;

@@ -32,7 +32,7 @@ VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, i
   const float scale = __builtin_ldexpf(1.0f, -st.mip), scale_inv = __builtin_ldexpf(1.0f, st.mip);
   const f2 res = mk2(env.screen_size.x * scale, env.screen_size.y * scale);
   const f2 res_inv = mk2(env.screen_size_inv.x * scale_inv, env.screen_size_inv.y * scale_inv);
-  const f3 position = rc.origin + st.t * rc.direction;
+  const f3 position = madd(rc.origin, st.t, rc.direction);
   const f2 mip_pos = res * xy(position);
   // texelFetch(depth_tex, ivec2(p), mip): beyond the last mip or outside the mip extent -> 0
   float surface_z = 0.0f;
@@ -50,7 +50,7 @@ VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, i
                            rc.direction.y < 0.0f ? -env.uv_offset_abs.y : env.uv_offset_abs.y);
   const f2 floor_offset = mk2(rc.direction.x < 0.0f ? 0.0f : 1.0f, rc.direction.y < 0.0f ? 0.0f : 1.0f);
   f2 xy_plane = mk2(floorf(mip_pos.x), floorf(mip_pos.y)) + floor_offset;
-  xy_plane = xy_plane * res_inv + uv_offset;
+  xy_plane = mk2(cfma(xy_plane.x, res_inv.x, uv_offset.x), cfma(xy_plane.y, res_inv.y, uv_offset.y));
   f3 t = (mk3(xy_plane.x, xy_plane.y, surface_z) - rc.origin) * rc.inv_direction;
   t.z = rc.direction.z > 0.0f ? t.z : 3.402823466e+38f;
   const float t_min = vmin(vmin(t.x, t.y), t.z);
@@ -62,7 +62,7 @@ VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, i
   ++st.i;
   // trace.comp:253-262: horizon tracking around the new position
   if (HORIZON && st.mip <= 1) {
-    const f3 np = rc.origin + st.t * rc.direction;
+    const f3 np = madd(rc.origin, st.t, rc.direction);
     const f3 v = reconstruct_view_vec(xy(np), surface_z, env.pr) - rc.view_vec;
     const float d2 = dot(v, v);
     if (d2 < env.horizon_d2) {  // length(v) < 0.3, decided exactly on the squared length
@@ -90,7 +90,7 @@ VKR_DEV float initial_advance(const MarchEnv& env, const RayConst& rc) {
   const f2 res_inv = mk2(env.screen_size_inv.x * scale_inv, env.screen_size_inv.y * scale_inv);
   const f2 cur_pos = res * xy(rc.origin);
   f2 xy_plane = mk2(floorf(cur_pos.x), floorf(cur_pos.y)) + floor_offset;
-  xy_plane = xy_plane * res_inv + uv_offset;
+  xy_plane = mk2(cfma(xy_plane.x, res_inv.x, uv_offset.x), cfma(xy_plane.y, res_inv.y, uv_offset.y));
   const f2 t = (xy_plane - xy(rc.origin)) * xy(rc.inv_direction);
   return vmin(t.x, t.y);
 }

@@ -184,7 +184,7 @@ VKR_DEV void perspective(const ScreenTri& t, const float lambda[3], float b[3]) 
 VKR_DEV int wrap_repeat(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
 // texture(sampler2D, uv) of an RGBA8_SRGB mip chain: REPEAT, bilinear, linear between the two mips of `lod`
 VKR_DEV f4 sample_level_repeat(const Tex& t, f2 uv) {
-  const float x = uv.x * (float)t.fw - 0.5f, y = uv.y * (float)t.fh - 0.5f;
+  const float x = cfma(uv.x, (float)t.fw, -0.5f), y = cfma(uv.y, (float)t.fh, -0.5f);
   const float x0f = floorf(x), y0f = floorf(y);
   const float fx = x - x0f, fy = y - y0f;
   const int x0 = wrap_repeat(f2i(x0f), t.fw), y0 = wrap_repeat(f2i(y0f), t.fh);

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_defered_shading(ShadingArgs a) {
   float occlusion;
   f3 reflection;
   {
-    const float hx = screen_uv.x * (float)a.depth1.fw - 0.5f, hy = screen_uv.y * (float)a.depth1.fh - 0.5f;
+    const float hx = cfma(screen_uv.x, (float)a.depth1.fw, -0.5f), hy = cfma(screen_uv.y, (float)a.depth1.fh, -0.5f);
     const float hx0f = floorf(hx), hy0f = floorf(hy);
     const float fx = hx - hx0f, fy = hy - hy0f;
     const int x0 = f2i(hx0f), y0 = f2i(hy0f);

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   }
   if (!active) return;
   if (running) { st.t = s_rc[15][tid]; st.h = s_rc[16][tid]; }  // this thread's ray was finished by another lane
-  const f3 out_ray = rc.origin + st.t * rc.direction;
+  const f3 out_ray = madd(rc.origin, st.t, rc.direction);
   const float h = st.h;
   const f3 pixel_normal = rc.normal, view_vec = rc.view_vec;
   bool valid_hit = true;  // i <= 80 always (trace.comp:265)

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void k_sssr_trace_indirect(TraceIndirectArgs a)
   bool more = max_steps > 0;
 #pragma unroll 1
   while (more) more = march_step<false, 0>(env, rc, st, max_steps);
-  const f3 out_ray = rc.origin + st.t * rc.direction;
+  const f3 out_ray = madd(rc.origin, st.t, rc.direction);
 
   bool valid_hit = true;  // i <= max always (screen_trace.glsl:97)
   {

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_ssr_simple(SsrArgs a) {
     bool more = true;
 #pragma unroll 1
     while (more) more = march_step<false, 0>(env, rc, st, 100);
-    const f3 out_ray = rc.origin + st.t * rc.direction;  // valid_hit = (i <= 100) is always true
+    const f3 out_ray = madd(rc.origin, st.t, rc.direction);  // valid_hit = (i <= 100) is always true
 
     const f2 dist0 = mk2(fabsf(out_ray.x - start.x), fabsf(out_ray.y - start.y));
     if (dist0.x < 2.0f / tex_size.x && dist0.y < 2.0f / tex_size.y) break;

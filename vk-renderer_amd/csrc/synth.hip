@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_stream_read(const float4* __restrict__ 
 __global__ __launch_bounds__(256) void k_selftest_division(uint32_t* counters, float znear, float zfar) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. 2^24-1
   const float d = d24_to_float(i);
-  const float ref = (znear * zfar) / (d * (zfar - znear) - zfar);
+  const float ref = (znear * zfar) / cfma(d, zfar - znear, -zfar);  // the contract's linearize_depth2 with the IEEE quotient
   if (linearize_depth2_unorm(d, znear, zfar) != ref) atomicAdd(&counters[0], 1u);
   const float a = __uint_as_float(0x30000000u + (pcg(i) & 0x1FFFFFFFu));        // ~4.7e-10 .. 1.8e+19
   float b = __uint_as_float(0x30000000u + (pcg(i ^ 0x9E3779B9u) & 0x1FFFFFFFu));

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_taa_resolve(TaaArgs a) {
     // texture(prev_uv) and its four textureOffset neighbours (resolve.comp:41-45) share weights and
     // overlap in texels: the 12 distinct texels of the plus-shaped footprint are loaded and decoded
     // once; each of the five results is then the same lerp-of-lerps the sampler would compute.
-    const float hx = prev_uv.x * (float)a.history.fw - 0.5f, hy = prev_uv.y * (float)a.history.fh - 0.5f;
+    const float hx = cfma(prev_uv.x, (float)a.history.fw, -0.5f), hy = cfma(prev_uv.y, (float)a.history.fh, -0.5f);
     const float hx0f = floorf(hx), hy0f = floorf(hy);
     const float fx = hx - hx0f, fy = hy - hy0f;
     const int hx0 = f2i(hx0f), hy0 = f2i(hy0f);

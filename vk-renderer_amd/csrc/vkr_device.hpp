@@ -1,8 +1,14 @@
 // vkr_device.hpp — device-side vocabulary of the HIP hot path (gfx950).
 //
-// * f2/f3/f4 value types with one frozen IEEE-754 binary32 operation order
-//   (no FMA contraction: the library is built with -ffp-contract=off) so hit/no-hit
-//   and horizon-break decisions are reproducible bit-for-bit;
+// * f2/f3/f4 value types with one frozen IEEE-754 binary32 operation order so hit/no-hit
+//   and horizon-break decisions are reproducible bit-for-bit.  NUMERIC CONTRACT version
+//   VKR_CONTRACT (default 2; `make CONTRACT=1` builds the first one, to bisect): GLSL without
+//   `precise` lets a Vulkan driver fuse a*b+c, so fusing is as faithful to the reference as not
+//   fusing, provided oracle and kernels fuse the SAME expressions.  Contract 2 fuses exactly the
+//   accumulation steps of dot, mix, mat4*vec4, cross, reflect, madd(a,s,b) = a + s*b, the
+//   sampler's texel coordinate uv*size - 0.5, the 2x-1 / 0.5x+0.5 range maps and d*(f-n)-f of
+//   linearize_depth2, all written with cfma() below; contract 1 fused nothing.  The compiler
+//   never contracts on its own (-ffp-contract=off);
 // * Tex: one mip of a pitch-linear image window in HBM; typed texel loaders for the
 //   reference's storage formats (scene_renderer.cpp:13-43, gtao.cpp:26-47,
 //   advanced_ssr.cpp:62-92, taa.cpp:6);
@@ -14,9 +20,23 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#ifndef VKR_CONTRACT
+#define VKR_CONTRACT 2
+#endif
+
 namespace vkr {
 
 #define VKR_DEV __device__ __forceinline__
+
+// the one place where the two numeric contracts differ: a fused multiply-add (contract 2) or round(a*b) + c (contract 1);
+// every helper keeps the same association order under both
+VKR_DEV float cfma(float a, float b, float c) {
+#if VKR_CONTRACT >= 2
+  return __builtin_fmaf(a, b, c);
+#else
+  return a * b + c;
+#endif
+}
 
 struct f2 { float x, y; };
 struct f3 { float x, y, z; };
@@ -51,14 +71,17 @@ VKR_DEV float vmin(float a, float b) { return fminf(a, b); }
 VKR_DEV float vmax(float a, float b) { return fmaxf(a, b); }
 VKR_DEV float vclamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 VKR_DEV int iclamp(int x, int lo, int hi) { return min(max(x, lo), hi); }
-VKR_DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+VKR_DEV float mixf(float a, float b, float t) { return cfma(b, t, a * (1.0f - t)); }
 VKR_DEV f2 mix2(f2 a, f2 b, float t) { return mk2(mixf(a.x, b.x, t), mixf(a.y, b.y, t)); }
 VKR_DEV f3 mix3(f3 a, f3 b, float t) { return mk3(mixf(a.x, b.x, t), mixf(a.y, b.y, t), mixf(a.z, b.z, t)); }
 VKR_DEV f4 mix4(f4 a, f4 b, float t) { return mk4(mixf(a.x, b.x, t), mixf(a.y, b.y, t), mixf(a.z, b.z, t), mixf(a.w, b.w, t)); }
 VKR_DEV f3 min3(f3 a, f3 b) { return mk3(vmin(a.x, b.x), vmin(a.y, b.y), vmin(a.z, b.z)); }
 VKR_DEV f3 max3(f3 a, f3 b) { return mk3(vmax(a.x, b.x), vmax(a.y, b.y), vmax(a.z, b.z)); }
-VKR_DEV float dot(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
-VKR_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+VKR_DEV float dot(f2 a, f2 b) { return cfma(a.y, b.y, a.x * b.x); }
+VKR_DEV float dot(f3 a, f3 b) { return cfma(a.z, b.z, cfma(a.y, b.y, a.x * b.x)); }
+// a + s * b: ray positions, sample positions, projections off a normal
+VKR_DEV f2 madd(f2 a, float s, f2 b) { return mk2(cfma(s, b.x, a.x), cfma(s, b.y, a.y)); }
+VKR_DEV f3 madd(f3 a, float s, f3 b) { return mk3(cfma(s, b.x, a.x), cfma(s, b.y, a.y), cfma(s, b.z, a.z)); }
 VKR_DEV float length(f2 a) { return sqrtf(dot(a, a)); }
 VKR_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
 VKR_DEV f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
@@ -68,8 +91,8 @@ VKR_DEV float fast_rcp(float a) { return __builtin_amdgcn_rcpf(a); }
 VKR_DEV float fast_rsq(float a) { return __builtin_amdgcn_rsqf(a); }
 VKR_DEV float fast_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
 VKR_DEV f3 normalize_fast(f3 a) { return a * fast_rsq(dot(a, a)); }
-VKR_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-VKR_DEV f3 reflect(f3 I, f3 N) { return I - (2.0f * dot(N, I)) * N; }
+VKR_DEV f3 cross(f3 a, f3 b) { return mk3(cfma(a.y, b.z, -(a.z * b.y)), cfma(a.z, b.x, -(a.x * b.z)), cfma(a.x, b.y, -(a.y * b.x))); }
+VKR_DEV f3 reflect(f3 I, f3 N) { return madd(I, -(2.0f * dot(N, I)), N); }
 VKR_DEV bool is_nan(float a) { return a != a; }
 VKR_DEV float fractf(float a) { return a - floorf(a); }
 // float -> int: truncate, NaN -> 0, saturate at +-2^30 (a following +1 cannot overflow).
@@ -125,10 +148,10 @@ template <int CW, int CH> VKR_DEV i2 xcd_block() { return xcd_tile<CW, CH>(block
 struct Mat4 { float m[16]; };  // column-major
 VKR_DEV f4 mul(const Mat4& M, f4 v) {
   f4 r;
-  r.x = ((M.m[0] * v.x + M.m[4] * v.y) + M.m[8] * v.z) + M.m[12] * v.w;
-  r.y = ((M.m[1] * v.x + M.m[5] * v.y) + M.m[9] * v.z) + M.m[13] * v.w;
-  r.z = ((M.m[2] * v.x + M.m[6] * v.y) + M.m[10] * v.z) + M.m[14] * v.w;
-  r.w = ((M.m[3] * v.x + M.m[7] * v.y) + M.m[11] * v.z) + M.m[15] * v.w;
+  r.x = cfma(M.m[12], v.w, cfma(M.m[8], v.z, cfma(M.m[4], v.y, M.m[0] * v.x)));
+  r.y = cfma(M.m[13], v.w, cfma(M.m[9], v.z, cfma(M.m[5], v.y, M.m[1] * v.x)));
+  r.z = cfma(M.m[14], v.w, cfma(M.m[10], v.z, cfma(M.m[6], v.y, M.m[2] * v.x)));
+  r.w = cfma(M.m[15], v.w, cfma(M.m[11], v.z, cfma(M.m[7], v.y, M.m[3] * v.x)));
   return r;
 }
 
@@ -231,7 +254,7 @@ template <class F> VKR_DEV typename F::T fetch_clamped(const Tex& t, int gx, int
 }
 // texture()/textureLod()/textureOffset(): bilinear, clamp-to-edge
 template <class F> VKR_DEV typename F::T sample(const Tex& t, f2 uv, int offx = 0, int offy = 0) {
-  float x = uv.x * (float)t.fw - 0.5f, y = uv.y * (float)t.fh - 0.5f;
+  float x = cfma(uv.x, (float)t.fw, -0.5f), y = cfma(uv.y, (float)t.fh, -0.5f);
   float x0f = floorf(x), y0f = floorf(y);
   float fx = x - x0f, fy = y - y0f;
   int x0 = f2i(x0f) + offx, y0 = f2i(y0f) + offy;
@@ -270,7 +293,7 @@ struct BilinearTaps { uint32_t t00, t10, t01, t11; float fx, fy; };
 // the four raw texels + weights of texture(tex, uv) for any 4-byte format
 VKR_DEV BilinearTaps bilinear_taps_u32(const Tex& t, f2 uv) {
   BilinearTaps b;
-  float x = uv.x * (float)t.fw - 0.5f, y = uv.y * (float)t.fh - 0.5f;
+  float x = cfma(uv.x, (float)t.fw, -0.5f), y = cfma(uv.y, (float)t.fh, -0.5f);
   float x0f = floorf(x), y0f = floorf(y);
   b.fx = x - x0f; b.fy = y - y0f;
   int x0 = f2i(x0f), y0 = f2i(y0f);
@@ -316,11 +339,11 @@ VKR_DEV f2 encode_normal(f3 v) {
   float inv = 1.0f / l1norm;
   f2 r = mk2(v.x * inv, v.y * inv);
   if (v.z < 0.0f) r = mk2((1.0f - fabsf(r.y)) * sign_nz(r.x), (1.0f - fabsf(r.x)) * sign_nz(r.y));
-  return mk2(0.5f * r.x + 0.5f, 0.5f * r.y + 0.5f);
+  return mk2(cfma(0.5f, r.x, 0.5f), cfma(0.5f, r.y, 0.5f));
 }
 // gbuffer_encode.glsl:29-37
 VKR_DEV f3 decode_normal(f2 uv) {
-  uv = mk2(2.0f * uv.x - 1.0f, 2.0f * uv.y - 1.0f);
+  uv = mk2(cfma(2.0f, uv.x, -1.0f), cfma(2.0f, uv.y, -1.0f));
   f3 v = mk3(uv.x, uv.y, (1.0f - fabsf(uv.x)) - fabsf(uv.y));
   if (v.z < 0.0f) {
     float nx = (1.0f - fabsf(v.y)) * sign_nz(v.x);
@@ -344,7 +367,7 @@ VKR_DEV float div_normal(float a, float b) {
 }
 // decode_normal whose result only enters smooth terms (weights, shading angles)
 VKR_DEV f3 decode_normal_fast(f2 uv) {
-  uv = mk2(2.0f * uv.x - 1.0f, 2.0f * uv.y - 1.0f);
+  uv = mk2(cfma(2.0f, uv.x, -1.0f), cfma(2.0f, uv.y, -1.0f));
   f3 v = mk3(uv.x, uv.y, (1.0f - fabsf(uv.x)) - fabsf(uv.y));
   if (v.z < 0.0f) {
     float nx = (1.0f - fabsf(v.y)) * sign_nz(v.x);
@@ -354,13 +377,13 @@ VKR_DEV f3 decode_normal_fast(f2 uv) {
   return normalize_fast(v);
 }
 // gbuffer_encode.glsl:53-56
-VKR_DEV float linearize_depth2(float d, float n, float f) { return (n * f) / (d * (f - n) - f); }
+VKR_DEV float linearize_depth2(float d, float n, float f) { return (n * f) / cfma(d, f - n, -f); }
 // the same for a stored depth d in [0,1]: the denominator lies in [-f, -n], far inside the normal range
-VKR_DEV float linearize_depth2_unorm(float d, float n, float f) { return div_normal(n * f, d * (f - n) - f); }
+VKR_DEV float linearize_depth2_unorm(float d, float n, float f) { return div_normal(n * f, cfma(d, f - n, -f)); }
 // gbuffer_encode.glsl:58-69.  d is always a depth-buffer value (or a lerp of them) in [0,1] here.
 VKR_DEV f3 reconstruct_view_vec(f2 uv, float d, const Proj& pr) {
   float z = linearize_depth2_unorm(d, pr.znear, pr.zfar);
-  float xd = 2.0f * uv.x - 1.0f, yd = 2.0f * uv.y - 1.0f;
+  float xd = cfma(2.0f, uv.x, -1.0f), yd = cfma(2.0f, uv.y, -1.0f);
   float x = -(xd) * ((z * pr.aspect) * pr.tg);
   float y = -(yd) * (z * pr.tg);
   return mk3(x, y, z);
@@ -373,7 +396,7 @@ VKR_DEV f3 project_view_vec(f3 v, const Proj& pr) {
   float depth = f / (f - n) + (f * n) / (z * (f - n));
   float pu = v.x / ((-v.z * pr.tg) * pr.aspect);
   float pv = v.y / (-z * pr.tg);
-  return mk3(0.5f * pu + 0.5f, 0.5f * pv + 0.5f, depth);
+  return mk3(cfma(0.5f, pu, 0.5f), cfma(0.5f, pv, 0.5f), depth);
 }
 
 // brdf.glsl:6-13
