@@ -213,7 +213,8 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame():
             counts[name] += n
             texels[name] += got.shape[0] * (got.shape[1] // bpp)
             if n:
-                print(f"[deviation] rank {r} {name}: {n} texels differ from the one-GPU frame")
+                where = diff.any(dim=-1).nonzero()[:8].tolist()  # (row inside the tile, column), in the surface's own resolution
+                print(f"[deviation] rank {r} {name}: {n} texels differ from the one-GPU frame, e.g. tile row / column {where} (tile rows {th >> dv})")
         t.frame.close()
     report_d = {"frame": [W, H], "grid": [cols, rows], "halo_px": 48, "frames": frames,
                 "differing_texels": counts, "compared_texels": texels}
