@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PRODUCT_LIB = os.path.join(ROOT, "vk-renderer_amd", "csrc", "libvkr_postfx.so")
+# VKR_POSTFX_LIB: development only (tools/blur_timeline.py loads an instrumented build of the same sources)
+PRODUCT_LIB = os.environ.get("VKR_POSTFX_LIB") or os.path.join(ROOT, "vk-renderer_amd", "csrc", "libvkr_postfx.so")
 HOST_LIB = os.path.join(ROOT, "vk-renderer_amd", "host", "libvkr_host.so")
 
 VKR_MAX_MIPS = 16

@@ -373,6 +373,17 @@ struct BlurCentre {  // per output pixel
   int r, tc;
 };
 
+// Development instrumentation, compiled only with -DVKR_BLUR_STAMPS (tools/blur_timeline.py builds such a library next to the
+// product one): wave 0 of every block records the 100 MHz wall clock at its phase boundaries, plus where it ran.
+#ifdef VKR_BLUR_STAMPS
+__device__ unsigned long long g_blur_stamps[65536 * 8];
+#define VKR_STAMP(slot) do { if (threadIdx.x == 0 && threadIdx.y == 0) g_blur_stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+#define VKR_STAMP_VALUE(slot, v) do { if (threadIdx.x == 0 && threadIdx.y == 0) g_blur_stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = (unsigned long long)(v); } while (0)
+#else
+#define VKR_STAMP(slot) do {} while (0)
+#define VKR_STAMP_VALUE(slot, v) do {} while (0)
+#endif
+
 // accumulators: xyz = sum w * colour (UNORM8 code units), w = sum w
 VKR_DEV void blur_tap(const float4* s_nd, const uint32_t* s_refl, const BlurCentre& c, int t, float wg, f4& acc) {
   const float4 nd = s_nd[t];
@@ -473,6 +484,7 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
     history_taps[k] = bilinear_taps_u32(a.history, uv_c[k]);  // screen_uv, not prev_uv (blur.comp:103)
   }
   __syncthreads();
+  VKR_STAMP(1);  // tile staged, per-pixel loads issued
   if (!live) return;
 
   // per-pixel set-up (blur.comp:34-55) and the temporal test (blur.comp:79-105) for A and B
@@ -511,6 +523,8 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
     history_color[k] = taps_resolve<FmtRGBA8>(history_taps[k]);
   }
 
+  VKR_STAMP(2);  // per-pixel set-up done
+  VKR_STAMP_VALUE(5, c[0].r);
   f4 accA, accB = mk4(0, 0, 0, 0);
   if (!has_b || c[0].r != c[1].r) {
     accA = blur_single(s_nd, s_refl, c[0]);
@@ -574,6 +588,7 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
     accB = mk4(accB.x * g2.y, accB.y * g2.y, accB.z * g2.y, accB.w * g2.y);
   }
 
+  VKR_STAMP(3);  // tap loop done (wave 0)
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     if (k == 1 && !has_b) break;
@@ -591,8 +606,18 @@ __global__ __launch_bounds__(BLUR_THREADS, 4) void k_sssr_blur(BlurArgs a) {
   __shared__ uint32_t s_refl[BLUR_TH * BLUR_TW];
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   const int tid = threadIdx.y * BLUR_BX + threadIdx.x;
+  VKR_STAMP(0);
+#ifdef VKR_BLUR_STAMPS
+  {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    VKR_STAMP_VALUE(6, ((unsigned long long)xcc << 32) | hw);
+  }
+#endif
   srgb_lut_stage(s_lut, tid, BLUR_THREADS);
   blur_tile(a, xcd_block<4, 2>(), s_nd, s_refl, s_lut, tid);  // chunks of 128 x 64 output pixels
+  VKR_STAMP(4);
 }
 
 }  // namespace vkr
@@ -692,6 +717,12 @@ static int make_blur_args(BlurArgs& a, const vkr_img* depth, const vkr_img* norm
   }
   return VKR_OK;
 }
+
+#ifdef VKR_BLUR_STAMPS
+extern "C" int vkr_debug_blur_stamps(void* dst, uint64_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_blur_stamps), bytes < sizeof(g_blur_stamps) ? bytes : sizeof(g_blur_stamps));
+}
+#endif
 
 extern "C" int vkr_sssr_blur(const vkr_img* depth, const vkr_img* normal, const vkr_img* reflections,
                              const vkr_img* material, const vkr_img* history, const vkr_img* velocity,
