@@ -46,7 +46,9 @@ typedef enum vkr_format {
   VKR_FMT_RGBA16_SFLOAT  = 7,  /* 4 x fp16                                         */
   VKR_FMT_R16_SFLOAT     = 8,  /* 1 x fp16                                         */
   VKR_FMT_R32_SFLOAT     = 9,  /* 1 x fp32                                         */
-  VKR_FMT_R8_UNORM       = 10  /* 1 x uint8 (create_gtao_texture, gtao.cpp:10)     */
+  VKR_FMT_R8_UNORM       = 10, /* 1 x uint8 (create_gtao_texture, gtao.cpp:10)     */
+  VKR_FMT_RGBA32_SFLOAT  = 11  /* 4 x fp32: AdvancedSSR::tile_planes (advanced_ssr.cpp:85), allocated by the reference's
+                                  constructor, bound by no program of this path       */
 } vkr_format;
 
 /* bytes per texel of a vkr_format (0 for unknown) */

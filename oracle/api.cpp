@@ -29,6 +29,7 @@ uint32_t vkr_format_bytes(uint32_t format) {
     case VKR_FMT_D24_UNORM_S8: case VKR_FMT_RG16_UNORM: case VKR_FMT_RG16_SFLOAT:
     case VKR_FMT_RGBA8_SRGB: case VKR_FMT_RGBA8_UNORM: case VKR_FMT_R32_SFLOAT: return 4;
     case VKR_FMT_RGBA16_UNORM: case VKR_FMT_RGBA16_SFLOAT: return 8;
+    case VKR_FMT_RGBA32_SFLOAT: return 16;
     case VKR_FMT_R16_SFLOAT: return 2;
     case VKR_FMT_R8_UNORM: return 1;
     default: return 0;

@@ -10,7 +10,8 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # VKR_POSTFX_LIB: development only (tools/blur_timeline.py loads an instrumented build of the same sources)
 PRODUCT_LIB = os.environ.get("VKR_POSTFX_LIB") or os.path.join(ROOT, "vk-renderer_amd", "csrc", "libvkr_postfx.so")
-HOST_LIB = os.path.join(ROOT, "vk-renderer_amd", "host", "libvkr_host.so")
+# VKR_HOST_LIB: tests only (tests/test_reference_passes_gpu.py loads the mirror built around the reference's own pass sources)
+HOST_LIB = os.environ.get("VKR_HOST_LIB") or os.path.join(ROOT, "vk-renderer_amd", "host", "libvkr_host.so")
 
 VKR_MAX_MIPS = 16
 HALTON_SEQ_SIZE = 128
@@ -26,7 +27,8 @@ FMT_RGBA16_SFLOAT = 7
 FMT_R16_SFLOAT = 8
 FMT_R32_SFLOAT = 9
 FMT_R8_UNORM = 10
-FORMAT_BYTES = {1: 4, 2: 4, 3: 4, 4: 4, 5: 4, 6: 8, 7: 8, 8: 2, 9: 4, 10: 1}
+FMT_RGBA32_SFLOAT = 11
+FORMAT_BYTES = {1: 4, 2: 4, 3: 4, 4: 4, 5: 4, 6: 8, 7: 8, 8: 2, 9: 4, 10: 1, 11: 16}
 
 NORMALIZE_REFLECTIONS = 1
 ACCUMULATE_REFLECTIONS = 2

@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
+
 #include <map>
 #include <mutex>
 
@@ -52,6 +54,7 @@ uint32_t to_vkr_format(VkFormat fmt) {
     case VK_FORMAT_R16_SFLOAT: return VKR_FMT_R16_SFLOAT;
     case VK_FORMAT_R32_SFLOAT: return VKR_FMT_R32_SFLOAT;
     case VK_FORMAT_R8_UNORM: return VKR_FMT_R8_UNORM;
+    case VK_FORMAT_R32G32B32A32_SFLOAT: return VKR_FMT_RGBA32_SFLOAT;
     default: throw std::runtime_error{"Unsupported image format on the post-process path"};
   }
 }
@@ -207,6 +210,26 @@ vkr_img tex(const LaunchState& st, uint32_t slot, SetSlot::Kind kind, const char
   }
   return s.view.image->describe(s.view.range.base_mip, s.view.range.mips_count);
 }
+// The Halton(2,3) UBO of AdvancedSSR (advanced_ssr.cpp:54-58: 128 x vec4, xy filled, zw = 0).  The HIP programs want
+// cos / sin(2 PI y) in zw (evaluated on the host once instead of per ray, vkr_halton23_fill); a table that arrives as
+// the reference builds it is completed here, in the buffer's host shadow, before it is uploaded.
+const float* halton_table(Buffer* b, void* stream) {
+  const float* h = (const float*)b->host_data();
+  const size_t n = b->get_size() / 16;
+  bool raw = h != nullptr && n > 0;
+  for (size_t i = 0; raw && i < n; i++) raw = h[4 * i + 2] == 0.0f && h[4 * i + 3] == 0.0f;
+  if (raw) {
+    float* w = (float*)b->get_mapped_ptr();  // marks the shadow dirty: re-uploaded by device_ptr() below
+    const float PI = 3.1415926535897932384626433832795f;
+    for (size_t i = 0; i < n; i++) {
+      const float phi = (2.0f * PI) * w[4 * i + 1];
+      w[4 * i + 2] = (float)std::cos((double)phi);
+      w[4 * i + 3] = (float)std::sin((double)phi);
+    }
+  }
+  return (const float*)b->device_ptr(stream);
+}
+
 template <typename T> const T* ubo(const LaunchState& st, uint32_t slot, const char* prog) {
   const SetSlot& s = st.set ? st.set->slots[slot] : SetSlot{};
   if (!st.set || s.kind != SetSlot::Ubo) throw std::runtime_error{std::string{prog} + ": uniform block " + std::to_string(slot) + " is not bound"};
@@ -257,6 +280,10 @@ void register_hot_path_programs() {
       vkr_img depth = ds.view.image->describe(ds.view.range.base_mip, 1 + (uint32_t)st.attachments.size());
       return vkr_depth_mips(&depth, 0, st.stream);
     });
+    // Programs the reference's constructors name but this path does not implement (out of scope):
+    // known to the table, so that constructing the pass works as it does in the reference; launching one throws.
+    for (const char* name : {"tile_regression", "gtao_rt_main"})
+      create_program(name, [name](LaunchState&) -> int { throw std::runtime_error{std::string{name} + ": program is not implemented on the post-process path"}; });
     create_program("pdf_preintegrate", [=](LaunchState& st) {
       vkr_img out = tex(st, 0, S, "pdf_preintegrate");
       return vkr_pdf_preintegrate(&out, st.stream);
@@ -267,7 +294,7 @@ void register_hot_path_programs() {
       vkr_img rays = tex(st, 5, S, P), occ = tex(st, 6, S, P), pdf = tex(st, 7, T, P);
       const SetSlot& h = st.set->slots[4];
       if (h.kind != SetSlot::Ubo || !h.buffer) throw std::runtime_error{"sssr_trace: Halton buffer (binding 4) is not bound"};
-      return vkr_sssr_trace(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), (const float*)h.buffer->device_ptr(st.stream),
+      return vkr_sssr_trace(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), halton_table(h.buffer.get(), st.stream),
                             &rays, &occ, &pdf, push<vkr_trace_push>(st, P), st.stream);
     });
     create_program("sssr_filter", [=](LaunchState& st) {
@@ -320,7 +347,7 @@ void register_hot_path_programs() {
       const SetSlot& h = st.set->slots[0];
       if (h.kind != SetSlot::Ubo || !h.buffer) throw std::runtime_error{"brdf_preintegrate: Halton buffer (binding 0) is not bound"};
       vkr_img out = tex(st, 1, S, "brdf_preintegrate");
-      return vkr_brdf_preintegrate((const float*)h.buffer->device_ptr(st.stream), &out, st.stream);
+      return vkr_brdf_preintegrate(halton_table(h.buffer.get(), st.stream), &out, st.stream);
     });
     // defered_shading/shader.frag: set {0 albedo, 1 normal, 2 material, 3 depth, 4 Constants, 5 shadow (unused), 6 occlusion, 7 brdf, 8 reflections}
     create_program("defered_shading", [=](LaunchState& st) {
@@ -352,7 +379,7 @@ void register_hot_path_programs() {
       const SetSlot& h = st.set->slots[4];
       if (h.kind != SetSlot::Ubo || !h.buffer) throw std::runtime_error{"sssr_trace_indirect: Halton buffer (binding 4) is not bound"};
       Buffer* tiles = ssbo(st, 6, P);
-      return vkr_sssr_trace_indirect(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), (const float*)h.buffer->device_ptr(st.stream), &rays,
+      return vkr_sssr_trace_indirect(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), halton_table(h.buffer.get(), st.stream), &rays,
                                      (const int32_t*)tiles->device_ptr(st.stream), (const uint32_t*)st.indirect->device_ptr(st.stream),
                                      (uint32_t)(tiles->get_size() / sizeof(int32_t)), push<vkr_trace_indirect_push>(st, P), st.stream);
     });

@@ -81,6 +81,7 @@ void Gbuffer::enable_tiling(RenderGraph &graph, uint32_t full_width, uint32_t fu
 }
 
 // ==== DownsamplePass (downsample_pass.cpp) ================================================================
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 DownsamplePass::DownsamplePass() : sampler {default_sampler()} {
   gpu::Registers always_write {};  // :6-9: depth test ALWAYS + depth write
   always_write.depth_stencil.depthTestEnable = VK_TRUE;
@@ -89,8 +90,10 @@ DownsamplePass::DownsamplePass() : sampler {default_sampler()} {
   downsample_gbuffer = fullscreen_pipeline("downsample_gbuffer", always_write);
   downsample_depth = fullscreen_pipeline("depth_mips", always_write);
 }
+#endif
 
 // :25-92.  Size checks and their messages :37-50.
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void DownsamplePass::run_downsample_gbuff(RenderGraph &graph, ImageResourceId src_normals, ImageResourceId src_velocity, ImageResourceId depth,
   ImageResourceId out_normal, ImageResourceId out_velocity)
 {
@@ -107,10 +110,12 @@ void DownsamplePass::run_downsample_gbuff(RenderGraph &graph, ImageResourceId sr
      rec::color_target(out_normal), rec::color_target(out_velocity), rec::depth_target(depth, 1)},
     rec::no_push(), half_w, half_h);
 }
+#endif
 
 // :94-131 records one "DownsampleDepth" draw per mip (L-2 dependent passes).  MI355X-first: one task whose
 // attachments are all remaining mips; the bound program reduces five levels per workgroup through LDS.
 // Each mip is still the 2x2 min of its parent with extent max(1, W >> i) (:118-120).
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void DownsamplePass::run_downsample_depth(RenderGraph &graph, ImageResourceId depth, uint32_t src_mip) {
   const auto desc = graph.get_descriptor(depth);
   if (src_mip + 1 >= desc.mip_levels) return;
@@ -120,20 +125,26 @@ void DownsamplePass::run_downsample_depth(RenderGraph &graph, ImageResourceId de
   rec::fullscreen(graph, "DownsampleDepth", downsample_depth, binds, rec::no_push(),
                   std::max(desc.width >> (src_mip + 1), 1u), std::max(desc.height >> (src_mip + 1), 1u));
 }
+#endif
 
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void DownsamplePass::run(RenderGraph &graph, ImageResourceId src_normals, ImageResourceId src_velocity, ImageResourceId depth,
   ImageResourceId out_normals, ImageResourceId out_velocity)
 {
   run_downsample_gbuff(graph, src_normals, src_velocity, depth, out_normals, out_velocity);  // :133-143
   run_downsample_depth(graph, depth, 1);
 }
+#endif
 
 // ==== GTAO (gtao.cpp) ================================================================================
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 ImageResourceId create_gtao_texture(RenderGraph &graph, uint32_t width, uint32_t height) {  // :10-13
   return make_image(graph, VK_FORMAT_R8_UNORM, width, height, VK_IMAGE_USAGE_COLOR_ATTACHMENT_BIT|VK_IMAGE_USAGE_SAMPLED_BIT);
 }
+#endif
 
 // resources :17-47, pipelines :49-81
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 GTAO::GTAO(RenderGraph &graph, uint32_t width, uint32_t height, bool use_ray_query, bool half_res, int pattern_n)
   : deinterleave_n {pattern_n}, pinned_jitter {std::numeric_limits<float>::quiet_NaN()}
 {
@@ -164,6 +175,7 @@ GTAO::GTAO(RenderGraph &graph, uint32_t width, uint32_t height, bool use_ray_que
   main_pipeline_gfx.set_rendersubpass({false, {graph.get_descriptor(raw).format}});
   sampler = default_sampler();
 }
+#endif
 
 // the 12-entry angle table + jitter every main-pass flavour uses (:109-111, :362-364, :487-489)
 float GTAO::next_base_angle() {
@@ -173,6 +185,7 @@ float GTAO::next_base_angle() {
 }
 
 // :84-148; PushConsts :101-113; floor dispatch :145
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void GTAO::add_main_pass(RenderGraph &graph, const GTAOParams &params, ImageResourceId depth, ImageResourceId normal,
   ImageResourceId material, ImageResourceId preintegrated_pdf)
 {
@@ -183,16 +196,20 @@ void GTAO::add_main_pass(RenderGraph &graph, const GTAOParams &params, ImageReso
      rec::sampled(3, material, sampler), rec::sampled(4, preintegrated_pdf, sampler), rec::storage(5, raw)},
     rec::push(pc), rec::Grid {raw, 8, 4, rec::Floor});
 }
+#endif
 
 // :198-239
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void GTAO::add_filter_pass(RenderGraph &graph, const GTAOParams &params, ImageResourceId depth) {
   const vkr_gtao_filter_push pc {params.znear, params.zfar};
   rec::compute(graph, "GTAO_filter", filter_pipeline,
     {rec::sampled_mips(0, depth, sampler, DEPTH, depth_lod, 1), rec::sampled(1, raw, sampler), rec::storage(2, filtered)},
     rec::push(pc), rec::Grid {filtered, 8, 4, rec::Floor});
 }
+#endif
 
 // :286-347; AccumConstants :300-305; clear_history is consumed once :313-315; ceil dispatch :345
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void GTAO::add_accumulate_pass(RenderGraph &graph, const DrawTAAParams &params, const Gbuffer &gbuffer) {
   vkr_gtao_accum_params consts;
   copy_mat(consts.inverse_camera, glm::inverse(params.camera));
@@ -207,9 +224,11 @@ void GTAO::add_accumulate_pass(RenderGraph &graph, const DrawTAAParams &params, 
      rec::sampled(5, accumulated_history, sampler), rec::uniform(6, consts)},
     rec::push(pc), rec::Grid {accumulated_ao, 8, 4, rec::Ceil});
 }
+#endif
 
 // ---- the variants the reference's frame loop never records ----
 // :349-413: full-screen triangle into `raw`
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void GTAO::add_main_pass_graphics(RenderGraph &graph, const GTAOParams &params, ImageResourceId depth, ImageResourceId normal) {
   const vkr_gtao_gfx_push pc {next_base_angle()};
   const auto ext = graph.get_descriptor(raw);
@@ -217,13 +236,17 @@ void GTAO::add_main_pass_graphics(RenderGraph &graph, const GTAOParams &params, 
     {rec::sampled_mips(0, depth, sampler, DEPTH, depth_lod, 1), rec::uniform(1, params), rec::sampled(2, normal, sampler), rec::color_target(raw)},
     rec::push(pc), ext.width, ext.height);
 }
+#endif
 
 // :150-196 (VK_KHR_ray_query against the scene's TLAS): not part of this path
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void GTAO::add_main_rt_pass(RenderGraph &, const GTAORTParams &, VkAccelerationStructureKHR, ImageResourceId, ImageResourceId) {
   throw std::runtime_error {"GTAO::add_main_rt_pass: the ray-query pass needs a scene acceleration structure (out of scope: SURVEY.md section 2b)"};
 }
+#endif
 
 // :528-536, the panel as the reference draws it; the ImGui names are inert in this headless build (imgui_pass.hpp)
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void GTAO::draw_ui() {
   ImGui::Begin("GTAO");
   ImGui::Checkbox("Enable MIS", &mis_gtao);
@@ -233,8 +256,10 @@ void GTAO::draw_ui() {
   clear_history = ImGui::Button("Clear history") || clear_history;  // a headless request_clear_history() stays pending
   ImGui::End();
 }
+#endif
 
 // :241-284: filtered + prev_frame -> output
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void GTAO::add_reprojection_pass(RenderGraph &graph, const GTAOReprojection &params, ImageResourceId depth, ImageResourceId prev_depth) {
   static_assert(sizeof(GTAOReprojection) == sizeof(vkr_gtao_reprojection), "GTAOReprojection must match the C-ABI");
   rec::compute(graph, "GTAO_reproject", reproject_pipeline,
@@ -242,16 +267,20 @@ void GTAO::add_reprojection_pass(RenderGraph &graph, const GTAOReprojection &par
      rec::sampled(3, filtered, sampler), rec::sampled(4, prev_frame, sampler), rec::storage(5, output)},
     rec::no_push(), rec::Grid {output, 8, 4, rec::Floor});
 }
+#endif
 
 // :445-470: the dispatch is sized by the *array* extent, as the reference records it (:468)
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void GTAO::deinterleave_depth(RenderGraph &graph, ImageResourceId depth) {
   const vkr_deinterleave_push pc {deinterleave_n};
   rec::compute(graph, "GTAO_deinterleave", deinterleave_pipeline,
     {rec::sampled_mips(0, depth, sampler, DEPTH, depth_lod, 1), rec::storage_array(1, deinterleaved_depth)},
     rec::push(pc), rec::Grid {deinterleaved_depth, 8, 4, rec::Floor});
 }
+#endif
 
 // :472-526: one dispatch per array layer of the *output* image (raw has one), exactly as the reference loops
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void GTAO::add_main_pass_deinterleaved(RenderGraph &graph, const GTAOParams &params, ImageResourceId normal) {
   const float base_angle = next_base_angle();
   const uint32_t layers = graph.get_descriptor(raw).array_layers? graph.get_descriptor(raw).array_layers : 1;
@@ -262,6 +291,7 @@ void GTAO::add_main_pass_deinterleaved(RenderGraph &graph, const GTAOParams &par
       rec::push(pc), rec::Grid {raw, 8, 4, rec::Floor});
   }
 }
+#endif
 
 // ==== AdvancedSSR (advanced_ssr.cpp) ========================================================================
 // radical inverse with the reference's float-floor division (:8-20) kept as is
@@ -276,14 +306,17 @@ static float halton_elem(uint32_t index, uint32_t base) {
   return result;
 }
 
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 std::vector<glm::vec4> halton23_seq(uint32_t count) {  // :22-34
   std::vector<glm::vec4> seq(count);
   for (uint32_t i = 0; i < count; i++)
     seq[i] = glm::vec4 {halton_elem(i + 1, 2), halton_elem(i + 1, 3), 0.f, 0.f};
   return seq;
 }
+#endif
 
 // :36-93
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 AdvancedSSR::AdvancedSSR(RenderGraph &graph, uint32_t w, uint32_t h) {
   trace_pass = gpu::create_compute_pipeline("sssr_trace");
   filter_pass = gpu::create_compute_pipeline("sssr_filter");
@@ -326,17 +359,22 @@ AdvancedSSR::AdvancedSSR(RenderGraph &graph, uint32_t w, uint32_t h) {
   reflective_tiles = graph.create_buffer(VMA_MEMORY_USAGE_GPU_ONLY, tile_bytes, VK_BUFFER_USAGE_STORAGE_BUFFER_BIT);
   glossy_tiles = graph.create_buffer(VMA_MEMORY_USAGE_GPU_ONLY, tile_bytes, VK_BUFFER_USAGE_STORAGE_BUFFER_BIT);
 }
+#endif
 
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void AdvancedSSR::preintegrate_pdf(RenderGraph &graph) {  // :95-114
   rec::compute(graph, "SSR_preintegrate", preintegrate_pass, {rec::storage(0, preintegrated_pdf)}, rec::no_push(),
                rec::Grid {preintegrated_pdf, 8, 4, rec::Ceil});
 }
+#endif
 
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void AdvancedSSR::preintegrate_brdf(RenderGraph &graph) {  // :116-136
   rec::compute(graph, "BRDF_preintegrate", preintegrate_brdf_pass,
                {rec::uniform_buffer(0, halton_buffer), rec::storage(1, preintegrated_brdf)}, rec::no_push(),
                rec::Grid {preintegrated_brdf, 8, 4, rec::Ceil});
 }
+#endif
 
 // TraceParams (:138-145) with the frame counter, which cycles modulo max_accumulated_rays (:168-171)
 static vkr_trace_params trace_params(const AdvancedSSRParams &p, uint32_t counter) {
@@ -353,6 +391,7 @@ void AdvancedSSR::advance_counter() {
 
 // :147-214.  Single GPU: the march reads image mips 1..L-1 of gbuff.depth (:186); tiled: the gathered
 // whole-frame pyramid and normals.
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void AdvancedSSR::run_trace_pass(RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff, ImageResourceId ssr_occlusion) {
   const vkr_trace_params config = trace_params(params, counter);
   const vkr_trace_push pc {settings.max_rougness};
@@ -366,8 +405,10 @@ void AdvancedSSR::run_trace_pass(RenderGraph &graph, const AdvancedSSRParams &pa
      rec::sampled(7, preintegrated_pdf, sampler)},
     rec::push(pc), rec::Grid {rays, 8, 8, rec::Ceil});
 }
+#endif
 
 // :308-369; flags :331-338; depth view = mips 0..9 (:342); tiled: the hit colour comes from the whole-frame albedo
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void AdvancedSSR::run_filter_pass(RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff) {
   const vkr_trace_params config = trace_params(params, counter);
   vkr_filter_push pc {0u};
@@ -381,8 +422,10 @@ void AdvancedSSR::run_filter_pass(RenderGraph &graph, const AdvancedSSRParams &p
      rec::sampled(4, gbuff.material, sampler), rec::storage(5, reflections), rec::uniform(6, config)},
     rec::push(pc), rec::Grid {reflections, 8, 8, rec::Ceil});
 }
+#endif
 
 // :371-438
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void AdvancedSSR::run_blur_pass(RenderGraph &graph, const AdvancedSSRParams &, const DrawTAAParams &taa_params, const Gbuffer &gbuff) {
   const vkr_blur_push pc {settings.max_rougness, settings.accumulate_reflections? 1u : 0u, settings.use_blur? 0u : 1u};
   const uint32_t depth_mips = std::min(10u, graph.get_descriptor(gbuff.depth).mip_levels);
@@ -393,8 +436,10 @@ void AdvancedSSR::run_blur_pass(RenderGraph &graph, const AdvancedSSRParams &, c
      rec::storage(7, blurred_reflection), rec::uniform(8, reproject_params(taa_params))},
     rec::push(pc), rec::Grid {blurred_reflection, 8, 8, rec::Ceil});
 }
+#endif
 
 // :440-452: VkDispatchIndirectCommand{0, 1, 1} into both argument buffers
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void AdvancedSSR::clear_indirect_params(RenderGraph &graph) {
   struct Nothing {};
   const auto a = reflective_indirect, b = glossy_indirect;
@@ -409,8 +454,10 @@ void AdvancedSSR::clear_indirect_params(RenderGraph &graph) {
       cmd.update_buffer(resources.get_buffer(b)->api_buffer(), 0, none);
     });
 }
+#endif
 
 // :454-495
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void AdvancedSSR::run_classification_pass(RenderGraph &graph, const AdvancedSSRParams &, const Gbuffer &gbuff) {
   const auto extent = graph.get_descriptor(rays).extent2D();
   const vkr_classification_push pc {int(extent.width), int(extent.height), settings.max_rougness, settings.glossy_roughness_value};
@@ -419,8 +466,10 @@ void AdvancedSSR::run_classification_pass(RenderGraph &graph, const AdvancedSSRP
      rec::storage_buffer(3, reflective_indirect, false), rec::storage_buffer(4, glossy_indirect, false)},
     rec::push(pc), rec::Grid {rays, 8, 8, rec::Ceil});
 }
+#endif
 
 // :216-302: two indirect dispatches of one program, mirror tiles (reflection_type 0) then glossy tiles (1)
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void AdvancedSSR::run_trace_indirect_pass(RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff) {
   const vkr_trace_params config = trace_params(params, counter);
   const float max_roughness = settings.max_rougness;
@@ -455,6 +504,7 @@ void AdvancedSSR::run_trace_indirect_pass(RenderGraph &graph, const AdvancedSSRP
       }
     });
 }
+#endif
 
 void AdvancedSSR::run_trace(RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff, ImageResourceId ssr_occlusion) {
   if (settings.use_tile_classification) {  // the path advanced_ssr.cpp:547-550 keeps commented out
@@ -471,14 +521,17 @@ void AdvancedSSR::run_resolve(RenderGraph &graph, const AdvancedSSRParams &param
   run_blur_pass(graph, params, taa_params, gbuff);
 }
 
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void AdvancedSSR::run(RenderGraph &graph, const AdvancedSSRParams &params, const DrawTAAParams &taa_params, const Gbuffer &gbuff,
   ImageResourceId ssr_occlusion)
 {
   run_trace(graph, params, gbuff, ssr_occlusion);  // :540-554
   run_resolve(graph, params, taa_params, gbuff);
 }
+#endif
 
 // ==== TAA (taa.cpp) ========================================================================================
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 TAA::TAA(RenderGraph &graph, uint32_t w, uint32_t h) {  // :3-12
   pipeline = gpu::create_compute_pipeline("taa_resolve");
   const auto usage = VK_IMAGE_USAGE_SAMPLED_BIT|VK_IMAGE_USAGE_STORAGE_BIT|VK_IMAGE_USAGE_TRANSFER_SRC_BIT;
@@ -486,7 +539,9 @@ TAA::TAA(RenderGraph &graph, uint32_t w, uint32_t h) {  // :3-12
   target = make_image(graph, VK_FORMAT_R16G16B16A16_SFLOAT, w, h, usage);
   sampler = default_sampler();
 }
+#endif
 
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void TAA::run(RenderGraph &graph, const Gbuffer &gbuffer, ImageResourceId color, const DrawTAAParams &params) {  // :19-63
   rec::compute(graph, "TAA", pipeline,
     {rec::sampled(0, history, sampler), rec::sampled(1, gbuffer.prev_depth, sampler, DEPTH), rec::sampled(2, gbuffer.depth, sampler, DEPTH),
@@ -494,13 +549,16 @@ void TAA::run(RenderGraph &graph, const Gbuffer &gbuffer, ImageResourceId color,
      rec::uniform(6, reproject_params(params))},
     rec::no_push(), rec::Grid {target, 8, 8, rec::Ceil});
 }
+#endif
 
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void TAA::remap_targets(RenderGraph &graph) { graph.remap(history, target); }  // :65-67
 
 // ==== simple SSR (ssr.cpp) =====================================================================================
 ImageResourceId create_ssr_tex(RenderGraph &graph, uint32_t w, uint32_t h) {  // :5-8
   return make_image(graph, VK_FORMAT_R8G8B8A8_UNORM, w, h, VK_IMAGE_USAGE_COLOR_ATTACHMENT_BIT|VK_IMAGE_USAGE_SAMPLED_BIT|VK_IMAGE_USAGE_STORAGE_BIT);
 }
+#endif
 
 // :10-73.  Depth is read through a NEAREST sampler with U / W clamp-to-border (:21-28).
 void add_ssr_pass(RenderGraph &graph, ImageResourceId depth, ImageResourceId normal, ImageResourceId color, ImageResourceId material,
@@ -568,11 +626,14 @@ void ScreenSpaceTrace::add_accumulate_pass(RenderGraph &graph, const ScreenTrace
 
 // ==== DeferedShadingPass (defered_shading.cpp) ======================================================================
 // advanced_ssr.cpp:497-545: the program "tile_regression" is not in the table (out of scope)
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void AdvancedSSR::run_tile_regression_pass(RenderGraph &, const AdvancedSSRParams &, const Gbuffer &) {
-  tile_regression = gpu::create_compute_pipeline("tile_regression");  // throws "Program not found"
+  throw std::runtime_error {"AdvancedSSR::run_tile_regression_pass: tile_regression is not implemented on the post-process path"};
 }
+#endif
 
 // advanced_ssr.cpp:556-567
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void AdvancedSSR::render_ui() {
   ImGui::Begin("SSSR");
   ImGui::SliderFloat("Max Roughness", &settings.max_rougness, 0.f, 1.f);
@@ -585,6 +646,7 @@ void AdvancedSSR::render_ui() {
   ImGui::Checkbox("Enable bilateral filter", &settings.bilateral_filter);
   ImGui::End();
 }
+#endif
 
 // defered_shading.cpp:120-126
 void DeferedShadingPass::draw_ui() {
