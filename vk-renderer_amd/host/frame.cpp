@@ -1,6 +1,7 @@
 // frame.cpp — see frame.hpp.  C++ exceptions thrown by the pass / graph code (the reference's
 // only error channel, gpu/common.cpp:6-12) are turned into status codes at this C boundary.
 #include "frame.hpp"
+#include "gpu_transfer.hpp"
 
 #include <hip/hip_runtime_api.h>
 
@@ -38,6 +39,8 @@ struct PostFxFrame {
   vkrh_config cfg;
   rendergraph::RenderGraph graph;
   GraphInit init;
+  struct TransferInit { explicit TransferInit(rendergraph::RenderGraph& g) { gpu_transfer::init(g); } };  // main.cpp: before the passes
+  TransferInit transfer_init;
   Gbuffer gbuffer;
   DownsamplePass downsample_pass;
   GTAO gtao;
@@ -45,6 +48,7 @@ struct PostFxFrame {
   TAA taa_pass;
   DeferedShadingPass shading_pass;
   rendergraph::ImageResourceId color_out_tex;
+  rendergraph::ImageResourceId shadow_map;  // main.cpp passes its shadow map to the shading pass (binding 5; the shader never reads it)
   SyntheticGbuffer synth;
   ScreenSpaceTrace screen_trace;
   ReadBackSystem readback;
@@ -57,7 +61,7 @@ struct PostFxFrame {
   std::string task_names, task_lanes;
 
   explicit PostFxFrame(const vkrh_config& c)
-      : cfg{c}, graph{c.stream}, init{graph, c},
+      : cfg{c}, graph{c.stream}, init{graph, c}, transfer_init{graph},
         gbuffer{graph, c.width, c.height},
         gtao{graph, c.width, c.height, false, true},  // main.cpp:265: (graph, W, H, USE_RAY_QUERY = 0, half_res = 1)
         ssr{graph, c.width, c.height},
@@ -65,6 +69,8 @@ struct PostFxFrame {
         shading_pass{graph, nullptr},
         screen_trace{graph, c.width, c.height} {
     if (c.tiled) gbuffer.enable_tiling(graph, c.full_width, c.full_height);
+    shadow_map = graph.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_D24_UNORM_S8_UINT, VK_IMAGE_ASPECT_DEPTH_BIT, 16, 16},
+                                    VK_IMAGE_TILING_OPTIMAL, VK_IMAGE_USAGE_DEPTH_STENCIL_ATTACHMENT_BIT | VK_IMAGE_USAGE_SAMPLED_BIT);
     // main.cpp:289-291
     color_out_tex = graph.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo{VK_FORMAT_R8G8B8A8_SRGB, VK_IMAGE_ASPECT_COLOR_BIT, c.width, c.height},
                                        VK_IMAGE_TILING_OPTIMAL, VK_IMAGE_USAGE_COLOR_ATTACHMENT_BIT | VK_IMAGE_USAGE_SAMPLED_BIT);
@@ -146,7 +152,7 @@ struct PostFxFrame {
     // composite of BASELINE.json is the nine passes without shading).
     if (mask & VKRH_STAGE_SHADING) {
       shading_pass.update_params(view, glm::mat4{1.f}, fazz.x, fazz.y, fazz.z, fazz.w);
-      shading_pass.draw(graph, gbuffer, rendergraph::ImageResourceId{}, gtao.accumulated_ao, ssr.get_preintegrated_brdf(), ssr.get_blurred(), color_out_tex);
+      shading_pass.draw(graph, gbuffer, shadow_map, gtao.accumulated_ao, ssr.get_preintegrated_brdf(), ssr.get_blurred(), color_out_tex);
     }
     if (mask & VKRH_STAGE_TAA) taa_pass.run(graph, gbuffer, (mask & VKRH_STAGE_SHADING) ? color_out_tex : gbuffer.albedo, draw_params);
     graph.submit();

@@ -649,6 +649,7 @@ void AdvancedSSR::render_ui() {
 #endif
 
 // defered_shading.cpp:120-126
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void DeferedShadingPass::draw_ui() {
   ImGui::Begin("DeferedShading");
   ImGui::SliderFloat("Max Roughness", &min_max_roughness.y, min_max_roughness.x, 1.f);
@@ -656,16 +657,20 @@ void DeferedShadingPass::draw_ui() {
   ImGui::Checkbox("Show AO only", &only_ao);
   ImGui::End();
 }
+#endif
 
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 DeferedShadingPass::DeferedShadingPass(RenderGraph &graph, SDL_Window *) {  // :14-31
   pipeline = fullscreen_pipeline("defered_shading");
   sampler = default_sampler();
   ubo_consts = graph.create_buffer(VMA_MEMORY_USAGE_GPU_ONLY, sizeof(vkr_shading_params), VK_BUFFER_USAGE_TRANSFER_DST_BIT|VK_BUFFER_USAGE_UNIFORM_BUFFER_BIT);
   graph_ref = &graph;
 }
+#endif
 
 // :33-45: ShaderConstants {inverse(camera), camera, shadow_mvp, fovy, aspect, znear, zfar} written into the constant
 // buffer (gpu_transfer::write_buffer in the reference; here the buffer keeps a host shadow the program reads)
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void DeferedShadingPass::update_params(const glm::mat4 &camera, const glm::mat4 &shadow, float fovy, float aspect, float znear, float zfar) {
   vkr_shading_params consts;
   copy_mat(consts.inverse_camera, glm::inverse(camera));
@@ -674,9 +679,11 @@ void DeferedShadingPass::update_params(const glm::mat4 &camera, const glm::mat4 
   consts.fovy = fovy; consts.aspect = aspect; consts.znear = znear; consts.zfar = zfar;
   std::memcpy(graph_ref->get_buffer(ubo_consts)->get_mapped_ptr(), &consts, sizeof(consts));
 }
+#endif
 
 // :47-118.  Bindings 0-8 (:93-102); the shadow map (binding 5) is bound by the reference but never read by the
 // shader, so it may be left out; push constants {vec2 min_max_roughness, uint show_ao} (:68-72).
+#ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 void DeferedShadingPass::draw(RenderGraph &graph, const Gbuffer &gbuffer, ImageResourceId shadow, ImageResourceId ssao, ImageResourceId brdf_tex,
   ImageResourceId reflections, ImageResourceId out_image)
 {
@@ -690,6 +697,7 @@ void DeferedShadingPass::draw(RenderGraph &graph, const Gbuffer &gbuffer, ImageR
   const auto ext = graph.get_descriptor(out_image);
   rec::fullscreen(graph, "DeferedShading", pipeline, binds, rec::push(pc), ext.width, ext.height);
 }
+#endif
 
 // ==== SyntheticGbuffer ===============================================================================================
 SyntheticGbuffer::SyntheticGbuffer(uint32_t s) : seed {s} {
