@@ -582,7 +582,6 @@ void CmdContext::launch() {
   state.push = push_data.data();
   state.push_size = (uint32_t)push_data.size();
   state.stream = stream;
-  state.grow_scratch = [this](uint64_t bytes) { return require_scratch(bytes); };
   int rc = it->second(state);
   push_data.clear();
   state.set = nullptr;

@@ -221,7 +221,6 @@ struct LaunchState {
   bool cleared_color = false, cleared_depth = false;
   void* scratch = nullptr;                    // device scratch owned by the command context
   uint64_t scratch_bytes = 0;
-  std::function<void*(uint64_t)> grow_scratch;  // programs that need scratch sized by their bindings ask for it here
   void* stream = nullptr;
 };
 using ProgramFn = std::function<int(LaunchState&)>;
