@@ -23,6 +23,10 @@ import time
 # ROCr reads HSA_* once, at hsa_init: this must be in the environment before anything touches the GPU
 # (the host driver only supports dmabuf IPC; without it RCCL fails with hipIpcGetMemHandle: invalid argument).
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # one node: let RCCL bootstrap over the loopback interface (the container's hostname may not resolve, and by default
+    # NCCL skips `lo` unless it is named); a launcher that knows better sets the variable itself
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
