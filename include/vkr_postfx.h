@@ -429,6 +429,9 @@ int vkr_stream_read(const void* src, uint64_t bytes, float* sink, uint32_t sink_
 /* Test hook: counts (into 5 device uint32, zeroed by the caller) where the kernels' cheap exact
  * arithmetic — normal-range division, UNORM decodes — disagrees with its IEEE definition.        */
 int vkr_selftest_division(uint32_t* device_counters5, float znear, float zfar, void* stream);
+/* Test hook: counts (into one device uint32, zeroed by the caller) the pixel centres g < size, size = 1..max_size (<= 65535),
+ * whose uv = (g + 0.5) / size differs between the kernels' normal-range division and IEEE '/'.     */
+int vkr_selftest_pixel_uv(uint32_t* device_counter, uint32_t max_size, void* stream);
 
 #ifdef __cplusplus
 }

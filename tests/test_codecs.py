@@ -36,6 +36,12 @@ def test_device_division_and_decodes_are_exact():
         abi.check(lib.vkr_selftest_division(counters.data_ptr(), znear, zfar, torch.cuda.current_stream().cuda_stream), lib)
         torch.cuda.synchronize()
         assert counters.tolist() == [0, 0, 0, 0, 0], (znear, zfar, counters.tolist())
+    # screen_uv = (g + 0.5) / size of every pixel centre of every extent up to 16384
+    lib.vkr_selftest_pixel_uv.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    abi.check(lib.vkr_selftest_pixel_uv(counter.data_ptr(), 16384, torch.cuda.current_stream().cuda_stream), lib)
+    torch.cuda.synchronize()
+    assert counter.item() == 0
 
 
 def test_half_roundtrip_all_codes(oracle_lib):

@@ -131,6 +131,32 @@ def test_chain_end_to_end(size, oracle_lib, parity_table):
     _compare(ref, gpu, ("blurred_hist", "acc_hist", "taa_hist"), budget=1e-5 if size[0] >= 3840 else 2e-4)
 
 
+@pytest.mark.parametrize("size", [(640, 360), (206, 226)])
+def test_taa_generic_footprints(size, oracle_lib, monkeypatch):
+    """taa.hip shares one bilinear footprint between colour, velocity and depth when their windows agree (always, in a
+    frame); VKR_TAA_GENERIC=1 forces the instantiation that computes the three separately.  Both must give the
+    oracle's image, also with a camera that moves enough for the depth test to decide (|velocity| >= 0.005)."""
+    from vk_renderer_amd.camera import FrameSetup
+
+    for generic in ("", "1"):
+        if generic:
+            monkeypatch.setenv("VKR_TAA_GENERIC", generic)
+        else:
+            monkeypatch.delenv("VKR_TAA_GENERIC", raising=False)
+        ref, gpu = _pair(*size, oracle_lib, setup=FrameSetup(*size))
+        ref.synth()
+        ref.build_prev_hiz()
+        ref.init_histories()
+        _sync_inputs(ref, gpu)
+        ref.taa()
+        gpu.taa()
+        _compare(ref, gpu, ("taa_target",), budget=0)
+        vel = ref.velocity.decode(0)
+        moving = int(((vel[..., 0] ** 2 + vel[..., 1] ** 2) >= 0.005 ** 2).sum())
+        print(f"[parity] taa generic={bool(generic)}: texels with |velocity| >= 0.005: {moving}")
+        assert moving > 0, "the test frame never reaches the depth comparison of the resolve"
+
+
 def test_gtao_only_config1(oracle_lib):
     """BASELINE config 1: GTAO main pass only, non-MIS (use_mis = 0), single and two directions."""
     from vk_renderer_amd.camera import FrameSetup

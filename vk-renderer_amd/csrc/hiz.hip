@@ -20,18 +20,18 @@ __global__ __launch_bounds__(256) void k_downsample_gbuffer(Tex d0, Tex d1, Tex 
   const bool has_x1 = px + 1 < d0.w, has_y1 = py + 1 < d0.h;  // only false for odd extents
   uint32_t da, db, dc, dd, na, nb, nc, nd, va, vb, vc, vd;
   if (has_x1 && has_y1) {
-    uint2 r0 = *(const uint2*)(d0.p + (size_t)py * d0.pitch + (size_t)px * 4);
-    uint2 r1 = *(const uint2*)(d0.p + (size_t)(py + 1) * d0.pitch + (size_t)px * 4);
+    uint2 r0 = *(const uint2*)(d0.p + toff(d0, px, py, 4));
+    uint2 r1 = *(const uint2*)(d0.p + toff(d0, px, (py + 1), 4));
     da = r0.x & 0xFFFFFFu; db = r0.y & 0xFFFFFFu; dc = r1.x & 0xFFFFFFu; dd = r1.y & 0xFFFFFFu;
-    uint2 m0 = *(const uint2*)(n0.p + (size_t)py * n0.pitch + (size_t)px * 4);
-    uint2 m1 = *(const uint2*)(n0.p + (size_t)(py + 1) * n0.pitch + (size_t)px * 4);
+    uint2 m0 = *(const uint2*)(n0.p + toff(n0, px, py, 4));
+    uint2 m1 = *(const uint2*)(n0.p + toff(n0, px, (py + 1), 4));
     na = m0.x; nb = m0.y; nc = m1.x; nd = m1.y;
-    uint2 w0 = *(const uint2*)(v0.p + (size_t)py * v0.pitch + (size_t)px * 4);
-    uint2 w1 = *(const uint2*)(v0.p + (size_t)(py + 1) * v0.pitch + (size_t)px * 4);
+    uint2 w0 = *(const uint2*)(v0.p + toff(v0, px, py, 4));
+    uint2 w1 = *(const uint2*)(v0.p + toff(v0, px, (py + 1), 4));
     va = w0.x; vb = w0.y; vc = w1.x; vd = w1.y;
   } else {  // texelFetch out of bounds -> 0
     auto ld = [&](const Tex& t, int lx, int ly) -> uint32_t {
-      return (lx < t.w && ly < t.h) ? *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4) : 0u;
+      return (lx < t.w && ly < t.h) ? *(const uint32_t*)(t.p + toff(t, lx, ly, 4)) : 0u;
     };
     da = ld(d0, px, py) & 0xFFFFFFu; db = ld(d0, px + 1, py) & 0xFFFFFFu;
     dc = ld(d0, px, py + 1) & 0xFFFFFFu; dd = ld(d0, px + 1, py + 1) & 0xFFFFFFu;
@@ -75,12 +75,12 @@ __global__ __launch_bounds__(256) void k_depth_mips_fused(MipChainArgs a) {
     if (x < a.dst[0].w && y < a.dst[0].h) {
       uint32_t q0, q1, q2, q3;
       if (2 * x + 1 < src.w && 2 * y + 1 < src.h) {
-        uint2 r0 = *(const uint2*)(src.p + (size_t)(2 * y) * src.pitch + (size_t)(2 * x) * 4);
-        uint2 r1 = *(const uint2*)(src.p + (size_t)(2 * y + 1) * src.pitch + (size_t)(2 * x) * 4);
+        uint2 r0 = *(const uint2*)(src.p + toff(src, (2 * x), (2 * y), 4));
+        uint2 r1 = *(const uint2*)(src.p + toff(src, (2 * x), (2 * y + 1), 4));
         q0 = r0.x & 0xFFFFFFu; q1 = r0.y & 0xFFFFFFu; q2 = r1.x & 0xFFFFFFu; q3 = r1.y & 0xFFFFFFu;
       } else {  // parent extent 1: texelFetch out of bounds -> 0
         auto ld = [&](int lx, int ly) -> uint32_t {
-          return (lx < src.w && ly < src.h) ? (*(const uint32_t*)(src.p + (size_t)ly * src.pitch + (size_t)lx * 4) & 0xFFFFFFu) : 0u;
+          return (lx < src.w && ly < src.h) ? (*(const uint32_t*)(src.p + toff(src, lx, ly, 4)) & 0xFFFFFFu) : 0u;
         };
         q0 = ld(2 * x, 2 * y); q1 = ld(2 * x + 1, 2 * y); q2 = ld(2 * x, 2 * y + 1); q3 = ld(2 * x + 1, 2 * y + 1);
       }

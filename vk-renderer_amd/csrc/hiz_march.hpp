@@ -41,7 +41,7 @@ VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, i
     const int tx = f2i(mip_pos.x), ty = f2i(mip_pos.y);
     if (tx >= 0 && ty >= 0 && tx < (int)(m.w & 0xFFFFu) && ty < (int)(m.w >> 16)) {
       typedef const __attribute__((address_space(1))) uint32_t* gptr_t;  // a global, not flat, address
-      const uint64_t addr = (((uint64_t)m.y << 32) | m.x) + (uint64_t)ty * m.z + (uint64_t)tx * 4u;
+      const uint64_t addr = (((uint64_t)m.y << 32) | m.x) + (uint64_t)(__umul24((uint32_t)ty, m.z) + (uint32_t)tx * 4u);  // 32-bit offset, see toff()
       surface_z = d24_to_float(*(gptr_t)addr);
     }
   }

@@ -53,10 +53,16 @@ struct TraceArgs {
 // rays of one 8x8 tile finish anywhere between 16 and 80 steps (mean 30, per-wave maximum mean 59
 // at 4K: half the lanes idle without compaction).  Every ray executes exactly the shader's step
 // sequence; only which lane executes it changes.
-#define TRACE_THREADS 256
-#define TRACE_ROUND 16
+#ifndef TRACE_WY
+#define TRACE_WY 1          // rows of 8x8 tiles per block: the block covers 32 x (8 TRACE_WY) pixels with 4 TRACE_WY waves
+#endif
+#ifndef TRACE_ROUND
+#define TRACE_ROUND 16      // steps per compacted round
+#endif
+#define TRACE_PIN_ROUND 16  // round 0: the pinned steps, run by every ray
+#define TRACE_THREADS (256 * TRACE_WY)
 __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
-  const i2 blk = xcd_block<4, 8>();  // chunks of 128 x 64 output pixels
+  const i2 blk = xcd_block<4, 8 / TRACE_WY>();  // chunks of 128 x 64 output pixels
   __shared__ uint4 s_mip[16];
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   __shared__ float s_rc[17][TRACE_THREADS];     // RayConst (15) + t + h of unfinished rays
@@ -68,10 +74,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   if (tid < 16) s_mip[tid] = mip_descriptor(a.depth.mip[tid < a.depth.count ? tid : 0]);
   if (tid < 2) s_count[tid] = 0;
   __syncthreads();
-  // 256 threads = 4 waves; wave w owns the 8x8 tile (blk.x*4 + w, blk.y)
+  // wave w owns the 8x8 tile (blk.x*4 + w % 4, blk.y*TRACE_WY + w / 4)
   const int wave = tid >> 6, lane = tid & 63;
-  const int lx = (blk.x * 4 + wave) * 8 + (lane & 7);
-  const int ly = blk.y * 8 + (lane >> 3);
+  const int lx = (blk.x * 4 + (wave & 3)) * 8 + (lane & 7);
+  const int ly = (blk.y * TRACE_WY + (wave >> 2)) * 8 + (lane >> 3);
   const bool active = lx < a.out_ray.w && ly < a.out_ray.h;
   const int gx = a.out_ray.ox + lx, gy = a.out_ray.oy + ly;
   const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
     // round 0: the first 15 steps never leave mip 0, so every ray runs exactly 16 steps here
     running = true;
 #pragma unroll 1
-    for (int k = 0; k < TRACE_ROUND && running; k++) running = march_step<true, 15>(env, rc, st, 80);
+    for (int k = 0; k < TRACE_PIN_ROUND && running; k++) running = march_step<true, 15>(env, rc, st, 80);
   }
   // park the unfinished rays in LDS
   if (running) {
@@ -668,7 +674,7 @@ extern "C" int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const
   a.max_roughness = push->max_roughness;
   a.horizon_d2 = horizon_threshold_d2();
   dim3 block(TRACE_THREADS, 1);
-  dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 7) / 8);
+  dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 8 * TRACE_WY - 1) / (8 * TRACE_WY));
   hipLaunchKernelGGL(k_sssr_trace, grid, block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_trace");
 }

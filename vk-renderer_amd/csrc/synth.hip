@@ -147,9 +147,24 @@ __global__ __launch_bounds__(256) void k_selftest_division(uint32_t* counters, f
   if (i < 256u && unorm8_to_float(i) != (float)i / 255.0f) atomicAdd(&counters[4], 1u);
 }
 
+// [0] div_normal(g + 0.5, size) vs the IEEE quotient for every pixel centre g < size of every extent size <= max_size:
+// the screen_uv of a pass that computes it with div_normal
+__global__ __launch_bounds__(256) void k_selftest_pixel_uv(uint32_t* counter, uint32_t max_size) {
+  const uint32_t size = blockIdx.y + 1u, g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (size > max_size || g >= size) return;
+  const float a = (float)g + 0.5f, b = (float)size;
+  if (div_normal(a, b) != a / b) atomicAdd(counter, 1u);
+}
+
 }  // namespace vkr
 
 using namespace vkr;
+
+extern "C" int vkr_selftest_pixel_uv(uint32_t* device_counter, uint32_t max_size, void* stream) {
+  if (!device_counter || max_size == 0 || max_size > 65535u) { set_error("selftest_pixel_uv: bad arguments"); return VKR_ERR_NULL; }
+  hipLaunchKernelGGL(k_selftest_pixel_uv, dim3((max_size + 255u) / 256u, max_size), dim3(256), 0, (hipStream_t)stream, device_counter, max_size);
+  return launch_status("selftest_pixel_uv");
+}
 
 extern "C" int vkr_selftest_division(uint32_t* device_counters5, float znear, float zfar, void* stream) {
   if (!device_counters5) { set_error("selftest_division: NULL counters"); return VKR_ERR_NULL; }

@@ -3,6 +3,7 @@
 // Reference: src/taa.cpp:19-63 + shaders/taa/resolve.comp:20-77.  Full resolution;
 // the largest byte mover of the chain: 32 B per pixel (history 8 + prev_depth 4 + depth 4 +
 // velocity 4 + colour 4 read, target 8 written).  Roofline: HBM.
+#include <cstdlib>
 #include "vkr_host.hpp"
 
 namespace vkr {
@@ -11,10 +12,45 @@ struct TaaArgs {
   Tex history, hist_depth, cur_depth, velocity, color, out;
   Mat4 inverse_camera, prev_inverse_camera;
   Proj pr;
+  float still_d2;  // smallest d2 with sqrtf(d2) >= 0.005f: |velocity| < 0.005 <=> dot(velocity, velocity) < still_d2
 };
+
+// smallest float x with sqrtf(x) >= limit (correctly rounded sqrt is monotone)
+inline float sqrt_threshold(float limit) {
+  float x = limit * limit;
+  while (sqrtf(x) >= limit) x = nextafterf(x, 0.0f);
+  while (sqrtf(x) < limit) x = nextafterf(x, 1.0f);
+  return x;
+}
 
 VKR_DEV f3 rgb(f4 v) { return mk3(v.x, v.y, v.z); }
 
+// Byte offsets (4-byte texels) and weights of the bilinear footprint of texture(t, uv): what sample<F>() computes
+// before it loads.  Images that share one window geometry and pitch share the whole record.
+struct Footprint { uint32_t o00, o10, o01, o11; float fx, fy; };
+VKR_DEV Footprint footprint4(const Tex& t, f2 uv) {
+  Footprint f;
+  const float x = cfma(uv.x, (float)t.fw, -0.5f), y = cfma(uv.y, (float)t.fh, -0.5f);
+  const float x0f = floorf(x), y0f = floorf(y);
+  f.fx = x - x0f; f.fy = y - y0f;
+  const int x0 = f2i(x0f) - t.ox, y0 = f2i(y0f) - t.oy;
+  const uint32_t xa = (uint32_t)iclamp(x0, 0, t.w - 1) * 4u, xb = (uint32_t)iclamp(x0 + 1, 0, t.w - 1) * 4u;
+  const uint32_t ra = __umul24((uint32_t)iclamp(y0, 0, t.h - 1), (uint32_t)t.pitch);
+  const uint32_t rb = __umul24((uint32_t)iclamp(y0 + 1, 0, t.h - 1), (uint32_t)t.pitch);
+  f.o00 = ra + xa; f.o10 = ra + xb; f.o01 = rb + xa; f.o11 = rb + xb;
+  return f;
+}
+VKR_DEV BilinearTaps taps_at(const Tex& t, const Footprint& f) {
+  BilinearTaps b;
+  b.t00 = *(const uint32_t*)(t.p + f.o00); b.t10 = *(const uint32_t*)(t.p + f.o10);
+  b.t01 = *(const uint32_t*)(t.p + f.o01); b.t11 = *(const uint32_t*)(t.p + f.o11);
+  b.fx = f.fx; b.fy = f.fy;
+  return b;
+}
+
+// SHARED: colour, velocity and current depth have one window geometry and pitch (the launcher checks), so the three
+// samples at screen_uv share one footprint.
+template <bool SHARED>
 __global__ __launch_bounds__(256) void k_taa_resolve(TaaArgs a) {
   const i2 blk = xcd_block<2, 16>();  // chunks of 128 x 64 output pixels
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
@@ -24,44 +60,74 @@ __global__ __launch_bounds__(256) void k_taa_resolve(TaaArgs a) {
   const int ly = blk.y * blockDim.y + threadIdx.y;
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
-  const f2 screen_uv = mk2(((float)gx + 0.5f) / (float)a.out.fw, ((float)gy + 0.5f) / (float)a.out.fh);
-  const f3 current_color = sample_srgb_rgb(a.color, screen_uv, s_lut);
-  const f2 velocity = sample<FmtRG16F>(a.velocity, screen_uv);
-  const float delta_len = length(velocity);
+  // (g + 0.5) / size: both operands and the quotient are far inside the normal range
+  const f2 screen_uv = mk2(div_normal((float)gx + 0.5f, (float)a.out.fw), div_normal((float)gy + 0.5f, (float)a.out.fh));
+  const Footprint fc = footprint4(a.color, screen_uv);
+  const Footprint fv = SHARED ? fc : footprint4(a.velocity, screen_uv);
+  const BilinearTaps tc = taps_at(a.color, fc), tv = taps_at(a.velocity, fv);
+  const f2 velocity = taps_resolve<FmtRG16F>(tv);
   const f2 prev_uv = screen_uv + velocity;
-  f3 out_color = current_color;
-  if (prev_uv.x >= 0.0f && prev_uv.y >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y <= 1.0f) {
-    // texture(prev_uv) and its four textureOffset neighbours (resolve.comp:41-45) share weights and
-    // overlap in texels: the 12 distinct texels of the plus-shaped footprint are loaded and decoded
-    // once; each of the five results is then the same lerp-of-lerps the sampler would compute.
+  const bool inside = prev_uv.x >= 0.0f && prev_uv.y >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y <= 1.0f;
+  // texture(prev_uv) and its four textureOffset neighbours (resolve.comp:41-45) share weights and
+  // overlap in texels: the 12 distinct texels of the plus-shaped footprint are loaded and decoded
+  // once; each of the five results is then the same lerp-of-lerps the sampler would compute.
+  float fx = 0.0f, fy = 0.0f;
+  uint2 h[12];
+  if (inside) {
     const float hx = cfma(prev_uv.x, (float)a.history.fw, -0.5f), hy = cfma(prev_uv.y, (float)a.history.fh, -0.5f);
     const float hx0f = floorf(hx), hy0f = floorf(hy);
-    const float fx = hx - hx0f, fy = hy - hy0f;
-    const int hx0 = f2i(hx0f), hy0 = f2i(hy0f);
-    auto tex = [&](int dx, int dy) { return rgb(fetch_clamped<FmtRGBA16F>(a.history, hx0 + dx, hy0 + dy)); };
-    const f3 t_m1_0 = tex(-1, 0), t_m1_1 = tex(-1, 1);
-    const f3 t_0_m1 = tex(0, -1), t_0_0 = tex(0, 0), t_0_1 = tex(0, 1), t_0_2 = tex(0, 2);
-    const f3 t_1_m1 = tex(1, -1), t_1_0 = tex(1, 0), t_1_1 = tex(1, 1), t_1_2 = tex(1, 2);
-    const f3 t_2_0 = tex(2, 0), t_2_1 = tex(2, 1);
-    auto bil = [&](f3 t00, f3 t10, f3 t01, f3 t11) { return mix3(mix3(t00, t10, fx), mix3(t01, t11, fx), fy); };
-    f3 history = bil(t_0_0, t_1_0, t_0_1, t_1_1);
-    const f3 color0 = bil(t_1_0, t_2_0, t_1_1, t_2_1);    // offset (+1, 0)
-    const f3 color1 = bil(t_0_1, t_1_1, t_0_2, t_1_2);    // offset ( 0,+1)
-    const f3 color2 = bil(t_m1_0, t_0_0, t_m1_1, t_0_1);  // offset (-1, 0)
-    const f3 color3 = bil(t_0_m1, t_1_m1, t_0_0, t_1_0);  // offset ( 0,-1)
-    const f3 color_min = min3(color0, min3(color1, min3(color2, color3)));
-    const f3 color_max = max3(color0, max3(color1, max3(color2, color3)));
-    history = min3(max3(history, color_min), color_max);
-    const f3 blended = mix3(history, current_color, 0.1f);
-    const f3 vc = reconstruct_view_vec(screen_uv, sample<FmtD24>(a.cur_depth, screen_uv), a.pr);
-    const f3 v_world_cur = xyz(mul(a.inverse_camera, mk4(vc.x, vc.y, vc.z, 1.0f)));
-    const f3 vp = reconstruct_view_vec(prev_uv, sample<FmtD24>(a.hist_depth, prev_uv), a.pr);
-    const f3 v_world_prev = xyz(mul(a.prev_inverse_camera, mk4(vp.x, vp.y, vp.z, 1.0f)));
-    const f3 v_camera = xyz(mul(a.inverse_camera, mk4(0, 0, 0, 1)));
-    const float error = length(v_world_cur - v_world_prev);
-    const float pixel_dist = length(v_world_cur - v_camera);
-    const bool reprojected = (delta_len < 0.005f) || (error < vclamp((0.1f * pixel_dist) * delta_len, 0.01f, 0.2f));
-    if (reprojected) out_color = blended;
+    fx = hx - hx0f; fy = hy - hy0f;
+    const int hx0 = f2i(hx0f) - a.history.ox, hy0 = f2i(hy0f) - a.history.oy;
+    uint32_t xo[4], ro[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      xo[i] = (uint32_t)iclamp(hx0 + i - 1, 0, a.history.w - 1) * 8u;
+      ro[i] = __umul24((uint32_t)iclamp(hy0 + i - 1, 0, a.history.h - 1), (uint32_t)a.history.pitch);
+    }
+    auto ld = [&](int ix, int iy) { return *(const uint2*)(a.history.p + (ro[iy + 1] + xo[ix + 1])); };
+    h[0] = ld(-1, 0); h[1] = ld(-1, 1);
+    h[2] = ld(0, -1); h[3] = ld(0, 0); h[4] = ld(0, 1); h[5] = ld(0, 2);
+    h[6] = ld(1, -1); h[7] = ld(1, 0); h[8] = ld(1, 1); h[9] = ld(1, 2);
+    h[10] = ld(2, 0); h[11] = ld(2, 1);
+  }
+  const f3 current_color = mix3(mix3(srgb_rgb(tc.t00, s_lut), srgb_rgb(tc.t10, s_lut), tc.fx),
+                                mix3(srgb_rgb(tc.t01, s_lut), srgb_rgb(tc.t11, s_lut), tc.fx), tc.fy);
+  f3 out_color = current_color;
+  if (inside) {
+    // delta_len < 0.005 decided on the squared length (correctly rounded sqrt is monotone); the length itself is only
+    // needed on the other side of the test
+    const float d2 = dot(velocity, velocity);
+    bool reprojected = d2 < a.still_d2;
+    if (!reprojected) {
+      const float delta_len = sqrtf(d2);
+      const Footprint fd = SHARED ? fc : footprint4(a.cur_depth, screen_uv);
+      const f3 vc = reconstruct_view_vec(screen_uv, taps_resolve<FmtD24>(taps_at(a.cur_depth, fd)), a.pr);
+      const f3 v_world_cur = xyz(mul(a.inverse_camera, mk4(vc.x, vc.y, vc.z, 1.0f)));
+      const f3 vp = reconstruct_view_vec(prev_uv, sample<FmtD24>(a.hist_depth, prev_uv), a.pr);
+      const f3 v_world_prev = xyz(mul(a.prev_inverse_camera, mk4(vp.x, vp.y, vp.z, 1.0f)));
+      const f3 v_camera = xyz(mul(a.inverse_camera, mk4(0, 0, 0, 1)));
+      const float error = length(v_world_cur - v_world_prev);
+      const float pixel_dist = length(v_world_cur - v_camera);
+      reprojected = error < vclamp((0.1f * pixel_dist) * delta_len, 0.01f, 0.2f);
+    }
+    if (reprojected) {
+      auto tex = [&](int i) { return mk3(half_bits_to_float(h[i].x & 0xFFFFu), half_bits_to_float(h[i].x >> 16), half_bits_to_float(h[i].y & 0xFFFFu)); };
+      const f3 t_m1_0 = tex(0), t_m1_1 = tex(1);
+      const f3 t_0_m1 = tex(2), t_0_0 = tex(3), t_0_1 = tex(4), t_0_2 = tex(5);
+      const f3 t_1_m1 = tex(6), t_1_0 = tex(7), t_1_1 = tex(8), t_1_2 = tex(9);
+      const f3 t_2_0 = tex(10), t_2_1 = tex(11);
+      // the horizontal lerps of rows 0 and 1 between columns 0 and 1 serve three of the five samples
+      const f3 r_m1 = mix3(t_0_m1, t_1_m1, fx), r_0 = mix3(t_0_0, t_1_0, fx), r_1 = mix3(t_0_1, t_1_1, fx), r_2 = mix3(t_0_2, t_1_2, fx);
+      f3 history = mix3(r_0, r_1, fy);
+      const f3 color0 = mix3(mix3(t_1_0, t_2_0, fx), mix3(t_1_1, t_2_1, fx), fy);    // offset (+1, 0)
+      const f3 color1 = mix3(r_1, r_2, fy);                                           // offset ( 0,+1)
+      const f3 color2 = mix3(mix3(t_m1_0, t_0_0, fx), mix3(t_m1_1, t_0_1, fx), fy);  // offset (-1, 0)
+      const f3 color3 = mix3(r_m1, r_0, fy);                                          // offset ( 0,-1)
+      const f3 color_min = min3(color0, min3(color1, min3(color2, color3)));
+      const f3 color_max = max3(color0, max3(color1, max3(color2, color3)));
+      history = min3(max3(history, color_min), color_max);
+      out_color = mix3(history, current_color, 0.1f);
+    }
   }
   uint2 o;
   o.x = float_to_half_bits(out_color.x) | (float_to_half_bits(out_color.y) << 16);
@@ -90,7 +156,11 @@ extern "C" int vkr_taa_resolve(const vkr_img* history_color, const vkr_img* hist
   a.pr.aspect = params->fovy_aspect_znear_zfar[1];
   a.pr.znear = params->fovy_aspect_znear_zfar[2];
   a.pr.zfar = params->fovy_aspect_znear_zfar[3];
+  a.still_d2 = sqrt_threshold(0.005f);
+  const bool shared = same_window(a.color, a.velocity) && same_window(a.color, a.cur_depth) && a.color.pitch == a.velocity.pitch &&
+                      a.color.pitch == a.cur_depth.pitch && !getenv("VKR_TAA_GENERIC");
   dim3 block(64, 4);
-  hipLaunchKernelGGL(k_taa_resolve, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  if (shared) hipLaunchKernelGGL(k_taa_resolve<true>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_taa_resolve<false>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   return launch_status("taa_resolve");
 }

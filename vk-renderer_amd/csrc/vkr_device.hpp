@@ -198,6 +198,10 @@ struct Tex {
   int fw, fh;
   int ox, oy;
 };
+// Byte offset of a texel inside its window: 32-bit (make_tex rejects windows of 4 GiB and more), so that a load from a
+// kernel-argument image is `global_load v, v_offset, s[base]` — one v_mad_u32_u24-class instruction per address instead of
+// a 64-bit multiply-add pair.
+VKR_DEV uint32_t toff(const Tex& t, int lx, int ly, int bpp) { return __umul24((uint32_t)ly, (uint32_t)t.pitch) + (uint32_t)lx * (uint32_t)bpp; }
 struct Pyramid {
   Tex mip[16];
   int count;
@@ -205,37 +209,37 @@ struct Pyramid {
 
 struct FmtD24 { typedef float T; static VKR_DEV T zero() { return 0.0f; }
   static VKR_DEV T decode(uint32_t v) { return d24_to_float(v); }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4)); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + toff(t, lx, ly, 4))); }
   static VKR_DEV T lerp(T a, T b, float f) { return mixf(a, b, f); } };
 struct FmtR32F { typedef float T; static VKR_DEV T zero() { return 0.0f; }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { return *(const float*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return *(const float*)(t.p + toff(t, lx, ly, 4)); }
   static VKR_DEV T lerp(T a, T b, float f) { return mixf(a, b, f); } };
 struct FmtR16F { typedef float T; static VKR_DEV T zero() { return 0.0f; }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { return half_bits_to_float(*(const uint16_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 2)); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return half_bits_to_float(*(const uint16_t*)(t.p + toff(t, lx, ly, 2))); }
   static VKR_DEV T lerp(T a, T b, float f) { return mixf(a, b, f); } };
 struct FmtRG16U { typedef f2 T; static VKR_DEV T zero() { return mk2(0, 0); }
   static VKR_DEV T decode(uint32_t v) { return mk2(unorm16_to_float(v & 0xFFFFu), unorm16_to_float(v >> 16)); }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4)); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + toff(t, lx, ly, 4))); }
   static VKR_DEV T lerp(T a, T b, float f) { return mix2(a, b, f); } };
 struct FmtRG16F { typedef f2 T; static VKR_DEV T zero() { return mk2(0, 0); }
   static VKR_DEV T decode(uint32_t v) { return mk2(half_bits_to_float(v & 0xFFFFu), half_bits_to_float(v >> 16)); }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4)); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + toff(t, lx, ly, 4))); }
   static VKR_DEV T lerp(T a, T b, float f) { return mix2(a, b, f); } };
 // rgb of an RGBA8_SRGB texel (alpha is never consumed on this path)
 struct FmtSRGB8 { typedef f3 T; static VKR_DEV T zero() { return mk3(0, 0, 0); }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint32_t v = *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint32_t v = *(const uint32_t*)(t.p + toff(t, lx, ly, 4));
     return mk3(srgb8_to_float(v & 0xFFu), srgb8_to_float((v >> 8) & 0xFFu), srgb8_to_float((v >> 16) & 0xFFu)); }
   static VKR_DEV T lerp(T a, T b, float f) { return mix3(a, b, f); } };
 struct FmtRGBA8 { typedef f3 T; static VKR_DEV T zero() { return mk3(0, 0, 0); }
   static VKR_DEV T decode(uint32_t v) { return mk3(unorm8_to_float(v & 0xFFu), unorm8_to_float((v >> 8) & 0xFFu), unorm8_to_float((v >> 16) & 0xFFu)); }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4)); }
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { return decode(*(const uint32_t*)(t.p + toff(t, lx, ly, 4))); }
   static VKR_DEV T lerp(T a, T b, float f) { return mix3(a, b, f); } };
 struct FmtRGBA16U { typedef f4 T; static VKR_DEV T zero() { return mk4(0, 0, 0, 0); }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint2 v = *(const uint2*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 8);
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint2 v = *(const uint2*)(t.p + toff(t, lx, ly, 8));
     return mk4(unorm16_to_float(v.x & 0xFFFFu), unorm16_to_float(v.x >> 16), unorm16_to_float(v.y & 0xFFFFu), unorm16_to_float(v.y >> 16)); }
   static VKR_DEV T lerp(T a, T b, float f) { return mix4(a, b, f); } };
 struct FmtRGBA16F { typedef f4 T; static VKR_DEV T zero() { return mk4(0, 0, 0, 0); }
-  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint2 v = *(const uint2*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 8);
+  static VKR_DEV T load(const Tex& t, int lx, int ly) { uint2 v = *(const uint2*)(t.p + toff(t, lx, ly, 8));
     return mk4(half_bits_to_float(v.x & 0xFFFFu), half_bits_to_float(v.x >> 16), half_bits_to_float(v.y & 0xFFFFu), half_bits_to_float(v.y >> 16)); }
   static VKR_DEV T lerp(T a, T b, float f) { return mix4(a, b, f); } };
 
@@ -287,7 +291,7 @@ VKR_DEV uint32_t float_to_srgb8_lds(float x, const float* thresh) {
 }
 VKR_DEV uint32_t load_u32_clamped(const Tex& t, int gx, int gy) {
   int lx = iclamp(gx - t.ox, 0, t.w - 1), ly = iclamp(gy - t.oy, 0, t.h - 1);
-  return *(const uint32_t*)(t.p + (size_t)ly * t.pitch + (size_t)lx * 4);
+  return *(const uint32_t*)(t.p + toff(t, lx, ly, 4));
 }
 struct BilinearTaps { uint32_t t00, t10, t01, t11; float fx, fy; };
 // the four raw texels + weights of texture(tex, uv) for any 4-byte format
@@ -326,7 +330,7 @@ VKR_DEV f3 sample_srgb_rgb(const Tex& t, f2 uv, const float* lut) {
   return mix3(mix3(srgb_rgb(b.t00, lut), srgb_rgb(b.t10, lut), b.fx), mix3(srgb_rgb(b.t01, lut), srgb_rgb(b.t11, lut), b.fx), b.fy);
 }
 
-template <class T> VKR_DEV T* texel_ptr(const Tex& t, int lx, int ly) { return (T*)(const_cast<uint8_t*>(t.p) + (size_t)ly * t.pitch) + lx; }
+template <class T> VKR_DEV T* texel_ptr(const Tex& t, int lx, int ly) { return (T*)(const_cast<uint8_t*>(t.p) + toff(t, lx, ly, (int)sizeof(T))); }
 
 // ---- shared shader helpers (gbuffer_encode.glsl / brdf.glsl), literal operation order -------
 struct Proj { float tg, aspect, znear, zfar; };  // tg = tanf(fovy/2) evaluated on the host

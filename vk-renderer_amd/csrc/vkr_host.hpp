@@ -35,6 +35,11 @@ inline int make_tex(const vkr_img* d, int mip, uint32_t want_format, const char*
     set_error("%s: bad layout (w %d pitch %u)", what, w, d->pitch_bytes[mip]);
     return VKR_ERR_LAYOUT;
   }
+  // texel offsets are 32-bit, rows x pitch a 24-bit multiply (toff() in vkr_device.hpp)
+  if (d->pitch_bytes[mip] >= (1u << 24) || (uint64_t)d->pitch_bytes[mip] * (uint64_t)h >= (1ull << 32)) {
+    set_error("%s: window too large for 32-bit texel offsets (pitch %u x %d rows)", what, d->pitch_bytes[mip], h);
+    return VKR_ERR_LAYOUT;
+  }
   int fw = mip_dim(d->full_width, mip), fh = mip_dim(d->full_height, mip);
   int ox = d->origin_x >> mip, oy = d->origin_y >> mip;
   if (d->origin_x < 0 || d->origin_y < 0 || ox + w > fw || oy + h > fh) {
