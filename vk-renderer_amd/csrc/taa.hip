@@ -78,17 +78,31 @@ __global__ __launch_bounds__(256) void k_taa_resolve(TaaArgs a) {
     const float hx0f = floorf(hx), hy0f = floorf(hy);
     fx = hx - hx0f; fy = hy - hy0f;
     const int hx0 = f2i(hx0f) - a.history.ox, hy0 = f2i(hy0f) - a.history.oy;
-    uint32_t xo[4], ro[4];
+    if (hx0 >= 1 && hy0 >= 1 && hx0 + 2 < a.history.w && hy0 + 2 < a.history.h) {
+      // interior footprint: pairs of horizontally adjacent texels as one 16-byte load each (6 loads instead of 12: measured
+      // 0.094 -> 0.085 ms; pairing the 4-byte taps of the other footprints the same way gains nothing more)
+      const uint8_t* p0 = a.history.p + (__umul24((uint32_t)(hy0 - 1), (uint32_t)a.history.pitch) + (uint32_t)(hx0 - 1) * 8u);
+      const uint32_t pitch = (uint32_t)a.history.pitch;
+      auto ld2 = [&](int ix, int iy) { return load_u32x4(p0 + ((uint32_t)(iy + 1) * pitch + (uint32_t)(ix + 1) * 8u)); };
+      const U32x4 a_m1 = ld2(0, -1), a_2 = ld2(0, 2);                 // rows -1 and 2: columns 0, 1
+      const U32x4 l_0 = ld2(-1, 0), r_0 = ld2(1, 0), l_1 = ld2(-1, 1), r_1 = ld2(1, 1);  // rows 0 and 1: columns -1, 0 and 1, 2
+      h[0] = make_uint2(l_0.x, l_0.y); h[1] = make_uint2(l_1.x, l_1.y);
+      h[2] = make_uint2(a_m1.x, a_m1.y); h[3] = make_uint2(l_0.z, l_0.w); h[4] = make_uint2(l_1.z, l_1.w); h[5] = make_uint2(a_2.x, a_2.y);
+      h[6] = make_uint2(a_m1.z, a_m1.w); h[7] = make_uint2(r_0.x, r_0.y); h[8] = make_uint2(r_1.x, r_1.y); h[9] = make_uint2(a_2.z, a_2.w);
+      h[10] = make_uint2(r_0.z, r_0.w); h[11] = make_uint2(r_1.z, r_1.w);
+    } else {
+      uint32_t xo[4], ro[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      xo[i] = (uint32_t)iclamp(hx0 + i - 1, 0, a.history.w - 1) * 8u;
-      ro[i] = __umul24((uint32_t)iclamp(hy0 + i - 1, 0, a.history.h - 1), (uint32_t)a.history.pitch);
+      for (int i = 0; i < 4; i++) {
+        xo[i] = (uint32_t)iclamp(hx0 + i - 1, 0, a.history.w - 1) * 8u;
+        ro[i] = __umul24((uint32_t)iclamp(hy0 + i - 1, 0, a.history.h - 1), (uint32_t)a.history.pitch);
+      }
+      auto ld = [&](int ix, int iy) { return *(const uint2*)(a.history.p + (ro[iy + 1] + xo[ix + 1])); };
+      h[0] = ld(-1, 0); h[1] = ld(-1, 1);
+      h[2] = ld(0, -1); h[3] = ld(0, 0); h[4] = ld(0, 1); h[5] = ld(0, 2);
+      h[6] = ld(1, -1); h[7] = ld(1, 0); h[8] = ld(1, 1); h[9] = ld(1, 2);
+      h[10] = ld(2, 0); h[11] = ld(2, 1);
     }
-    auto ld = [&](int ix, int iy) { return *(const uint2*)(a.history.p + (ro[iy + 1] + xo[ix + 1])); };
-    h[0] = ld(-1, 0); h[1] = ld(-1, 1);
-    h[2] = ld(0, -1); h[3] = ld(0, 0); h[4] = ld(0, 1); h[5] = ld(0, 2);
-    h[6] = ld(1, -1); h[7] = ld(1, 0); h[8] = ld(1, 1); h[9] = ld(1, 2);
-    h[10] = ld(2, 0); h[11] = ld(2, 1);
   }
   const f3 current_color = mix3(mix3(srgb_rgb(tc.t00, s_lut), srgb_rgb(tc.t10, s_lut), tc.fx),
                                 mix3(srgb_rgb(tc.t01, s_lut), srgb_rgb(tc.t11, s_lut), tc.fx), tc.fy);

@@ -293,6 +293,13 @@ VKR_DEV uint32_t load_u32_clamped(const Tex& t, int gx, int gy) {
   int lx = iclamp(gx - t.ox, 0, t.w - 1), ly = iclamp(gy - t.oy, 0, t.h - 1);
   return *(const uint32_t*)(t.p + toff(t, lx, ly, 4));
 }
+// Two / four consecutive dwords from any 4-byte aligned address as ONE global load (dwordx2 / dwordx4 only need dword
+// alignment).  The texture-address unit spends the same time on a wave's load whatever its width, so kernels whose
+// loads — not their arithmetic — set the pace (TAA) fetch horizontally adjacent texels together.
+struct __attribute__((packed, aligned(4))) U32x2 { uint32_t x, y; };
+struct __attribute__((packed, aligned(4))) U32x4 { uint32_t x, y, z, w; };
+VKR_DEV U32x2 load_u32x2(const uint8_t* p) { return *(const U32x2*)p; }
+VKR_DEV U32x4 load_u32x4(const uint8_t* p) { return *(const U32x4*)p; }
 struct BilinearTaps { uint32_t t00, t10, t01, t11; float fx, fy; };
 // the four raw texels + weights of texture(tex, uv) for any 4-byte format
 VKR_DEV BilinearTaps bilinear_taps_u32(const Tex& t, f2 uv) {
