@@ -41,7 +41,8 @@ def short(name):
 
 
 def find(d, suffix):
-    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    # gpurun merges every call's files into the same local directory: take the newest, not the last by name
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True), key=os.path.getmtime)
     if not hits:
         raise SystemExit(f"no *{suffix} under {d}")
     return hits[-1]
