@@ -6,9 +6,10 @@
 //   vkr_halo_exchange  one grouped ncclSend / ncclRecv launch refreshing the halo rings of a history surface
 //
 // Both enqueue on the caller's stream and return; nothing blocks the host.  RCCL is loaded with dlopen the first
-// time a communicator is made (librccl.so.1 of the ROCm installation, private namespace), so the library has no
-// link-time dependency on it: a single-GPU process never touches RCCL, and a process that also uses
-// torch.distributed keeps torch's own copy apart from this one.
+// time a communicator is made, so the library has no link-time dependency on it and a single-GPU process never
+// touches RCCL.  dlopen resolves by soname: in a process that has already loaded a librccl.so.1 (PyTorch brings its
+// own under torch/lib) that copy is the one used; a plain C++ integrator gets the ROCm installation's.
+// VKR_RCCL_LIBRARY names a specific file instead.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
