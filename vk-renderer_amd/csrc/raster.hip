@@ -7,8 +7,8 @@
 //                     two sub-triangles), 8-bit sub-pixel snap, orientation -> ScreenTri records in scratch
 //                     in scratch; records whose bounding box exceeds 64 blocks of 8x8 pixels go to a work list
 //   k_raster_small    one wave per triangle walks the (<= 64) blocks of its bounding box, one pixel per lane
-//   k_raster_large    the listed triangles: 256 waves share the blocks of one triangle (a screen-filling quad
-//                     does not serialise on one wave)
+//   k_raster_large    the listed triangles, their bounding boxes cut into chunks of 16 blocks that are dealt to all
+//                     waves of the launch (a screen-filling quad does not serialise on a few waves)
 //                     both: fill rule on exact 64-bit edge functions of 24.8 coordinates, D24 depth, atomicMin
 //                     of (depth << 32 | ~record) — LESS_OR_EQUAL with later triangles winning ties
 //                     (gpu/pipelines.hpp:128)
@@ -83,6 +83,7 @@ struct ScreenTri {
   int x[3], y[3];  // 24.8 fixed point, |v| <= 2^28 (guard band)
   float w[3], z[3];  // clip w and z / w
   long long area2;
+  double inv_area2;  // 1.0 / (double)area2, once per triangle: every pixel's barycentrics multiply by it
   VsOut v[3];
   uint32_t alpha_tex;  // albedo texture whose filtered alpha decides the discard, 0xFFFFFFFF: no test
   bool valid;
@@ -143,12 +144,22 @@ VKR_DEV ScreenTri setup_triangle(const RasterArgs& a, const DrawDev& d, uint32_t
     tf = t.z[1]; t.z[1] = t.z[2]; t.z[2] = tf;
     t.area2 = -t.area2;
   }
+  t.inv_area2 = 1.0 / (double)t.area2;
   t.valid = true;
   return t;
 }
 
+// What coverage and depth need of a ScreenTri, copied into registers once per triangle: the rasterising waves issue
+// atomics between their reads of the record, and the compiler must otherwise assume those change it and reload.
+struct CoverTri {
+  int x[3], y[3];
+  float z[3];
+  double inv_area2;
+  VKR_DEV CoverTri() {}
+  VKR_DEV explicit CoverTri(const ScreenTri& t) : x {t.x[0], t.x[1], t.x[2]}, y {t.y[0], t.y[1], t.y[2]}, z {t.z[0], t.z[1], t.z[2]}, inv_area2 {t.inv_area2} {}
+};
 // coverage + depth of pixel (px, py); lambda: screen-space barycentrics
-VKR_DEV bool cover(const ScreenTri& t, int px, int py, float lambda[3], uint32_t* d24) {
+template <class T> VKR_DEV bool cover(const T& t, int px, int py, float lambda[3], uint32_t* d24) {
   const int X = (px << 8) + 128, Y = (py << 8) + 128;
   const long long e0 = edge_fn(t.x[1], t.y[1], t.x[2], t.y[2], X, Y);
   const long long e1 = edge_fn(t.x[2], t.y[2], t.x[0], t.y[0], X, Y);
@@ -157,7 +168,7 @@ VKR_DEV bool cover(const ScreenTri& t, int px, int py, float lambda[3], uint32_t
   if (e0 == 0 && !is_top_left(t.x[1], t.y[1], t.x[2], t.y[2])) return false;
   if (e1 == 0 && !is_top_left(t.x[2], t.y[2], t.x[0], t.y[0])) return false;
   if (e2 == 0 && !is_top_left(t.x[0], t.y[0], t.x[1], t.y[1])) return false;
-  const double inv = 1.0 / (double)t.area2;
+  const double inv = t.inv_area2;
   lambda[0] = (float)((double)e0 * inv);
   lambda[1] = (float)((double)e1 * inv);
   lambda[2] = (float)((double)e2 * inv);
@@ -169,7 +180,7 @@ VKR_DEV bool cover(const ScreenTri& t, int px, int py, float lambda[3], uint32_t
 // barycentrics at an arbitrary (possibly uncovered) pixel, for the forward differences of uv
 VKR_DEV void lambda_at(const ScreenTri& t, int px, int py, float lambda[3]) {
   const int X = (px << 8) + 128, Y = (py << 8) + 128;
-  const double inv = 1.0 / (double)t.area2;
+  const double inv = t.inv_area2;
   lambda[0] = (float)((double)edge_fn(t.x[1], t.y[1], t.x[2], t.y[2], X, Y) * inv);
   lambda[1] = (float)((double)edge_fn(t.x[2], t.y[2], t.x[0], t.y[0], X, Y) * inv);
   lambda[2] = (float)((double)edge_fn(t.x[0], t.y[0], t.x[1], t.y[1], X, Y) * inv);
@@ -181,9 +192,14 @@ VKR_DEV void perspective(const ScreenTri& t, const float lambda[3], float b[3]) 
 }
 #define BARY(F) ((b[0] * t.v[0].F + b[1] * t.v[1].F) + b[2] * t.v[2].F)
 
-VKR_DEV int wrap_repeat(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+VKR_DEV int wrap_repeat(int i, int n) {
+  if ((n & (n - 1)) == 0) return i & (n - 1);  // power-of-two extent (every mip of the usual texture): no integer division
+  const int m = i % n;
+  return m < 0 ? m + n : m;
+}
 // texture(sampler2D, uv) of an RGBA8_SRGB mip chain: REPEAT, bilinear, linear between the two mips of `lod`
-VKR_DEV f4 sample_level_repeat(const Tex& t, f2 uv) {
+// `lut`: the sRGB decode table (srgb_lut_stage), in LDS where the caller has staged it
+VKR_DEV f4 sample_level_repeat(const Tex& t, f2 uv, const float* lut) {
   const float x = cfma(uv.x, (float)t.fw, -0.5f), y = cfma(uv.y, (float)t.fh, -0.5f);
   const float x0f = floorf(x), y0f = floorf(y);
   const float fx = x - x0f, fy = y - y0f;
@@ -191,11 +207,11 @@ VKR_DEV f4 sample_level_repeat(const Tex& t, f2 uv) {
   const int x1 = wrap_repeat(x0 + 1, t.fw), y1 = wrap_repeat(y0 + 1, t.fh);
   auto dec = [&](int tx, int ty) {
     const uint32_t v = *texel_ptr<const uint32_t>(t, tx, ty);
-    return mk4(srgb8_to_float(v & 0xFFu), srgb8_to_float((v >> 8) & 0xFFu), srgb8_to_float((v >> 16) & 0xFFu), unorm8_to_float(v >> 24));
+    return mk4(lut[v & 0xFFu], lut[(v >> 8) & 0xFFu], lut[(v >> 16) & 0xFFu], unorm8_to_float(v >> 24));
   };
   return mix4(mix4(dec(x0, y0), dec(x1, y0), fx), mix4(dec(x0, y1), dec(x1, y1), fx), fy);
 }
-VKR_DEV f4 sample_trilinear(const Pyramid& p, f2 uv, f2 duvdx, f2 duvdy) {
+VKR_DEV f4 sample_trilinear(const Pyramid& p, f2 uv, f2 duvdx, f2 duvdy, const float* lut) {
   const float w = (float)p.mip[0].fw, h = (float)p.mip[0].fh;
   // rho^2 = max squared footprint; lod = log2(rho).  The level pair comes from the exponent of rho^2
   // (exact), only the blend factor from log2f (smooth) — a libm ulp must not flip the pair.
@@ -210,9 +226,9 @@ VKR_DEV f4 sample_trilinear(const Pyramid& p, f2 uv, f2 duvdx, f2 duvdy) {
   }
   if (l0 >= p.count - 1) { l0 = p.count - 1; f = 0.0f; }  // sampler LOD range [0, 10] and the chain length
   const int l1 = min(l0 + 1, p.count - 1);
-  const f4 a = sample_level_repeat(p.mip[l0], uv);
+  const f4 a = sample_level_repeat(p.mip[l0], uv, lut);
   if (f == 0.0f || l1 == l0) return a;
-  return mix4(a, sample_level_repeat(p.mip[l1], uv), f);
+  return mix4(a, sample_level_repeat(p.mip[l1], uv, lut), f);
 }
 
 
@@ -251,7 +267,7 @@ __global__ void k_raster_clear(unsigned long long* vis, size_t n) {
 }
 
 // pixel bounding box (centres that can be covered), clipped to the viewport; false when empty
-VKR_DEV bool tri_bbox(const ScreenTri& t, int width, int height, int* x0, int* y0, int* x1, int* y1) {
+template <class T> VKR_DEV bool tri_bbox(const T& t, int width, int height, int* x0, int* y0, int* x1, int* y1) {
   const int minx = min(t.x[0], min(t.x[1], t.x[2])), maxx = max(t.x[0], max(t.x[1], t.x[2]));
   const int miny = min(t.y[0], min(t.y[1], t.y[2])), maxy = max(t.y[0], max(t.y[1], t.y[2]));
   *x0 = max((minx - 128) >> 8, 0); *x1 = min((maxx - 128) >> 8, width - 1);
@@ -259,14 +275,27 @@ VKR_DEV bool tri_bbox(const ScreenTri& t, int width, int height, int* x0, int* y
   return *x0 <= *x1 && *y0 <= *y1;
 }
 #define RASTER_SMALL_BLOCKS 64  // sub-triangles whose bounding box has more 8x8 blocks go to the shared-work kernel
-#define RASTER_LARGE_GRID_X 128
-#define RASTER_LARGE_GRID_Y 64
+#define RASTER_LARGE_CHUNK 16   // blocks per work item of the shared-work kernel
+#define RASTER_LARGE_GRID 2048  // its blocks of four waves: chunk c goes to wave c mod (4 x grid)
+struct LargeEntry { uint32_t rec, first_chunk; };  // a listed sub-triangle and the index of its first chunk
 
-// one thread per triangle; large sub-triangles are appended to `large_list` (record index), counted in large_count
-__global__ __launch_bounds__(256) void k_raster_setup(RasterArgs a, uint32_t draw_index, uint32_t* large_count, uint32_t* large_list) {
-  const DrawDev d = a.draws[draw_index];
-  const uint32_t tri = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tri >= d.tri_count) return;
+// one thread per triangle; a large sub-triangle takes a list slot AND its range of chunks with one 64-bit atomicAdd on
+// *large_state (entries << 32 | chunks), so the list is sorted by first_chunk
+// the draw that owns global triangle `gtri` (draws are consecutive ranges [tri_base, tri_base + tri_count))
+VKR_DEV uint32_t draw_of(const RasterArgs& a, uint32_t gtri) {
+  uint32_t lo = 0, hi = a.draw_count - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (a.draws[mid].tri_base <= gtri) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+// (every draw of the frame in one launch: a draw of a few thousand triangles does not fill the chip on its own)
+__global__ __launch_bounds__(256) void k_raster_setup(RasterArgs a, uint32_t total_tris, unsigned long long* large_state, LargeEntry* large_list) {
+  const uint32_t gtri = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gtri >= total_tris) return;
+  const DrawDev d = a.draws[draw_of(a, gtri)];
+  const uint32_t tri = gtri - d.tri_base;
   for (int sub = 0; sub < 2; sub++) {
     int count;
     ScreenTri t = setup_triangle(a, d, tri, sub, &count);
@@ -276,55 +305,83 @@ __global__ __launch_bounds__(256) void k_raster_setup(RasterArgs a, uint32_t dra
     int x0, y0, x1, y1;
     if (t.valid && tri_bbox(t, a.width, a.height, &x0, &y0, &x1, &y1)) {
       const int nb = ((x1 >> 3) - (x0 >> 3) + 1) * ((y1 >> 3) - (y0 >> 3) + 1);
-      if (nb > RASTER_SMALL_BLOCKS) large_list[atomicAdd(large_count, 1u)] = rec;
+      if (nb > RASTER_SMALL_BLOCKS) {
+        const uint32_t chunks = (uint32_t)(nb + RASTER_LARGE_CHUNK - 1) / RASTER_LARGE_CHUNK;
+        const unsigned long long v = atomicAdd(large_state, (1ull << 32) | (unsigned long long)chunks);
+        large_list[(uint32_t)(v >> 32)] = LargeEntry {rec, (uint32_t)v};
+      }
     }
   }
 }
 
+// Largest value edge a->b takes over the pixel centres X in [X0, X1], Y in [Y0, Y1] (24.8): when it is negative no pixel of
+// the block is inside the triangle (an edge function is linear, its maximum over a box sits at a corner)
+VKR_DEV long long edge_max(int ax, int ay, int bx, int by, int X0, int Y0, int X1, int Y1) {
+  const int dx = bx - ax, dy = by - ay;
+  return (long long)dx * (long long)((dx > 0 ? Y1 : Y0) - ay) - (long long)dy * (long long)((dy > 0 ? X0 : X1) - ax);
+}
 // 8x8 pixel block `b` (row-major inside the bounding box) of record `rec`, one pixel per lane
-VKR_DEV void raster_block(const RasterArgs& a, const ScreenTri& t, uint32_t rec, int x0, int y0, int x1, int y1, int b, int lane) {
+VKR_DEV void raster_block(const RasterArgs& a, const CoverTri& t, uint32_t alpha_tex, uint32_t rec, int x0, int y0, int x1, int y1, int b, int lane) {
   const int bw = (x1 >> 3) - (x0 >> 3) + 1;
-  const int px = (((x0 >> 3) + b % bw) << 3) + (lane & 7), py = (((y0 >> 3) + b / bw) << 3) + (lane >> 3);
+  const int bx0 = ((x0 >> 3) + b % bw) << 3, by0 = ((y0 >> 3) + b / bw) << 3;
+  {  // the whole block outside one edge (half the blocks of a large triangle's bounding box): nothing to test per pixel
+    const int X0 = (bx0 << 8) + 128, Y0 = (by0 << 8) + 128, X1 = X0 + 7 * 256, Y1 = Y0 + 7 * 256;
+    if (edge_max(t.x[1], t.y[1], t.x[2], t.y[2], X0, Y0, X1, Y1) < 0 || edge_max(t.x[2], t.y[2], t.x[0], t.y[0], X0, Y0, X1, Y1) < 0 ||
+        edge_max(t.x[0], t.y[0], t.x[1], t.y[1], X0, Y0, X1, Y1) < 0)
+      return;
+  }
+  const int px = bx0 + (lane & 7), py = by0 + (lane >> 3);
   if (px < x0 || px > x1 || py < y0 || py > y1) return;
   float lambda[3];
   uint32_t d24;
   if (!cover(t, px, py, lambda, &d24)) return;
-  if (t.alpha_tex != 0xFFFFFFFFu) {  // opaque_taa.frag:32-34: out_albedo.a == 0 -> discard (no depth, no colour)
-    const FragUv f = fragment_uv(t, px, py, lambda);
-    if (sample_trilinear(a.tex[t.alpha_tex], f.uv, f.ddx, f.ddy).w == 0.0f) return;
+  if (alpha_tex != 0xFFFFFFFFu) {  // opaque_taa.frag:32-34: out_albedo.a == 0 -> discard (no depth, no colour)
+    const FragUv f = fragment_uv(a.setup[rec], px, py, lambda);
+    if (sample_trilinear(a.tex[alpha_tex], f.uv, f.ddx, f.ddy, (const float*)k_srgb_decode_bits).w == 0.0f) return;  // only alpha is used: the colour decodes fold away
   }
   atomicMin(&a.vis[(size_t)py * a.width + px], ((unsigned long long)d24 << 32) | (0xFFFFFFFFull - (unsigned long long)rec));
 }
 
 // small triangles: one wave per triangle walks its (at most 64) blocks
-__global__ __launch_bounds__(256) void k_raster_small(RasterArgs a, uint32_t draw_index) {
-  const DrawDev& d = a.draws[draw_index];
-  const uint32_t tri = blockIdx.x * 4u + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void k_raster_small(RasterArgs a, uint32_t total_tris) {
+  const uint32_t gtri = blockIdx.x * 4u + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (tri >= d.tri_count) return;
+  if (gtri >= total_tris) return;
   for (uint32_t sub = 0; sub < 2; sub++) {
-    const uint32_t rec = (d.tri_base + tri) * 2u + sub;
-    const ScreenTri& t = a.setup[rec];
-    int x0, y0, x1, y1;
-    if (!t.valid || !tri_bbox(t, a.width, a.height, &x0, &y0, &x1, &y1)) continue;
-    const int nb = ((x1 >> 3) - (x0 >> 3) + 1) * ((y1 >> 3) - (y0 >> 3) + 1);
-    if (nb > RASTER_SMALL_BLOCKS) continue;
-    for (int b = 0; b < nb; b++) raster_block(a, t, rec, x0, y0, x1, y1, b, lane);
-  }
-}
-
-// large triangles: blockIdx.x strides the list, the 4 * gridDim.y waves of a column share one triangle's blocks
-__global__ __launch_bounds__(256) void k_raster_large(RasterArgs a, const uint32_t* large_count, const uint32_t* large_list) {
-  const uint32_t n = *large_count;
-  const int lane = threadIdx.x & 63;
-  const int slice = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6), slices = (int)gridDim.y * 4;
-  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint32_t rec = large_list[i];
-    const ScreenTri& t = a.setup[rec];
+    const uint32_t rec = gtri * 2u + sub;
+    if (!a.setup[rec].valid) continue;
+    const CoverTri t(a.setup[rec]);
+    const uint32_t alpha_tex = a.setup[rec].alpha_tex;
     int x0, y0, x1, y1;
     if (!tri_bbox(t, a.width, a.height, &x0, &y0, &x1, &y1)) continue;
     const int nb = ((x1 >> 3) - (x0 >> 3) + 1) * ((y1 >> 3) - (y0 >> 3) + 1);
-    for (int b = slice; b < nb; b += slices) raster_block(a, t, rec, x0, y0, x1, y1, b, lane);
+    if (nb > RASTER_SMALL_BLOCKS) continue;
+    for (int b = 0; b < nb; b++) raster_block(a, t, alpha_tex, rec, x0, y0, x1, y1, b, lane);
+  }
+}
+
+// large triangles: their bounding boxes are cut into chunks of RASTER_LARGE_CHUNK blocks, all chunks of all listed
+// triangles are dealt round-robin to the waves of the launch (a screen-filling quad is 4096 chunks at 4K: every wave
+// of the launch works on it, none serialises)
+__global__ __launch_bounds__(256) void k_raster_large(RasterArgs a, const unsigned long long* large_state, const LargeEntry* large_list) {
+  const unsigned long long st = *large_state;
+  const uint32_t n = (uint32_t)(st >> 32), chunks = (uint32_t)st;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), waves = gridDim.x * 4u;
+  for (uint32_t c = wave; c < chunks; c += waves) {
+    uint32_t lo = 0, hi = n - 1;  // the last entry with first_chunk <= c
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      if (large_list[mid].first_chunk <= c) lo = mid; else hi = mid - 1;
+    }
+    const LargeEntry e = large_list[lo];
+    const CoverTri t(a.setup[e.rec]);
+    const uint32_t alpha_tex = a.setup[e.rec].alpha_tex;
+    int x0, y0, x1, y1;
+    if (!tri_bbox(t, a.width, a.height, &x0, &y0, &x1, &y1)) continue;
+    const int nb = ((x1 >> 3) - (x0 >> 3) + 1) * ((y1 >> 3) - (y0 >> 3) + 1);
+    const int b0 = (int)(c - e.first_chunk) * RASTER_LARGE_CHUNK, b1 = min(b0 + RASTER_LARGE_CHUNK, nb);
+    for (int b = b0; b < b1; b++) raster_block(a, t, alpha_tex, e.rec, x0, y0, x1, y1, b, lane);
   }
 }
 
@@ -334,6 +391,10 @@ struct ResolveArgs {
 };
 
 __global__ __launch_bounds__(256) void k_raster_resolve(ResolveArgs a) {
+  __shared__ float s_lut[VKR_SRGB_LUT_SIZE], s_thresh[VKR_SRGB_LUT_SIZE];
+  srgb_lut_stage(s_lut, threadIdx.y * blockDim.x + threadIdx.x, 256);
+  srgb_thresh_stage(s_thresh, threadIdx.y * blockDim.x + threadIdx.x, 256);
+  __syncthreads();
   const int lx = blockIdx.x * blockDim.x + threadIdx.x;
   const int ly = blockIdx.y * blockDim.y + threadIdx.y;
   if (lx >= a.albedo.w || ly >= a.albedo.h) return;
@@ -343,9 +404,7 @@ __global__ __launch_bounds__(256) void k_raster_resolve(ResolveArgs a) {
   if (key != ~0ull) {
     const uint32_t gid2 = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
     const uint32_t gid = gid2 >> 1;
-    uint32_t di = 0;
-    while (di + 1 < a.r.draw_count && gid >= a.r.draws[di + 1].tri_base) di++;
-    const DrawDev& d = a.r.draws[di];
+    const DrawDev& d = a.r.draws[draw_of(a.r, gid)];
     const ScreenTri& t = a.r.setup[gid2];
     float lambda[3];
     uint32_t d24 = 0;
@@ -359,13 +418,13 @@ __global__ __launch_bounds__(256) void k_raster_resolve(ResolveArgs a) {
     const f2 ddx = fu.ddx, ddy = fu.ddy;
     // opaque_taa.frag:26-46
     f4 out_albedo = mk4(0.5f, 0.5f, 0.5f, 1.0f);
-    if (d.albedo_index != 0xFFFFFFFFu) out_albedo = sample_trilinear(a.r.tex[d.albedo_index], in_uv, ddx, ddy);
+    if (d.albedo_index != 0xFFFFFFFFu) out_albedo = sample_trilinear(a.r.tex[d.albedo_index], in_uv, ddx, ddy, s_lut);
     f4 out_material = mk4(0.5f, 0.9f, 0.5f, 0.5f);
-    if (d.mr_index != 0xFFFFFFFFu) out_material = sample_trilinear(a.r.tex[d.mr_index], in_uv, ddx, ddy);
+    if (d.mr_index != 0xFFFFFFFFu) out_material = sample_trilinear(a.r.tex[d.mr_index], in_uv, ddx, ddy, s_lut);
     const f2 en = encode_normal(in_normal);
     const f2 vel = mk2(0.5f * (pb.x / pb.w - pa.x / pa.w), 0.5f * (pb.y / pb.w - pa.y / pa.w));
-    o_albedo = float_to_srgb8(out_albedo.x) | (float_to_srgb8(out_albedo.y) << 8) | (float_to_srgb8(out_albedo.z) << 16) | (float_to_unorm8(out_albedo.w) << 24);
-    o_material = float_to_srgb8(out_material.x) | (float_to_srgb8(out_material.y) << 8) | (float_to_srgb8(out_material.z) << 16) | (float_to_unorm8(out_material.w) << 24);
+    o_albedo = float_to_srgb8_lds(out_albedo.x, s_thresh) | (float_to_srgb8_lds(out_albedo.y, s_thresh) << 8) | (float_to_srgb8_lds(out_albedo.z, s_thresh) << 16) | (float_to_unorm8(out_albedo.w) << 24);
+    o_material = float_to_srgb8_lds(out_material.x, s_thresh) | (float_to_srgb8_lds(out_material.y, s_thresh) << 8) | (float_to_srgb8_lds(out_material.z, s_thresh) << 16) | (float_to_unorm8(out_material.w) << 24);
     o_normal = float_to_unorm16(en.x) | (float_to_unorm16(en.y) << 16);
     o_velocity = float_to_half_bits(vel.x) | (float_to_half_bits(vel.y) << 16);
     o_depth = (uint32_t)(key >> 32);
@@ -395,7 +454,7 @@ static uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 extern "C" uint64_t vkr_raster_scratch_bytes(uint32_t width, uint32_t height, uint32_t triangle_count) {
   return align_up((uint64_t)width * height * 8u, 256) + align_up(sizeof(DrawDev) * 1024u, 256) + align_up(sizeof(Pyramid) * RASTER_MAX_TEXTURES, 256) +
-         align_up(sizeof(ScreenTri) * 2u * (uint64_t)triangle_count, 256) + align_up(4u * (2u * (uint64_t)triangle_count + 64u), 256);
+         align_up(sizeof(ScreenTri) * 2u * (uint64_t)triangle_count, 256) + 256u + align_up(sizeof(LargeEntry) * 2u * (uint64_t)triangle_count, 256);
 }
 
 extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_const* consts, const vkr_img* albedo,
@@ -459,8 +518,8 @@ extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_
   r.draws = (const DrawDev*)((uint8_t*)scratch + align_up((uint64_t)W * H * 8u, 256));
   r.tex = (const Pyramid*)((uint8_t*)r.draws + align_up(sizeof(DrawDev) * 1024u, 256));
   r.setup = (ScreenTri*)((uint8_t*)r.tex + align_up(sizeof(Pyramid) * RASTER_MAX_TEXTURES, 256));
-  uint32_t* large_count = (uint32_t*)((uint8_t*)r.setup + align_up(sizeof(ScreenTri) * 2u * total_tris, 256));
-  uint32_t* large_list = large_count + 64;
+  unsigned long long* large_state = (unsigned long long*)((uint8_t*)r.setup + align_up(sizeof(ScreenTri) * 2u * total_tris, 256));
+  LargeEntry* large_list = (LargeEntry*)((uint8_t*)large_state + 256);
   r.draw_count = scene->draw_count;
   r.width = W; r.height = H;
   r.jitter_x = consts->jitter[0]; r.jitter_y = consts->jitter[1];
@@ -480,16 +539,15 @@ extern "C" int vkr_raster_gbuffer(const vkr_raster_scene* scene, const vkr_gbuf_
   const size_t npx = (size_t)W * H;
   hipLaunchKernelGGL(k_raster_clear, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, r.vis, npx);
   {
-    hipError_t e = hipMemsetAsync(large_count, 0, 256, stream);
+    hipError_t e = hipMemsetAsync(large_state, 0, 256, stream);
     if (e != hipSuccess) { set_error("gbuf_opaque_taa: %s", hipGetErrorString(e)); return (int)e; }
   }
-  for (uint32_t i = 0; i < scene->draw_count; i++) {
-    if (!draws[i].tri_count) continue;
-    hipLaunchKernelGGL(k_raster_setup, dim3((draws[i].tri_count + 255) / 256), dim3(256), 0, stream, r, i, large_count, large_list);
-    hipLaunchKernelGGL(k_raster_small, dim3((draws[i].tri_count + 3) / 4), dim3(256), 0, stream, r, i);
+  if (tri_base) {
+    hipLaunchKernelGGL(k_raster_setup, dim3((tri_base + 255) / 256), dim3(256), 0, stream, r, tri_base, large_state, large_list);
+    hipLaunchKernelGGL(k_raster_small, dim3((tri_base + 3) / 4), dim3(256), 0, stream, r, tri_base);
   }
   // every draw's large triangles in one launch: submission order is carried by the record index in the key
-  hipLaunchKernelGGL(k_raster_large, dim3(RASTER_LARGE_GRID_X, RASTER_LARGE_GRID_Y), dim3(256), 0, stream, r, large_count, large_list);
+  hipLaunchKernelGGL(k_raster_large, dim3(RASTER_LARGE_GRID), dim3(256), 0, stream, r, large_state, large_list);
   ra.r = r;
   dim3 block(64, 4);
   hipLaunchKernelGGL(k_raster_resolve, grid2d(ra.albedo.w, ra.albedo.h, block), block, 0, stream, ra);
