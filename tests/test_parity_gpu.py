@@ -212,6 +212,15 @@ def test_defered_shading(size, oracle_lib):
         ref.shading(show_ao=show_ao)
         gpu.shading(show_ao=show_ao)
         _compare(ref, gpu, ("color_out",), budget=1e-4)
+    # the instantiation without shared footprints / paired loads (windows that differ in geometry) gives the same image
+    import os
+    os.environ["VKR_SHADING_GENERIC"] = "1"
+    try:
+        gpu.shading(show_ao=0)
+        ref.shading(show_ao=0)
+        _compare(ref, gpu, ("color_out",), budget=1e-4)
+    finally:
+        del os.environ["VKR_SHADING_GENERIC"]
     # TAA then resolves the shaded colour (main.cpp:390-391)
     ref.shading()
     gpu.shading()

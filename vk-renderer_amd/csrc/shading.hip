@@ -4,6 +4,7 @@
 // src/advanced_ssr.cpp:116-136, shaders/advanced_ssr/preintegrate_ssr.comp.
 // Full resolution, HBM-bound in the compulsory model: 23 B per pixel (albedo 4 + normal 4 + material 4
 // + depth0 4 + depth1 1 + ao 1 + reflections 1 read, colour 4 written).
+#include <cstdlib>
 #include "vkr_host.hpp"
 
 namespace vkr {
@@ -72,6 +73,11 @@ VKR_DEV float distribution_ggx(f3 N, f3 H, float alpha) {
 
 // shader.frag:41-130.  The 2x2 nearest-depth pick (sample_ocllusion_ssr) compares exactly computed
 // bilinear depths; the shading terms after it are smooth and written to an 8-bit sRGB target.
+// FAST (the launcher checks): normal, albedo, material and depth share one window geometry and pitch, and every sampled
+// image is at least two texels wide — the four full-resolution samples then share one footprint record, the material
+// texels are fetched once for both channels, and every bilinear row is one 8-byte load: 19 loads per pixel instead of
+// 41 (the pass is bound by the texture-address unit, which spends the same 16 cycles on a wave's load whatever its width).
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_defered_shading(ShadingArgs a) {
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   __shared__ float s_thresh[VKR_SRGB_LUT_SIZE];
@@ -86,11 +92,23 @@ __global__ __launch_bounds__(256) void k_defered_shading(ShadingArgs a) {
   const f2 screen_uv = mk2(((float)gx + 0.5f) / (float)a.out.fw, ((float)gy + 0.5f) / (float)a.out.fh);
   // Exact: the depths that decide the 2x2 pick.  Everything after the pick is shading arithmetic
   // written to an 8-bit sRGB target: hardware rsq / rcp.
-  const f3 N = decode_normal_fast(sample<FmtRG16U>(a.normal, screen_uv));
-  const f3 albedo = sample_srgb_rgb(a.albedo, screen_uv, s_lut);
-  const float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
-  const float metallic = mixf(0.1f, 1.0f, sample_srgb_channel(a.material, screen_uv, 2, s_lut));
-  const float depth = sample<FmtD24>(a.depth0, screen_uv);
+  f3 N, albedo;
+  float roughness, metallic, depth;
+  if (FAST) {
+    const PairFootprint fp = pair_footprint(a.normal, screen_uv);
+    const BilinearTaps tn = pair_taps(a.normal, fp), ta = pair_taps(a.albedo, fp), tm = pair_taps(a.material, fp), td = pair_taps(a.depth0, fp);
+    N = decode_normal_fast(taps_resolve<FmtRG16U>(tn));
+    albedo = mix3(mix3(srgb_rgb(ta.t00, s_lut), srgb_rgb(ta.t10, s_lut), ta.fx), mix3(srgb_rgb(ta.t01, s_lut), srgb_rgb(ta.t11, s_lut), ta.fx), ta.fy);
+    roughness = taps_srgb_channel(tm, 1, s_lut);
+    metallic = mixf(0.1f, 1.0f, taps_srgb_channel(tm, 2, s_lut));
+    depth = taps_resolve<FmtD24>(td);
+  } else {
+    N = decode_normal_fast(sample<FmtRG16U>(a.normal, screen_uv));
+    albedo = sample_srgb_rgb(a.albedo, screen_uv, s_lut);
+    roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
+    metallic = mixf(0.1f, 1.0f, sample_srgb_channel(a.material, screen_uv, 2, s_lut));
+    depth = sample<FmtD24>(a.depth0, screen_uv);
+  }
   // sample_ocllusion_ssr (:103-130): the four textureLodOffset taps share one 3x3 texel footprint
   float occlusion;
   f3 reflection;
@@ -100,10 +118,21 @@ __global__ __launch_bounds__(256) void k_defered_shading(ShadingArgs a) {
     const float fx = hx - hx0f, fy = hy - hy0f;
     const int x0 = f2i(hx0f), y0 = f2i(hy0f);
     float t[3][3];
+    const int wx0 = x0 - a.depth1.ox, wy0 = y0 - a.depth1.oy;
+    if (FAST && wx0 >= 0 && wy0 >= 0 && wx0 + 2 < a.depth1.w && wy0 + 2 < a.depth1.h) {
+      // interior: a row of the footprint is the pair (x0, x0 + 1) as one 8-byte load plus texel x0 + 2
 #pragma unroll
-    for (int j = 0; j < 3; j++)
+      for (int j = 0; j < 3; j++) {
+        const uint8_t* row = a.depth1.p + toff(a.depth1, wx0, wy0 + j, 4);
+        const U32x2 pr = load_u32x2(row);
+        t[j][0] = FmtD24::decode(pr.x); t[j][1] = FmtD24::decode(pr.y); t[j][2] = FmtD24::decode(*(const uint32_t*)(row + 8));
+      }
+    } else {
 #pragma unroll
-      for (int i = 0; i < 3; i++) t[j][i] = fetch_clamped<FmtD24>(a.depth1, x0 + i, y0 + j);
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) t[j][i] = fetch_clamped<FmtD24>(a.depth1, x0 + i, y0 + j);
+    }
     auto bil = [&](int ox, int oy) { return mixf(mixf(t[oy][ox], t[oy][ox + 1], fx), mixf(t[oy + 1][ox], t[oy + 1][ox + 1], fx), fy); };
     const float d0 = fabsf(bil(0, 0) - depth), d1 = fabsf(bil(1, 0) - depth), d2 = fabsf(bil(0, 1) - depth), d3 = fabsf(bil(1, 1) - depth);
     const float min_delta = vmin(vmin(d0, d1), vmin(d2, d3));
@@ -111,8 +140,13 @@ __global__ __launch_bounds__(256) void k_defered_shading(ShadingArgs a) {
     if (min_delta == d0) { ox = 0; oy = 0; }
     else if (min_delta == d1) { ox = 1; oy = 0; }
     else if (min_delta == d2) { ox = 0; oy = 1; }
-    occlusion = sample<FmtRG16F>(a.occlusion, screen_uv, ox, oy).x;
-    reflection = sample<FmtRGBA8>(a.reflections, screen_uv, ox, oy);
+    if (FAST) {
+      occlusion = taps_resolve<FmtRG16F>(pair_taps(a.occlusion, pair_footprint(a.occlusion, screen_uv, ox, oy))).x;
+      reflection = taps_resolve<FmtRGBA8>(pair_taps(a.reflections, pair_footprint(a.reflections, screen_uv, ox, oy)));
+    } else {
+      occlusion = sample<FmtRG16F>(a.occlusion, screen_uv, ox, oy).x;
+      reflection = sample<FmtRGBA8>(a.reflections, screen_uv, ox, oy);
+    }
   }
   const f3 vv = reconstruct_view_vec(screen_uv, depth, a.pr);
   const f3 world_pos = xyz(mul(a.inverse_camera, mk4(vv.x, vv.y, vv.z, 1.0f)));
@@ -140,7 +174,8 @@ __global__ __launch_bounds__(256) void k_defered_shading(ShadingArgs a) {
   const f3 kD = (mk3(1.0f, 1.0f, 1.0f) - F) * (1.0f - metallic);
   const f3 specular = ((NDF * G) * F) * fast_rcp((4.0f * NdotV) * NdotL + 0.0001f);
   const float biased_rougness = mixf(a.min_roughness, a.max_roughness, roughness);
-  const f2 ssr_brdf = sample<FmtRG16F>(a.brdf, mk2(biased_rougness, NdotV));
+  const f2 ssr_brdf = FAST ? taps_resolve<FmtRG16F>(pair_taps(a.brdf, pair_footprint(a.brdf, mk2(biased_rougness, NdotV))))
+                           : sample<FmtRG16F>(a.brdf, mk2(biased_rougness, NdotV));
   f3 Lo = (((kD * albedo) * (1.0f / VKR_PI) + specular) * rad) * NdotL;
   Lo = Lo + reflection * (F0 * ssr_brdf.x + mk3(ssr_brdf.y, ssr_brdf.y, ssr_brdf.y));
   const f3 color = occlusion * (mk3(0.6f, 0.6f, 0.6f) * albedo + Lo);
@@ -182,7 +217,10 @@ extern "C" int vkr_defered_shading(const vkr_img* albedo, const vkr_img* normal,
   a.min_roughness = push->min_max_roughness[0];
   a.max_roughness = push->min_max_roughness[1];
   a.show_ao = push->show_ao;
+  const bool fast = same_layout(a.normal, a.albedo) && same_layout(a.normal, a.material) && same_layout(a.normal, a.depth0) && a.normal.w >= 2 &&
+                    a.depth1.w >= 2 && a.occlusion.w >= 2 && a.reflections.w >= 2 && a.brdf.w >= 2 && !getenv("VKR_SHADING_GENERIC");
   dim3 block(64, 4);
-  hipLaunchKernelGGL(k_defered_shading, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  if (fast) hipLaunchKernelGGL(k_defered_shading<true>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_defered_shading<false>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   return launch_status("defered_shading");
 }

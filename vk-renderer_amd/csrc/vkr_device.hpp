@@ -317,6 +317,34 @@ VKR_DEV BilinearTaps bilinear_taps_u32(const Tex& t, f2 uv) {
 template <class F> VKR_DEV typename F::T taps_resolve(const BilinearTaps& b) {
   return F::lerp(F::lerp(F::decode(b.t00), F::decode(b.t10), b.fx), F::lerp(F::decode(b.t01), F::decode(b.t11), b.fx), b.fy);
 }
+// The bilinear footprint of texture(t, uv [, offset]) on a 4-byte format, each ROW fetched as one 8-byte load of the texel
+// pair (xs, xs + 1), xs = clamp(x0, 0, w - 2): the texture-address unit spends the same time on a wave's load whatever
+// its width, so two loads instead of four.  left_is_y / right_is_x say which half of the pair the left / right tap is;
+// they differ from (x, y) only in the first and last column, where clamp-to-edge makes both taps the same texel.
+// Needs w >= 2.  Images with one window geometry and pitch share the record.
+struct PairFootprint { uint32_t row0, row1; bool left_is_y, right_is_x; float fx, fy; };
+VKR_DEV PairFootprint pair_footprint(const Tex& t, f2 uv, int offx = 0, int offy = 0) {
+  PairFootprint f;
+  const float x = cfma(uv.x, (float)t.fw, -0.5f), y = cfma(uv.y, (float)t.fh, -0.5f);
+  const float x0f = floorf(x), y0f = floorf(y);
+  f.fx = x - x0f; f.fy = y - y0f;
+  const int x0 = f2i(x0f) + offx - t.ox, y0 = f2i(y0f) + offy - t.oy;
+  const int xs = iclamp(x0, 0, t.w - 2);
+  f.left_is_y = x0 > xs;    // x0 >= w - 1: both taps are the pair's second texel
+  f.right_is_x = x0 < xs;   // x0 <= -1: both taps are the pair's first texel
+  const uint32_t xb = (uint32_t)xs * 4u;
+  f.row0 = __umul24((uint32_t)iclamp(y0, 0, t.h - 1), (uint32_t)t.pitch) + xb;
+  f.row1 = __umul24((uint32_t)iclamp(y0 + 1, 0, t.h - 1), (uint32_t)t.pitch) + xb;
+  return f;
+}
+VKR_DEV BilinearTaps pair_taps(const Tex& t, const PairFootprint& f) {
+  BilinearTaps b;
+  const U32x2 r0 = load_u32x2(t.p + f.row0), r1 = load_u32x2(t.p + f.row1);
+  b.t00 = f.left_is_y ? r0.y : r0.x; b.t10 = f.right_is_x ? r0.x : r0.y;
+  b.t01 = f.left_is_y ? r1.y : r1.x; b.t11 = f.right_is_x ? r1.x : r1.y;
+  b.fx = f.fx; b.fy = f.fy;
+  return b;
+}
 // one channel (0 = r, 1 = g, 2 = b) of texture() on an RGBA8_SRGB image
 VKR_DEV float taps_srgb_channel(const BilinearTaps& b, int channel, const float* lut) {
   const int sh = channel * 8;

@@ -56,6 +56,9 @@ inline bool same_window(const Tex& a, const Tex& b) {
   return a.w == b.w && a.h == b.h && a.fw == b.fw && a.fh == b.fh && a.ox == b.ox && a.oy == b.oy;
 }
 
+// same window AND row pitch: texel (x, y) has the same byte offset in both (4-byte formats share bilinear footprints)
+inline bool same_layout(const Tex& a, const Tex& b) { return same_window(a, b) && a.pitch == b.pitch; }
+
 inline void load_mat(Mat4& dst, const vkr_mat4& src) { std::memcpy(dst.m, src.m, sizeof(float) * 16); }
 
 inline int launch_status(const char* what) {
