@@ -98,7 +98,7 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   if (gx >= a.tex_w || gy >= a.tex_h) return;
-  const f2 screen_uv = mk2(((float)gx + 0.5f) / (float)a.tex_w, ((float)gy + 0.5f) / (float)a.tex_h);
+  const f2 screen_uv = mk2(pixel_centre_uv(gx, (float)a.tex_w), pixel_centre_uv(gy, (float)a.tex_h));
   const float pdf_uniform = 1.0f / (2.0f * VKR_PI);
   float occ_x = 0.0f, occ_y = pdf_uniform;
   uint2* dst = texel_ptr<uint2>(a.out, lx, ly);
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_gtao_accumulate(AccumArgs a) {
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
-  const f2 screen_uv = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
+  const f2 screen_uv = mk2(pixel_centre_uv(gx, tex_size.x), pixel_centre_uv(gy, tex_size.y));
   const f2 velocity = sample<FmtRG16F>(a.velocity, screen_uv);
   const f2 prev_uv = screen_uv + velocity;
   bool reprojected = false;

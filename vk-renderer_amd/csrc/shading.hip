@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_defered_shading(ShadingArgs a) {
   const int ly = blockIdx.y * blockDim.y + threadIdx.y;
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
-  const f2 screen_uv = mk2(((float)gx + 0.5f) / (float)a.out.fw, ((float)gy + 0.5f) / (float)a.out.fh);
+  const f2 screen_uv = mk2(pixel_centre_uv(gx, (float)a.out.fw), pixel_centre_uv(gy, (float)a.out.fh));
   // Exact: the depths that decide the 2x2 pick.  Everything after the pick is shading arithmetic
   // written to an 8-bit sRGB target: hardware rsq / rcp.
   f3 N, albedo;

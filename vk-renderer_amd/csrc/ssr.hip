@@ -47,6 +47,10 @@ struct TraceArgs {
   uint32_t frame_random;
   float max_roughness;
   float horizon_d2;    // host-computed: smallest float x with sqrtf(x) >= 0.3f (trace.comp:257)
+  // quotients that are the same for every ray, divided once on the host (IEEE, as the kernel would): 1 / screen_size,
+  // 0.005 / screen_size (screen_trace.glsl:10,20 at most_detailed_mip 0) and zfar / (zfar - znear) (gbuffer_encode.glsl:77)
+  f2 screen_size_inv, uv_offset_abs;
+  float f_over_fn;
 };
 
 // One thread per ray in the prologue / epilogue; the march in between runs in rounds of
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   const bool active = lx < a.out_ray.w && ly < a.out_ray.h;
   const int gx = a.out_ray.ox + lx, gy = a.out_ray.oy + ly;
   const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
-  const f2 screen_uv = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
+  const f2 screen_uv = mk2(pixel_centre_uv(gx, tex_size.x), pixel_centre_uv(gy, tex_size.y));
   const Proj pr = a.pr;
   const Tex& depth0 = a.depth.mip[0];
 
@@ -90,8 +94,8 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   env.mip_table = s_mip;
   env.mip_count = a.depth.count;
   env.screen_size = mk2((float)depth0.fw, (float)depth0.fh);
-  env.screen_size_inv = mk2(1.0f / env.screen_size.x, 1.0f / env.screen_size.y);
-  env.uv_offset_abs = mk2(0.005f / env.screen_size.x, 0.005f / env.screen_size.y);  // most_detailed_mip = 0
+  env.screen_size_inv = a.screen_size_inv;
+  env.uv_offset_abs = a.uv_offset_abs;  // most_detailed_mip = 0
   env.pr = pr;
   env.horizon_d2 = a.horizon_d2;
 
@@ -128,9 +132,9 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
     R = reflect(rc.view_vec, N);
 
     // trace.comp:79-84
-    ray_start = project_view_vec(rc.view_vec + 0.001f * rc.normal, pr);
+    ray_start = project_view_vec(rc.view_vec + 0.001f * rc.normal, pr, a.f_over_fn);
     ray_start.z -= 0.0001f;
-    f3 ray_dir = project_view_vec(rc.view_vec + R, pr);
+    f3 ray_dir = project_view_vec(rc.view_vec + R, pr, a.f_over_fn);
     ray_dir = ray_dir - ray_start;
     ray_dir = ray_dir * ((1.0f - ray_start.z) / ray_dir.z);
 
@@ -461,7 +465,7 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const int gx = a.out.ox + min(lx, a.out.w - 1), gy = a.out.oy + min(lyA + k, a.out.h - 1);
-    uv_c[k] = mk2(((float)gx + 0.5f) / tex_size.x, ((float)gy + 0.5f) / tex_size.y);
+    uv_c[k] = mk2(pixel_centre_uv(gx, tex_size.x), pixel_centre_uv(gy, tex_size.y));
     velocity_taps[k] = bilinear_taps_u32(a.velocity, uv_c[k]);
   }
 
@@ -710,6 +714,12 @@ extern "C" int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const
   a.frame_random = params->frame_random;
   a.max_roughness = push->max_roughness;
   a.horizon_d2 = horizon_threshold_d2();
+  {
+    const float sw = (float)a.depth.mip[0].fw, sh = (float)a.depth.mip[0].fh;
+    a.screen_size_inv.x = 1.0f / sw; a.screen_size_inv.y = 1.0f / sh;
+    a.uv_offset_abs.x = 0.005f / sw; a.uv_offset_abs.y = 0.005f / sh;
+    a.f_over_fn = a.pr.zfar / (a.pr.zfar - a.pr.znear);
+  }
   dim3 block(TRACE_THREADS, 1);
   dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 8 * TRACE_WY - 1) / (8 * TRACE_WY));
   hipLaunchKernelGGL(k_sssr_trace, grid, block, 0, (hipStream_t)stream, a);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_taa_resolve(TaaArgs a) {
   if (lx >= a.out.w || ly >= a.out.h) return;
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   // (g + 0.5) / size: both operands and the quotient are far inside the normal range
-  const f2 screen_uv = mk2(div_normal((float)gx + 0.5f, (float)a.out.fw), div_normal((float)gy + 0.5f, (float)a.out.fh));
+  const f2 screen_uv = mk2(pixel_centre_uv(gx, (float)a.out.fw), pixel_centre_uv(gy, (float)a.out.fh));
   const Footprint fc = footprint4(a.color, screen_uv);
   const Footprint fv = SHARED ? fc : footprint4(a.velocity, screen_uv);
   const BilinearTaps tc = taps_at(a.color, fc), tv = taps_at(a.velocity, fv);

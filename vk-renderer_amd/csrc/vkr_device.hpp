@@ -404,6 +404,9 @@ VKR_DEV float div_normal(float a, float b) {
   const float e3 = __builtin_fmaf(-b, q, a);
   return __builtin_fmaf(e3, r, q);
 }
+// uv of the centre of pixel g of an extent of `size` pixels, (g + 0.5) / size with 0 <= g < size <= 65535: both operands
+// and the quotient are normal, so div_normal gives the IEEE quotient (vkr_selftest_pixel_uv checks every pair)
+VKR_DEV float pixel_centre_uv(int g, float size) { return div_normal((float)g + 0.5f, size); }
 // decode_normal whose result only enters smooth terms (weights, shading angles)
 VKR_DEV f3 decode_normal_fast(f2 uv) {
   uv = mk2(cfma(2.0f, uv.x, -1.0f), cfma(2.0f, uv.y, -1.0f));
@@ -430,6 +433,15 @@ VKR_DEV f3 reconstruct_view_vec(f2 uv, float d, const Proj& pr) {
 // gbuffer_encode.glsl:71-73
 VKR_DEV float encode_depth(float z, float n, float f) { return f / (f - n) + (f * n) / (z * (f - n)); }
 // gbuffer_encode.glsl:75-84
+// f_over_fn: zfar / (zfar - znear), the one quotient of the expression that is the same for every pixel (the trace gets
+// it from the host, where the same IEEE division produces the same float)
+VKR_DEV f3 project_view_vec(f3 v, const Proj& pr, float f_over_fn) {
+  float n = pr.znear, f = pr.zfar, z = v.z;
+  float depth = f_over_fn + (f * n) / (z * (f - n));
+  float pu = v.x / ((-v.z * pr.tg) * pr.aspect);
+  float pv = v.y / (-z * pr.tg);
+  return mk3(cfma(0.5f, pu, 0.5f), cfma(0.5f, pv, 0.5f), depth);
+}
 VKR_DEV f3 project_view_vec(f3 v, const Proj& pr) {
   float n = pr.znear, f = pr.zfar, z = v.z;
   float depth = f / (f - n) + (f * n) / (z * (f - n));
