@@ -61,7 +61,7 @@ typedef struct vkr_img {
   uint32_t width, height;              /* extent of view-mip 0 held in memory       */
   uint32_t full_width, full_height;    /* extent of view-mip 0 of the whole frame   */
   int32_t  origin_x, origin_y;         /* window origin inside the frame, view-mip 0*/
-  uint32_t pitch_bytes[VKR_MAX_MIPS];  /* row pitch of each mip: < 16 MiB, and pitch x rows of the mip < 4 GiB (the kernels
+  uint32_t pitch_bytes[VKR_MAX_MIPS];  /* row pitch of each mip: < 16 MiB, rows < 2^24, and pitch x rows of the mip < 4 GiB (the kernels
                                           address texels with 32-bit offsets; VKR_ERR_LAYOUT otherwise)  */
   uint64_t mip_offset[VKR_MAX_MIPS];   /* byte offset of each mip from `base`       */
 } vkr_img;

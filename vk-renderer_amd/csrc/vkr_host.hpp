@@ -36,7 +36,7 @@ inline int make_tex(const vkr_img* d, int mip, uint32_t want_format, const char*
     return VKR_ERR_LAYOUT;
   }
   // texel offsets are 32-bit, rows x pitch a 24-bit multiply (toff() in vkr_device.hpp)
-  if (d->pitch_bytes[mip] >= (1u << 24) || (uint64_t)d->pitch_bytes[mip] * (uint64_t)h >= (1ull << 32)) {
+  if (d->pitch_bytes[mip] >= (1u << 24) || h >= (1 << 24) || (uint64_t)d->pitch_bytes[mip] * (uint64_t)h >= (1ull << 32)) {
     set_error("%s: window too large for 32-bit texel offsets (pitch %u x %d rows)", what, d->pitch_bytes[mip], h);
     return VKR_ERR_LAYOUT;
   }
