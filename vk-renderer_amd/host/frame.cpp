@@ -229,7 +229,10 @@ struct TiledFrame {
     frame.reset(new PostFxFrame(fc));
     frame->hiz_gathered_mips = tiled ? k : 4;
     if (tiled) {
-      check(hipStreamCreateWithFlags(&xchg, hipStreamNonBlocking), "exchange stream");
+      // the exchanges' kernels (a few workgroups each) must not queue behind a frame's worth of compute waves
+      int prio_low = 0, prio_high = 0;
+      check(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high), "stream priority range");
+      check(hipStreamCreateWithPriority(&xchg, hipStreamNonBlocking, prio_high), "exchange stream");
       for (auto& e : ev_ready) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
       for (auto& e : ev_done) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
       for (int s = 0; s < 3; s++)
