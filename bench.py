@@ -243,6 +243,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # Strips balanced by cost (N > 1, C++ tiled frame): the rows of a frame do not cost the same — a strip of sky is cheap, a
+    # strip of reflecting floor is not (tools/lockstep_profile.py: 1.15 .. 2.11 ms for the eight equal strips of c4) — and
+    # the frame takes as long as the slowest rank.  Before the timed region every rank measures its passes (events around
+    # the kernels: no waiting for exchanges in it), the times are shared, vkrh_balance_rows cuts the frame where the
+    # cumulative cost is r / N of the total, and the frame is rebuilt on the new strips (their shares then travel with
+    # vkr_all_gather_v).  Twice: the cost inside a strip is not uniform either.  VKR_BALANCE=0 keeps equal strips.
+    row_bounds = [r * th for r in range(world + 1)]
+    balance_log = []
+    # (VKR_BALANCE_REBUILD=1, tests: the one-rank rehearsal goes through the same measure / share / rebuild sequence although
+    # its single strip cannot move)
+    force_rebuild = os.environ.get("VKR_BALANCE_REBUILD") == "1"
+    if ((world > 1 and args.config == "c4") or (args.rehearse_tiled and force_rebuild)) and comm is not None and os.environ.get("VKR_BALANCE", "1") != "0":
+        for _ in range(2):
+            BAL_STEPS = 3
+            frame.enable_task_timing(True)
+            for _ in range(BAL_STEPS):
+                tiled.step()
+            tiled.flush()
+            barrier()
+            mine = sum(v[0] for v in frame.collect_task_times().values()) / BAL_STEPS
+            frame.enable_task_timing(False)
+            every = [None] * world
+            dist.all_gather_object(every, float(mine))
+            new_bounds = host.balance_rows(every, row_bounds, align=16, min_rows=max(256, H // (4 * world) // 16 * 16))
+            balance_log.append({"rows": [row_bounds[r + 1] - row_bounds[r] for r in range(world)], "compute_ms": [round(v, 4) for v in every]})
+            if new_bounds == row_bounds and not force_rebuild:
+                break
+            row_bounds = new_bounds
+            frame.close()
+            tiled = TiledFrame(setup, rank, world, cols, rows, device, force_tiled=args.rehearse_tiled, native=True, comm=comm, row_bounds=row_bounds)
+            frame = tiled.frame
+            frame.set_async(args.overlap)
+            tiled.prepare()
+            for _ in range(max(args.warmup, 2)):
+                tiled.step()
+            tiled.flush()
+            barrier()
+
     # Per-pass times come from a short calibration run with an event pair around every pass; the timed region then
     # keeps only the pair around the dominant pass (the roofline's live measurement): an event record costs ~3.5 us
     # of queue time, and nine pairs per frame would slow the 1 ms frame that is being measured by 7 %.
@@ -330,6 +368,8 @@ def main():
                 "grid": [cols, rows],
                 "halo_px": tiled.halo,
                 "gathered_hiz_mips": tiled.gather_mips if tiled.tiled else 0,
+                "strip_rows": [row_bounds[r + 1] - row_bounds[r] for r in range(world)],
+                "strip_balance": balance_log,  # per balancing pass: the strips and every rank's compute time with them
                 "exchange": exchange,
                 "gbuffer": "rasterised procedural mesh scene (GbufferPass timed)" if args.raster else "analytic generator (not timed)",
             },

@@ -418,6 +418,12 @@ int vkr_comm_rank(const vkr_comm* comm, int* rank, int* world);
  * horizontal strips a tile's rows of a surface are contiguous, so recv can be the whole-frame image itself)       */
 typedef struct vkr_gather_part { const void* send; void* recv; uint64_t bytes; } vkr_gather_part;
 int vkr_all_gather(vkr_comm* comm, const vkr_gather_part* parts, uint32_t count, void* stream);
+/* the same for shares of different sizes (strips balanced by cost): rank r's share of a surface lies at
+ * recv + offsets[r] .. recv + offsets[r + 1] (offsets: world + 1 entries in host memory, identical on every rank; an
+ * empty share is allowed); `send` is this rank's share where it lies now.  One grouped launch: an ncclBroadcast per
+ * share, rooted at its owner.                                                                                        */
+typedef struct vkr_gather_v_part { const void* send; void* recv; const uint64_t* offsets; } vkr_gather_v_part;
+int vkr_all_gather_v(vkr_comm* comm, const vkr_gather_v_part* parts, uint32_t count, void* stream);
 /* halo refresh of one history surface: per neighbour the packed slice to send and the buffer to receive into
  * (either may be empty); pack / unpack with vkr_copy_rects around it                                               */
 typedef struct vkr_halo_peer { int32_t peer; uint32_t reserved; const void* send; uint64_t send_bytes; void* recv; uint64_t recv_bytes; } vkr_halo_peer;

@@ -60,3 +60,18 @@ def test_host_library_loads_and_rejects_unknown_program():
     for sym in ("vkrh_create", "vkrh_destroy", "vkrh_run", "vkrh_end_frame", "vkrh_image", "vkrh_set_camera", "vkrh_set_allocator",
                 "vkrh_collect_task_times", "vkrh_pin_randoms"):
         assert hasattr(lib, sym)
+
+
+def test_balance_rows_policy():
+    """vkrh_balance_rows: equal times keep equal strips; a frame whose lower half costs twice as much per row gets its
+    cut where the cumulative cost is half; alignment and the minimum height hold."""
+    from vk_renderer_amd import host
+
+    assert host.balance_rows([1.0, 1.0, 1.0, 1.0], [0, 160, 320, 480, 640]) == [0, 160, 320, 480, 640]
+    b = host.balance_rows([1.0, 2.0], [0, 1600, 3200])      # cost 1 per 1600 rows above, 2 below: half of 3 at row 1600 + 400
+    assert b == [0, 2000, 3200]
+    b = host.balance_rows([10.0, 0.1, 0.1, 0.1], [0, 256, 512, 768, 1024], align=16, min_rows=64)
+    assert b[0] == 0 and b[-1] == 1024 and all(x % 16 == 0 for x in b) and all(b[i + 1] - b[i] >= 64 for i in range(4))
+    assert b[1] == 64  # the expensive strip shrinks to the minimum
+    with pytest.raises(RuntimeError):
+        host.balance_rows([1.0, 1.0], [0, 64, 100])  # frame height not a multiple of the alignment

@@ -14,53 +14,7 @@ OUTPUTS = (("rays", 1), ("raw", 1), ("reflections", 1), ("filtered", 1), ("blurr
            ("dn", 1), ("dv", 1), ("depth", 0))
 
 
-def bytes_at(ranks, addr, nbytes):
-    """uint8 view of device memory [addr, addr + nbytes) owned by one of the ranks' allocators"""
-    for t in ranks:
-        try:
-            tensor, off = t.frame.allocator.tensor_at(addr)
-        except KeyError:
-            continue
-        assert off + nbytes <= tensor.numel()
-        return tensor[off: off + nbytes]
-    raise KeyError(hex(addr))
-
-
-def move_gather(ranks, which):
-    """what vkr_all_gather delivers: recv = [rank][bytes] of every rank's send"""
-    parts = [t.frame.tiled_gather_parts(which) for t in ranks]
-    for r, mine in enumerate(parts):
-        for i, (_, recv, nbytes) in enumerate(mine):
-            for src, theirs in enumerate(parts):
-                send, _, n2 = theirs[i]
-                assert n2 == nbytes
-                bytes_at(ranks, recv + src * nbytes, nbytes).copy_(bytes_at(ranks, send, nbytes))
-
-
-def move_halo(ranks, surface):
-    """what vkr_halo_exchange delivers: every receive buffer gets the send buffer its peer packed for this rank"""
-    peers = [t.frame.tiled_halo_peers(surface) for t in ranks]
-    for r, mine in enumerate(peers):
-        for peer, _, recv, nbytes in mine:
-            send = [p for p in peers[peer] if p[0] == r][0][1]
-            bytes_at(ranks, recv, nbytes).copy_(bytes_at(ranks, send, nbytes))
-
-
-def lockstep_frame(ranks):
-    for p in range(5):
-        for t in ranks:
-            t.frame.tiled_phase(p)
-        if p == 0:      # both gathers start after the downsample; the harness completes them at once
-            move_gather(ranks, 0)
-            move_gather(ranks, 1)
-        elif p == 1:
-            move_halo(ranks, 0)
-        elif p == 3:
-            move_halo(ranks, 1)
-        elif p == 4:
-            move_halo(ranks, 2)
-    for t in ranks:
-        t._frame_no += 1
+from vk_renderer_amd.tiling import native_lockstep_frame as lockstep_frame  # noqa: E402  (the harness: plays the wire with copies)
 
 
 def _plain(W, H, frames, device):
@@ -120,10 +74,44 @@ def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather):
     assert bad == 0
 
 
-def test_native_tiled_frame_through_a_one_rank_rccl_communicator():
-    """vkr_comm_unique_id / vkr_comm_create (librccl.so.1 via dlopen), grouped ncclAllGather launches on the frame's exchange
-    stream, event ordering against the compute stream: three frames must equal the plain frame bit for bit."""
+@pytest.mark.parametrize("bounds,gather", [([0, 160, 400, 480], 4), ([0, 96, 168, 304, 480], 3)])  # 168 = 8 * 21: mips 1..3 travel
+def test_strips_of_different_heights_match_single_gpu_frame(bounds, gather):
+    """Cost-balanced strips (vkrh_tiled_config.row_bounds): every rank owns a different number of rows; the shares of the
+    whole-frame surfaces then lie at different offsets (what vkr_all_gather_v moves).  Interiors must equal the plain frame."""
     import torch
+
+    from vk_renderer_amd.camera import FrameSetup
+    from vk_renderer_amd.tiling import TiledFrame
+
+    world, W, H = len(bounds) - 1, 256, bounds[-1]
+    device = torch.device("cuda", 0)
+    want = _plain(W, H, 3, device)
+    ranks = [TiledFrame(FrameSetup(W, H), r, world, 1, world, device, native=True, comm=None, row_bounds=bounds) for r in range(world)]
+    for r, t in enumerate(ranks):
+        assert t.native and t.gather_mips == gather and t.tile == (0, bounds[r], W, bounds[r + 1] - bounds[r])
+        t.prepare()
+    for _ in range(3):
+        lockstep_frame(ranks)
+    for t in ranks:
+        t.flush()
+    torch.cuda.synchronize()
+    bad = sum(_interiors_differ(t, want, W, t.th) for t in ranks)
+    for t in ranks:
+        t.frame.close()
+    assert bad == 0
+
+
+@pytest.mark.parametrize("gather_v", [False, True])
+def test_native_tiled_frame_through_a_one_rank_rccl_communicator(gather_v, monkeypatch):
+    """vkr_comm_unique_id / vkr_comm_create (librccl.so.1 via dlopen), grouped ncclAllGather launches on the frame's exchange
+    stream, event ordering against the compute stream: three frames must equal the plain frame bit for bit.
+    gather_v: the same through vkr_all_gather_v (grouped ncclBroadcast launches: what strips of different heights use)."""
+    import torch
+
+    if gather_v:
+        monkeypatch.setenv("VKR_TILED_FORCE_GATHER_V", "1")
+    else:
+        monkeypatch.delenv("VKR_TILED_FORCE_GATHER_V", raising=False)
 
     from vk_renderer_amd import abi
     from vk_renderer_amd.camera import FrameSetup

@@ -2,10 +2,15 @@
 frame with TAA overlapping the first gather) rehearsed on ONE GPU with a one-rank RCCL group: results must be
 bit-identical to the plain single-GPU frame.  (Real multi-rank runs are covered by the gloo tests on the oracle
 and by the driver's N = 2, 4, 8 scaling runs.)"""
+import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -44,3 +49,20 @@ def test_tiled_path_on_one_rank_matches_plain_frame():
             assert np.array_equal(results[0][n], results[1][n]), f"{n}: tiled code path differs from the plain frame"
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_rebuilds_the_frame_on_balanced_strips():
+    """bench.py at N > 1 measures every rank's passes, shares the times and rebuilds the C++ tiled frame on strips cut by
+    cost (vkrh_balance_rows) before its timed region.  One rank cannot move its strip, but VKR_BALANCE_REBUILD=1 takes the
+    rehearsal through the same sequence: measure, all_gather_object, close, rebuild with row_bounds, prepare, warm up."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29548", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", VKR_BALANCE_REBUILD="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-tiled", "--frame", "1024x576", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, out.stdout
+    res = json.loads(line[0])
+    assert res["config"]["strip_rows"] == [576]
+    assert len(res["config"]["strip_balance"]) == 2 and all(p["rows"] == [576] and p["compute_ms"][0] > 0 for p in res["config"]["strip_balance"])
+    assert res["value"] > 0

@@ -3,6 +3,7 @@
 //
 //   vkr_all_gather     one grouped ncclAllGather launch for several surfaces (the Hi-Z mips + downsampled normals, or
 //                      the albedo): recv = [rank][bytes], out of place, so a strip's rows land in the whole-frame image
+//   vkr_all_gather_v   the same for shares of different sizes (cost-balanced strips): a grouped ncclBroadcast per share
 //   vkr_halo_exchange  one grouped ncclSend / ncclRecv launch refreshing the halo rings of a history surface
 //
 // Both enqueue on the caller's stream and return; nothing blocks the host.  RCCL is loaded with dlopen the first
@@ -25,6 +26,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -50,6 +52,7 @@ void load_rccl() {
   VKR_SYM(CommInitRank, "ncclCommInitRank")
   VKR_SYM(CommDestroy, "ncclCommDestroy")
   VKR_SYM(AllGather, "ncclAllGather")
+  VKR_SYM(Broadcast, "ncclBroadcast")
   VKR_SYM(Send, "ncclSend")
   VKR_SYM(Recv, "ncclRecv")
   VKR_SYM(GroupStart, "ncclGroupStart")
@@ -126,6 +129,32 @@ extern "C" int vkr_all_gather(vkr_comm* comm, const vkr_gather_part* parts, uint
   const ncclResult_t e = g_rccl.GroupEnd();
   if (r != ncclSuccess) return fail("all_gather", r);
   return e == ncclSuccess ? vkr::VKR_OK : fail("all_gather", e);
+}
+
+extern "C" int vkr_all_gather_v(vkr_comm* comm, const vkr_gather_v_part* parts, uint32_t count, void* stream) {
+  if (count == 0) return vkr::VKR_OK;
+  if (!comm || !parts) { vkr::set_error("all_gather_v: NULL argument"); return vkr::VKR_ERR_NULL; }
+  for (uint32_t i = 0; i < count; i++) {
+    const vkr_gather_v_part& p = parts[i];
+    if (!p.recv || !p.offsets) { vkr::set_error("all_gather_v: part %u has a NULL buffer", i); return vkr::VKR_ERR_NULL; }
+    for (int r = 0; r < comm->world; r++)
+      if (p.offsets[r + 1] < p.offsets[r]) { vkr::set_error("all_gather_v: part %u: offsets must not decrease", i); return vkr::VKR_ERR_LAYOUT; }
+    if (p.offsets[comm->rank + 1] > p.offsets[comm->rank] && !p.send) { vkr::set_error("all_gather_v: part %u has no send buffer", i); return vkr::VKR_ERR_NULL; }
+  }
+  // all-gather-v as the usual group of broadcasts: share r of every surface from its owner into place on every rank
+  ncclResult_t r = g_rccl.GroupStart();
+  for (uint32_t i = 0; r == ncclSuccess && i < count; i++) {
+    const vkr_gather_v_part& p = parts[i];
+    for (int root = 0; r == ncclSuccess && root < comm->world; root++) {
+      const uint64_t n = p.offsets[root + 1] - p.offsets[root];
+      if (n == 0) continue;
+      void* dst = (uint8_t*)p.recv + p.offsets[root];
+      r = g_rccl.Broadcast(root == comm->rank ? p.send : dst, dst, (size_t)n, ncclUint8, root, comm->comm, (hipStream_t)stream);
+    }
+  }
+  const ncclResult_t e = g_rccl.GroupEnd();
+  if (r != ncclSuccess) return fail("all_gather_v", r);
+  return e == ncclSuccess ? vkr::VKR_OK : fail("all_gather_v", e);
 }
 
 extern "C" int vkr_halo_exchange(vkr_comm* comm, const vkr_halo_peer* peers, uint32_t count, void* stream) {

@@ -42,6 +42,14 @@ inline int make_tex(const vkr_img* d, int mip, uint32_t want_format, const char*
   }
   int fw = mip_dim(d->full_width, mip), fh = mip_dim(d->full_height, mip);
   int ox = d->origin_x >> mip, oy = d->origin_y >> mip;
+  if (mip > 0 && d->origin_x >= 0 && d->origin_y >= 0) {
+    // Mip extents are floor(extent / 2^mip), at least 1: where the frame's extent is not a multiple of 2^mip, a window
+    // that starts in the last, partial texel of a coarse mip (or is shorter than one texel of it) would start past the
+    // mip's last row.  Such a level holds no whole texel of the window; it is placed on the frame's last row / column so
+    // that the chain can still be built (nothing reads it: a window's levels past the gathered ones are never sampled).
+    if (ox + w > fw && w <= fw) ox = fw - w;
+    if (oy + h > fh && h <= fh) oy = fh - h;
+  }
   if (d->origin_x < 0 || d->origin_y < 0 || ox + w > fw || oy + h > fh) {
     set_error("%s: window (%d,%d)+(%d,%d) outside frame %dx%d at mip %d", what, ox, oy, w, h, fw, fh, mip);
     return VKR_ERR_EXTENT;

@@ -25,7 +25,7 @@ class HostConfig(C.Structure):
 class TiledConfig(C.Structure):
     _fields_ = [("full_width", C.c_uint32), ("full_height", C.c_uint32), ("rank", C.c_uint32), ("world", C.c_uint32),
                 ("halo", C.c_uint32), ("gathered_mips", C.c_uint32), ("force_tiled", C.c_uint32), ("reserved", C.c_uint32),
-                ("stream", C.c_void_p), ("comm", C.c_void_p)]
+                ("stream", C.c_void_p), ("comm", C.c_void_p), ("row_bounds", C.POINTER(C.c_uint32))]
 
 
 class GatherPart(C.Structure):
@@ -98,8 +98,21 @@ def lib():
         l.vkrh_tiled_phase.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_tiled_gather_parts.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(GatherPart), C.c_uint32, C.POINTER(C.c_uint32)]
         l.vkrh_tiled_halo_peers.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(HaloPeer), C.c_uint32, C.POINTER(C.c_uint32)]
+        l.vkrh_balance_rows.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        l.vkrh_balance_rows.restype = C.c_int
         _lib = l
     return _lib
+
+
+def balance_rows(ms, bounds, align=16, min_rows=64):
+    """frame.hpp vkrh_balance_rows: new strip bounds from the compute time each rank measured with `bounds`."""
+    world = len(ms)
+    assert len(bounds) == world + 1
+    out = (C.c_uint32 * (world + 1))()
+    rc = lib().vkrh_balance_rows((C.c_float * world)(*[float(v) for v in ms]), (C.c_uint32 * (world + 1))(*bounds), world, align, min_rows, out)
+    if rc != 0:
+        raise RuntimeError("vkrh_balance_rows: " + lib().vkrh_last_error().decode())
+    return list(out)
 
 
 class TorchAllocator:
@@ -159,8 +172,11 @@ class HostFrame:
         if native_tiled is not None:
             nt = native_tiled
             comm = nt.get("comm")
+            bounds = nt.get("row_bounds")  # world + 1 strip boundaries (rows), or None for equal strips
+            arr = (C.c_uint32 * len(bounds))(*bounds) if bounds is not None else None
             tc = TiledConfig(W, H, nt["rank"], nt["world"], nt["halo"], nt["gathered_mips"], 1 if nt.get("force_tiled") else 0, 0,
-                             C.c_void_p(stream), C.c_void_p(comm.handle if comm is not None else None))
+                             C.c_void_p(stream), C.c_void_p(comm.handle if comm is not None else None),
+                             C.cast(arr, C.POINTER(C.c_uint32)) if arr is not None else None)
             self.comm = comm  # keep the communicator alive as long as the frame
             self.tiled_handle = lib().vkrh_tiled_create(C.byref(tc))
             if not self.tiled_handle:

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -211,15 +212,36 @@ struct TiledFrame {
 
   static void check(hipError_t e, const char* what) { if (e != hipSuccess) throw std::runtime_error {std::string {what} + ": " + hipGetErrorString(e)}; }
 
+  std::vector<uint32_t> bounds;   // world + 1 strip boundaries (rows)
+  bool uniform = true;             // equal strips: ncclAllGather; otherwise vkr_all_gather_v
+  std::vector<std::vector<uint64_t>> gather_offsets[2];  // [which][part][world + 1]: byte offsets of the ranks' shares
+
   explicit TiledFrame(const vkrh_tiled_config& c) : cfg {c} {
     W = c.full_width; H = c.full_height;
-    if (c.world == 0 || c.rank >= c.world || H % c.world) throw std::runtime_error {"vkrh_tiled_create: the frame height must divide by the number of ranks"};
-    th = H / c.world; y0 = c.rank * th;
+    if (c.world == 0 || c.rank >= c.world) throw std::runtime_error {"vkrh_tiled_create: rank outside the world"};
     tiled = c.world > 1 || c.force_tiled;
     const uint32_t k = c.gathered_mips;
-    if (tiled && (k < 1 || k > 4 || th % (1u << k) || W % (1u << k) || (c.world > 1 && c.halo % (1u << k))))
+    bounds.resize(c.world + 1);
+    if (c.row_bounds) {
+      for (uint32_t r = 0; r <= c.world; r++) bounds[r] = c.row_bounds[r];
+      if (bounds[0] != 0 || bounds[c.world] != H) throw std::runtime_error {"vkrh_tiled_create: row_bounds must run from 0 to the frame height"};
+      for (uint32_t r = 0; r < c.world; r++) {
+        if (bounds[r + 1] <= bounds[r]) throw std::runtime_error {"vkrh_tiled_create: row_bounds must increase"};
+        if (bounds[r + 1] - bounds[r] != H / c.world || H % c.world) uniform = false;
+      }
+    } else {
+      if (H % c.world) throw std::runtime_error {"vkrh_tiled_create: the frame height must divide by the number of ranks"};
+      for (uint32_t r = 0; r <= c.world; r++) bounds[r] = r * (H / c.world);
+    }
+    if (getenv("VKR_TILED_FORCE_GATHER_V")) uniform = false;  // tests: the broadcast-based gather also for equal strips
+    cfg.row_bounds = nullptr;  // the caller's array need not outlive the call
+    th = bounds[c.rank + 1] - bounds[c.rank]; y0 = bounds[c.rank];
+    if (tiled && (k < 1 || k > 4 || W % (1u << k) || (c.world > 1 && c.halo % (1u << k))))
       throw std::runtime_error {"vkrh_tiled_create: tile extent and halo must be multiples of 2^gathered_mips (1..4)"};
-    if (c.world > 1 && (c.halo > th || (c.halo & 1u))) throw std::runtime_error {"vkrh_tiled_create: halo must be even and no larger than a strip"};
+    for (uint32_t r = 0; tiled && r <= c.world; r++)
+      if (bounds[r] % (1u << k) || (bounds[r] & 1u)) throw std::runtime_error {"vkrh_tiled_create: strip bounds must be multiples of 2^gathered_mips (1..4)"};
+    for (uint32_t r = 0; c.world > 1 && r < c.world; r++)
+      if (c.halo > bounds[r + 1] - bounds[r] || (c.halo & 1u)) throw std::runtime_error {"vkrh_tiled_create: halo must be even and no larger than a strip"};
     const uint32_t halo_px = c.world > 1 ? c.halo : 0;
     wy0 = y0 >= halo_px ? y0 - halo_px : 0;
     const uint32_t wy1 = std::min(H, y0 + th + halo_px);
@@ -294,12 +316,17 @@ struct TiledFrame {
   // A strip's rows of a whole-frame surface are contiguous in the window image AND in the frame image (same width, same
   // pitch), so every surface is gathered in place: send = the tile's rows where they lie, recv = the frame image.
   uint32_t gather_parts(int which, vkr_gather_part* out) {
+    auto& offs = gather_offsets[which];
+    offs.clear();
     auto part = [&](rendergraph::ImageResourceId src, uint32_t src_mip, rendergraph::ImageResourceId dst, uint32_t dst_mip, uint32_t dv) {
       const vkr_img s = frame->graph.get_image(src)->describe(src_mip, 1), d = frame->graph.get_image(dst)->describe(dst_mip, 1);
       const uint32_t rows = th >> dv;
-      if (s.pitch_bytes[0] != d.pitch_bytes[0] || d.height != rows * cfg.world || s.width != d.width || d.origin_y != 0)
+      if (s.pitch_bytes[0] != d.pitch_bytes[0] || d.height != (H >> dv) || s.width != d.width || d.origin_y != 0)
         throw std::runtime_error {"tiled frame: window and whole-frame images must share width and row pitch"};
       const uint32_t ly = (y0 >> dv) - uint32_t(s.origin_y);
+      std::vector<uint64_t> o(cfg.world + 1);
+      for (uint32_t r = 0; r <= cfg.world; r++) o[r] = uint64_t(bounds[r] >> dv) * s.pitch_bytes[0];
+      offs.push_back(std::move(o));
       return vkr_gather_part {(const uint8_t*)s.base + uint64_t(ly) * s.pitch_bytes[0], d.base, uint64_t(rows) * s.pitch_bytes[0]};
     };
     uint32_t n = 0;
@@ -325,7 +352,14 @@ struct TiledFrame {
     if (cfg.comm) check(hipStreamWaitEvent(compute, ev_done[slot], 0), "stream wait");
   }
   void start_gather(int which) {
-    start(which, [&] { vkr_gather_part p[8]; const uint32_t n = gather_parts(which, p); return vkr_all_gather(cfg.comm, p, n, xchg); });
+    start(which, [&] {
+      vkr_gather_part p[8];
+      const uint32_t n = gather_parts(which, p);
+      if (uniform) return vkr_all_gather(cfg.comm, p, n, xchg);
+      vkr_gather_v_part v[8];  // strips of different heights: every share at its own offset of the frame image
+      for (uint32_t i = 0; i < n; i++) v[i] = vkr_gather_v_part {p[i].send, p[i].recv, gather_offsets[which][i].data()};
+      return vkr_all_gather_v(cfg.comm, v, n, xchg);
+    });
   }
   void start_halo(int s) {
     halo_in_flight[s] = true;
@@ -390,7 +424,8 @@ struct TiledFrame {
   void local_gather(int which) {
     vkr_gather_part p[8];
     const uint32_t n = gather_parts(which, p);
-    for (uint32_t i = 0; i < n; i++) check(hipMemcpyAsync(p[i].recv, p[i].send, p[i].bytes, hipMemcpyDeviceToDevice, compute), "local gather");
+    for (uint32_t i = 0; i < n; i++)
+      check(hipMemcpyAsync((uint8_t*)p[i].recv + gather_offsets[which][i][cfg.rank], p[i].send, p[i].bytes, hipMemcpyDeviceToDevice, compute), "local gather");
   }
   void flush() { for (int s = 0; s < 3; s++) finish_halo(s); }
 };
@@ -675,6 +710,38 @@ int vkrh_tiled_halo_peers(void* tiled, uint32_t surface, vkr_halo_peer* out, uin
   return guarded([&] {
     if (!tiled || !out || !count || capacity < 2 || surface > 2) throw std::runtime_error{"vkrh_tiled_halo_peers: bad arguments (capacity >= 2)"};
     *count = ((TiledFrame*)tiled)->halo_peers((int)surface, out);
+  });
+}
+int vkrh_balance_rows(const float* ms, const uint32_t* bounds_in, uint32_t world, uint32_t align, uint32_t min_rows, uint32_t* bounds_out) {
+  return guarded([&] {
+    if (!ms || !bounds_in || !bounds_out || world == 0 || align == 0) throw std::runtime_error{"vkrh_balance_rows: bad arguments"};
+    const uint32_t H = bounds_in[world];
+    min_rows = std::max((min_rows + align - 1) / align * align, align);
+    if (bounds_in[0] != 0 || H % align || uint64_t(min_rows) * world > H) throw std::runtime_error{"vkrh_balance_rows: the frame does not hold `world` strips of min_rows"};
+    double total = 0.0;
+    for (uint32_t r = 0; r < world; r++) {
+      if (bounds_in[r + 1] <= bounds_in[r] || !(ms[r] > 0.0f)) throw std::runtime_error{"vkrh_balance_rows: bounds must increase and times be positive"};
+      total += ms[r];
+    }
+    // row y of the frame where the cumulative cost (piecewise linear: uniform inside a measured strip) reaches `target`
+    auto row_at = [&](double target) {
+      double acc = 0.0;
+      for (uint32_t r = 0; r < world; r++) {
+        if (acc + ms[r] >= target || r + 1 == world)
+          return bounds_in[r] + (target - acc) / ms[r] * double(bounds_in[r + 1] - bounds_in[r]);
+        acc += ms[r];
+      }
+      return double(H);
+    };
+    bounds_out[0] = 0; bounds_out[world] = H;
+    for (uint32_t r = 1; r < world; r++) {
+      const double y = row_at(total * r / world);
+      uint32_t b = uint32_t(y / align + 0.5) * align;
+      // keep every strip, the ones still to come included, at least min_rows high
+      b = std::max(b, bounds_out[r - 1] + min_rows);
+      b = std::min(b, H - (world - r) * min_rows);
+      bounds_out[r] = b;
+    }
   });
 }
 const char* vkrh_last_tasks(void* frame) { return ((PostFxFrame*)frame)->task_names.c_str(); }

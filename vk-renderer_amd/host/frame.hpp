@@ -139,6 +139,11 @@ typedef struct vkrh_tiled_config {
   uint32_t reserved;
   void*    stream;          /* compute stream                                                                */
   vkr_comm* comm;           /* RCCL communicator of include/vkr_postfx.h, or NULL (no wire: lockstep harness) */
+  /* NULL: world strips of full_height / world rows.  Otherwise world + 1 increasing row numbers, [0] = 0 and [world] =
+   * full_height, identical on every rank: strip r is rows [row_bounds[r], row_bounds[r + 1]).  Every bound is a
+   * multiple of 2^gathered_mips and of 2, every strip at least `halo` rows high.  Strips of different heights balance
+   * ranks whose rows differ in cost (vkrh_balance_rows); their shares travel with vkr_all_gather_v.                  */
+  const uint32_t* row_bounds;
 } vkrh_tiled_config;
 enum { VKRH_TILED_PHASES = 5, VKRH_GATHER_HIZ = 0, VKRH_GATHER_ALBEDO = 1, VKRH_HALO_TAA = 0, VKRH_HALO_AO = 1, VKRH_HALO_SSR = 2 };
 void* vkrh_tiled_create(const vkrh_tiled_config* cfg);
@@ -150,6 +155,10 @@ int   vkrh_tiled_flush(void* tiled);                 /* completes the halo refre
 int   vkrh_tiled_phase(void* tiled, uint32_t phase);
 int   vkrh_tiled_gather_parts(void* tiled, uint32_t which, vkr_gather_part* out, uint32_t capacity, uint32_t* count);
 int   vkrh_tiled_halo_peers(void* tiled, uint32_t surface, vkr_halo_peer* out, uint32_t capacity, uint32_t* count);
+/* New strip bounds from the compute time every rank measured with the current ones (ms[r] over rows
+ * [bounds_in[r], bounds_in[r + 1]); cost taken as uniform inside a strip): cuts the frame where the cumulative cost
+ * reaches r / world of the total, rounded to `align` rows, no strip below `min_rows`.  Pure host arithmetic.        */
+int   vkrh_balance_rows(const float* ms, const uint32_t* bounds_in, uint32_t world, uint32_t align, uint32_t min_rows, uint32_t* bounds_out);
 
 #ifdef __cplusplus
 }

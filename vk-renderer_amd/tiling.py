@@ -122,22 +122,37 @@ class HostBackend:
 
 
 class TiledFrame:
-    def __init__(self, setup, rank, world, cols, rows, device, backend="host", halo=HALO, force_tiled=False, native=False, comm=None):
+    def __init__(self, setup, rank, world, cols, rows, device, backend="host", halo=HALO, force_tiled=False, native=False, comm=None,
+                 row_bounds=None):
         """native (strips on the host backend only): the frame order, the pack / unpack launches and the exchanges run in
         C++ (host/frame.cpp TiledFrame: grouped RCCL launches on its own stream, ordered with events) — step() is one
-        call.  comm: abi.Comm, or None to drive the C++ phases from a harness (tests) / to rehearse on one rank."""
+        call.  comm: abi.Comm, or None to drive the C++ phases from a harness (tests) / to rehearse on one rank.
+        row_bounds (native strips only): world + 1 row numbers; strip r is rows [row_bounds[r], row_bounds[r + 1]) —
+        strips of different heights balance ranks whose rows differ in cost (host.balance_rows)."""
         assert cols * rows == world
         self.setup, self.rank, self.world, self.cols, self.rows_n = setup, rank, world, cols, rows
         W, H = setup.width, setup.height
         assert W % cols == 0 and H % rows == 0
         self.tw, self.th = W // cols, H // rows
         self.halo = halo if world > 1 else 0
-        self.gather_mips = gather_mips_for(self.tw, self.th, self.halo)
+        self.row_bounds = None
+        if row_bounds is not None and list(row_bounds) != [r * self.th for r in range(world + 1)]:
+            assert native and cols == 1 and len(row_bounds) == world + 1 and row_bounds[0] == 0 and row_bounds[-1] == H
+            self.row_bounds = [int(v) for v in row_bounds]
+            self.th = self.row_bounds[rank + 1] - self.row_bounds[rank]
+            self.gather_mips = GATHER_MIPS
+            while self.gather_mips > 1 and any(b % (1 << self.gather_mips) for b in self.row_bounds + [self.tw, self.halo]):
+                self.gather_mips -= 1
+            self.tile = (0, self.row_bounds[rank], self.tw, self.th)
+            y0, y1 = max(0, self.tile[1] - self.halo), min(H, self.tile[1] + self.th + self.halo)
+            self.window = (0, y0, W, y1 - y0)
+        else:
+            self.gather_mips = gather_mips_for(self.tw, self.th, self.halo)
+            self.tile = tile_rect(rank, cols, rows, self.tw, self.th)
+            self.window = window_rect(rank, cols, rows, self.tw, self.th, self.halo)
         if world > 1:
             assert self.tw % 2 == 0 and self.th % 2 == 0, "tile extent must be even"
             assert self.halo % 2 == 0 and self.halo <= min(self.tw, self.th)
-        self.tile = tile_rect(rank, cols, rows, self.tw, self.th)
-        self.window = window_rect(rank, cols, rows, self.tw, self.th, self.halo)
         # force_tiled: run the multi-GPU code path (gathers, whole-frame Hi-Z, staged frame) on one rank
         self.tiled = world > 1 or force_tiled
         # "host": the C++ host mirror on the GPU; anything else: a class with HostBackend's interface
@@ -146,7 +161,7 @@ class TiledFrame:
             assert backend == "host" and cols == 1, "the C++ tiled frame cuts horizontal strips"
             self.backend = HostBackend(setup, self.window, self.tiled, device,
                                        native=dict(rank=rank, world=world, halo=self.halo, gathered_mips=self.gather_mips,
-                                                   force_tiled=force_tiled, comm=comm))
+                                                   force_tiled=force_tiled, comm=comm, row_bounds=self.row_bounds))
         else:
             cls = HostBackend if backend == "host" else backend
             self.backend = cls(setup, self.window, self.tiled, device)
@@ -487,3 +502,57 @@ class RectBatch:
             return
         lib = abi.product()
         abi.check(lib.vkr_copy_rects(self.table, len(self.pairs), torch.cuda.current_stream(self.device).cuda_stream), lib)
+
+
+# ---- lockstep harness for the C++ tiled frame (tests, tools/lockstep_profile.py): all ranks of a grid on ONE GPU ------------
+def _bytes_at(ranks, addr, nbytes):
+    """uint8 view of device memory [addr, addr + nbytes) owned by one of the ranks' allocators"""
+    for t in ranks:
+        try:
+            tensor, off = t.frame.allocator.tensor_at(addr)
+        except KeyError:
+            continue
+        assert off + nbytes <= tensor.numel()
+        return tensor[off: off + nbytes]
+    raise KeyError(hex(addr))
+
+
+def _move_gather(ranks, which):
+    """what vkr_all_gather / vkr_all_gather_v deliver: every rank's share of a surface, in rank order, into every rank's
+    recv (shares are whole rows of consecutive strips, so share r starts where the shares before it end)"""
+    parts = [t.frame.tiled_gather_parts(which) for t in ranks]
+    for r, mine in enumerate(parts):
+        for i, (_, recv, _) in enumerate(mine):
+            offset = 0
+            for theirs in parts:
+                send, _, nbytes = theirs[i]
+                _bytes_at(ranks, recv + offset, nbytes).copy_(_bytes_at(ranks, send, nbytes))
+                offset += nbytes
+
+
+def _move_halo(ranks, surface):
+    """what vkr_halo_exchange delivers: every receive buffer gets the send buffer its peer packed for this rank"""
+    peers = [t.frame.tiled_halo_peers(surface) for t in ranks]
+    for r, mine in enumerate(peers):
+        for peer, _, recv, nbytes in mine:
+            send = [p for p in peers[peer] if p[0] == r][0][1]
+            _bytes_at(ranks, recv, nbytes).copy_(_bytes_at(ranks, send, nbytes))
+
+
+def native_lockstep_frame(ranks):
+    """One frame of every in-process rank of a strip grid (C++ tiled frames made with native=True, comm=None), advanced
+    phase by phase; between phases the harness copies exactly the buffers the RCCL calls would move."""
+    for p in range(5):
+        for t in ranks:
+            t.frame.tiled_phase(p)
+        if p == 0:      # both gathers start after the downsample; the harness completes them at once
+            _move_gather(ranks, 0)
+            _move_gather(ranks, 1)
+        elif p == 1:
+            _move_halo(ranks, 0)
+        elif p == 3:
+            _move_halo(ranks, 1)
+        elif p == 4:
+            _move_halo(ranks, 2)
+    for t in ranks:
+        t._frame_no += 1
