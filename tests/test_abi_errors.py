@@ -103,3 +103,14 @@ def test_error_string_is_replaced_by_the_next_failure(lib):
     first = lib.vkr_last_error()
     taa(lib, velocity=img(abi.FMT_RG16_UNORM, 64, 32))
     assert lib.vkr_last_error() != first
+
+
+def test_exchange_entries_refuse_missing_arguments(lib):
+    """vkr_all_gather / vkr_all_gather_v / vkr_halo_exchange: nothing to do is fine, a missing communicator is an error
+    (before RCCL is even loaded)."""
+    for name in ("vkr_all_gather", "vkr_all_gather_v", "vkr_halo_exchange"):
+        fn = getattr(lib, name)
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        fn.restype = C.c_int
+        assert fn(None, None, 0, None) == 0
+        assert fn(None, None, 1, None) == ERR_NULL and b"NULL" in lib.vkr_last_error()
