@@ -2,7 +2,8 @@
 //
 // Reference: src/taa.cpp:19-63 + shaders/taa/resolve.comp:20-77.  Full resolution;
 // the largest byte mover of the chain: 32 B per pixel (history 8 + prev_depth 4 + depth 4 +
-// velocity 4 + colour 4 read, target 8 written).  Roofline: HBM.
+// velocity 4 + colour 4 read, target 8 written).  Roofline: HBM in the compulsory model; in practice the pass sits
+// between its VALU and texture-address limits (DESIGN.md section 3 "TAA"), hence the shared footprints and wide loads.
 #include <cstdlib>
 #include "vkr_host.hpp"
 
@@ -22,8 +23,6 @@ inline float sqrt_threshold(float limit) {
   while (sqrtf(x) < limit) x = nextafterf(x, 1.0f);
   return x;
 }
-
-VKR_DEV f3 rgb(f4 v) { return mk3(v.x, v.y, v.z); }
 
 // Byte offsets (4-byte texels) and weights of the bilinear footprint of texture(t, uv): what sample<F>() computes
 // before it loads.  Images that share one window geometry and pitch share the whole record.
@@ -171,8 +170,7 @@ extern "C" int vkr_taa_resolve(const vkr_img* history_color, const vkr_img* hist
   a.pr.znear = params->fovy_aspect_znear_zfar[2];
   a.pr.zfar = params->fovy_aspect_znear_zfar[3];
   a.still_d2 = sqrt_threshold(0.005f);
-  const bool shared = same_window(a.color, a.velocity) && same_window(a.color, a.cur_depth) && a.color.pitch == a.velocity.pitch &&
-                      a.color.pitch == a.cur_depth.pitch && !getenv("VKR_TAA_GENERIC");
+  const bool shared = same_layout(a.color, a.velocity) && same_layout(a.color, a.cur_depth) && !getenv("VKR_TAA_GENERIC");
   dim3 block(64, 4);
   if (shared) hipLaunchKernelGGL(k_taa_resolve<true>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_taa_resolve<false>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
