@@ -266,7 +266,11 @@ def main():
             frame.enable_task_timing(False)
             every = [None] * world
             dist.all_gather_object(every, float(mine))
-            new_bounds = host.balance_rows(every, row_bounds, align=16, min_rows=max(256, H // (4 * world) // 16 * 16))
+            try:
+                new_bounds = host.balance_rows(every, row_bounds, align=16, min_rows=max(256, H // (4 * world) // 16 * 16))
+            except RuntimeError as e:  # e.g. a --frame whose height is not a multiple of 16: the same on every rank, keep the strips
+                print(f"[bench] strips not re-cut: {e}", file=sys.stderr)
+                new_bounds = row_bounds
             balance_log.append({"rows": [row_bounds[r + 1] - row_bounds[r] for r in range(world)], "compute_ms": [round(v, 4) for v in every]})
             if new_bounds == row_bounds and not force_rebuild:
                 break
