@@ -149,8 +149,13 @@ def test_c5_eight_rays_per_pixel_loop(oracle_lib, parity_table):
     frame.close()
 
 
-def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame():
-    """BASELINE configs[3] exactly as bench.py --gpus 8 cuts and drives it: eight 15360x1080 strips (+ 48 px halo, Hi-Z
+BALANCED_C4 = [0, 1552, 3136, 4400, 5312, 6144, 6960, 7776, 8640]  # what vkrh_balance_rows cuts for this frame (profiles/r02_final_strip_balance_c4.json)
+
+
+@pytest.mark.parametrize("bounds", [None, BALANCED_C4], ids=["equal_strips", "balanced_strips"])
+def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame(bounds):
+    """BASELINE configs[3] exactly as bench.py --gpus 8 cuts and drives it (equal strips first; then the cost-balanced
+    strips it re-cuts the frame into before timing, whose shares travel with vkr_all_gather_v): eight 15360x1080 strips (+ 48 px halo, Hi-Z
     mips 1..3 gathered) through the C++ tiled frame (host/frame.cpp: the frame order, pack / unpack launches and exchange
     points of the production path), every rank in-process on the one GPU with the wire played by copies of the very
     buffers the RCCL calls would move.  Two frames; tile interiors against the plain 15360x8640 frame.  Surfaces no
@@ -169,10 +174,10 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame():
     device = torch.device("cuda", 0)
     frames = 2
 
-    def crop(t, y0, dv):  # tile rows of a [rows, row bytes] uint8 view whose first row is frame row oy
+    def crop(t, y0, dv, rows_n):  # tile rows of a [rows, row bytes] uint8 view whose first row is frame row oy
         rows_t, bpp, (ox, oy, w, h) = t
         assert ox == 0
-        return rows_t[(y0 >> dv) - oy: (y0 >> dv) - oy + (th >> dv), : w * bpp]
+        return rows_t[(y0 >> dv) - oy: (y0 >> dv) - oy + (rows_n >> dv), : w * bpp]
 
     plain = TiledFrame(FrameSetup(W, H), 0, 1, 1, 1, device)
     plain.prepare()
@@ -188,9 +193,10 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame():
     del plain
     torch.cuda.empty_cache()
 
-    ranks = [TiledFrame(FrameSetup(W, H), r, world, cols, rows, device, native=True, comm=None) for r in range(world)]
+    ranks = [TiledFrame(FrameSetup(W, H), r, world, cols, rows, device, native=True, comm=None, row_bounds=bounds) for r in range(world)]
     for t in ranks:
-        assert t.tiled and t.native and t.halo == 48 and t.gather_mips == 3 and t.window[2:] in ((W, th + 48), (W, th + 96))
+        assert t.tiled and t.native and t.halo == 48 and t.window[2:] in ((W, t.th + 48), (W, t.th + 96))
+        assert t.gather_mips == (3 if bounds is None else 4) and (bounds is None) == (t.th == th)
         t.prepare()
     for _ in range(frames):
         lockstep_frame(ranks)
@@ -203,8 +209,8 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame():
     for r, t in enumerate(ranks):
         _, y0, _, _ = t.tile
         for name, dv in OUTPUTS:
-            got = crop(t.backend.rows(name), y0, dv)
-            ref = crop(want[name], y0, dv)
+            got = crop(t.backend.rows(name), y0, dv, t.th)
+            ref = crop(want[name], y0, dv, t.th)
             bpp = want[name][1]
             diff = (got != ref).view(got.shape[0], -1, bpp)
             if name == "depth":  # D24S8: the stencil byte is not part of the comparison
@@ -214,14 +220,14 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame():
             texels[name] += got.shape[0] * (got.shape[1] // bpp)
             if n:
                 where = diff.any(dim=-1).nonzero()[:8].tolist()  # (row inside the tile, column), in the surface's own resolution
-                print(f"[deviation] rank {r} {name}: {n} texels differ from the one-GPU frame, e.g. tile row / column {where} (tile rows {th >> dv})")
+                print(f"[deviation] rank {r} {name}: {n} texels differ from the one-GPU frame, e.g. tile row / column {where} (tile rows {t.th >> dv})")
         t.frame.close()
-    report_d = {"frame": [W, H], "grid": [cols, rows], "halo_px": 48, "frames": frames,
+    report_d = {"frame": [W, H], "grid": [cols, rows], "strip_rows": [t.th for t in ranks], "halo_px": 48, "frames": frames,
                 "differing_texels": counts, "compared_texels": texels}
     print("[deviation] " + json.dumps(report_d))
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "deviation_c4.json"), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "deviation_c4.json" if bounds is None else "deviation_c4_balanced.json"), "w") as f:
             json.dump(report_d, f, indent=1)
     except OSError:
         pass
