@@ -290,10 +290,23 @@ def main():
     # of queue time, and nine pairs per frame would slow the 1 ms frame that is being measured by 7 %.
     CAL_STEPS = 10
     frame.enable_task_timing(True)
+    timed_waits = tiled.native and frame.tiled_handle is not None and comm is not None
+    if timed_waits:  # how long the compute stream stands still for each exchange (diagnostics of the multi-GPU wire)
+        frame.tiled_time_waits(True)
     for _ in range(CAL_STEPS):
         tiled.step()
     tiled.flush()
     barrier()
+    exchange_wait_ms = None
+    if timed_waits:
+        mine = {k: v / CAL_STEPS for k, v in frame.tiled_wait_times().items()}
+        frame.tiled_time_waits(False)
+        every = [None] * world
+        if world > 1:
+            dist.all_gather_object(every, mine)
+        else:
+            every = [mine]
+        exchange_wait_ms = {k: [round(e[k], 4) for e in every] for k in mine}  # per rank
     calibration = frame.collect_task_times()
     per_pass_ms = {k: v[0] / CAL_STEPS for k, v in calibration.items()}          # all executions of the task in one step
     launches_per_step = {k: v[1] / CAL_STEPS for k, v in calibration.items()}    # executions of the task per step (c5: 8 x SSR)
@@ -402,6 +415,8 @@ def main():
             "per_pass_gbps": {k: BYTES_PER_PX[k] * tile_px * launches_per_step[k] / (v * 1e-3) / 1e9
                               for k, v in per_pass_ms.items() if k in BYTES_PER_PX and v > 0},
             "exchange_ms": tiled.exchange_ms(args.steps),
+            # calibration run: ms per frame every rank's compute stream stood still for each exchange (None: no wire)
+            "exchange_wait_ms": exchange_wait_ms,
             "measured_read_gbps": measured_read,
         }
         if step_ms:  # median of >= 50 hipEvent-timed frames, beside the contract's wall-clock mean

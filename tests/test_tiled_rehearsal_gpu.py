@@ -66,3 +66,6 @@ def test_bench_rebuilds_the_frame_on_balanced_strips():
     assert res["config"]["strip_rows"] == [576]
     assert len(res["config"]["strip_balance"]) == 2 and all(p["rows"] == [576] and p["compute_ms"][0] > 0 for p in res["config"]["strip_balance"])
     assert res["value"] > 0
+    # the calibration run reports how long the compute stream stood still for each exchange, per rank
+    assert set(res["exchange_wait_ms"]) == {"hiz_gather", "albedo_gather", "taa_halo", "ao_halo", "ssr_halo"}
+    assert all(len(v) == 1 and 0 <= v[0] < 1.0 for v in res["exchange_wait_ms"].values())

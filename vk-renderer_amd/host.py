@@ -98,6 +98,8 @@ def lib():
         l.vkrh_tiled_phase.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_tiled_gather_parts.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(GatherPart), C.c_uint32, C.POINTER(C.c_uint32)]
         l.vkrh_tiled_halo_peers.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(HaloPeer), C.c_uint32, C.POINTER(C.c_uint32)]
+        l.vkrh_tiled_time_waits.argtypes = [C.c_void_p, C.c_uint32]
+        l.vkrh_tiled_wait_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.vkrh_balance_rows.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         l.vkrh_balance_rows.restype = C.c_int
         _lib = l
@@ -322,6 +324,15 @@ class HostFrame:
 
     def tiled_phase(self, p):
         self._check(lib().vkrh_tiled_phase(self.tiled_handle, p))
+
+    def tiled_time_waits(self, on=True):
+        self._check(lib().vkrh_tiled_time_waits(self.tiled_handle, 1 if on else 0))
+
+    def tiled_wait_times(self):
+        """{exchange: ms the compute stream stood still for it since the last call} (frame.hpp vkrh_tiled_wait_times)"""
+        out = (C.c_float * 5)()
+        self._check(lib().vkrh_tiled_wait_times(self.tiled_handle, out))
+        return dict(zip(("hiz_gather", "albedo_gather", "taa_halo", "ao_halo", "ssr_halo"), [float(v) for v in out]))
 
     def tiled_gather_parts(self, which):
         """[(send address, recv address, bytes)] of all-gather `which` (0: Hi-Z mips + normals, 1: albedo)"""

@@ -348,8 +348,37 @@ struct TiledFrame {
     if (issue() != 0) throw std::runtime_error {std::string {"exchange: "} + vkr_last_error()};
     check(hipEventRecord(ev_done[slot], xchg), "event record");
   }
+  // Exposed waiting (diagnostics, vkrh_tiled_wait_times): with wait timing on, an event pair on the compute stream brackets
+  // every wait for an exchange — the second event cannot complete before the exchange has, so the pair measures how long
+  // the compute stream actually stood still for it (0 when the bytes had already arrived).
+  bool time_waits = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> wait_marks[5];
   void wait(int slot) {
-    if (cfg.comm) check(hipStreamWaitEvent(compute, ev_done[slot], 0), "stream wait");
+    if (!cfg.comm) return;
+    hipEvent_t before = nullptr, after = nullptr;
+    if (time_waits) {
+      check(hipEventCreate(&before), "event"); check(hipEventCreate(&after), "event");
+      check(hipEventRecord(before, compute), "event record");
+    }
+    check(hipStreamWaitEvent(compute, ev_done[slot], 0), "stream wait");
+    if (time_waits) {
+      check(hipEventRecord(after, compute), "event record");
+      wait_marks[slot].emplace_back(before, after);
+    }
+  }
+  // total exposed wait per exchange since the last call, ms: [hiz, albedo, taa halo, ao halo, ssr halo]; synchronises
+  void collect_waits(float out[5]) {
+    check(hipStreamSynchronize(compute), "synchronize");
+    for (int s = 0; s < 5; s++) {
+      out[s] = 0.0f;
+      for (auto& m : wait_marks[s]) {
+        float ms = 0.0f;
+        check(hipEventElapsedTime(&ms, m.first, m.second), "event elapsed");
+        out[s] += ms;
+        (void)hipEventDestroy(m.first); (void)hipEventDestroy(m.second);
+      }
+      wait_marks[s].clear();
+    }
   }
   void start_gather(int which) {
     start(which, [&] {
@@ -710,6 +739,13 @@ int vkrh_tiled_halo_peers(void* tiled, uint32_t surface, vkr_halo_peer* out, uin
   return guarded([&] {
     if (!tiled || !out || !count || capacity < 2 || surface > 2) throw std::runtime_error{"vkrh_tiled_halo_peers: bad arguments (capacity >= 2)"};
     *count = ((TiledFrame*)tiled)->halo_peers((int)surface, out);
+  });
+}
+int vkrh_tiled_time_waits(void* tiled, uint32_t on) { return guarded([&] { ((TiledFrame*)tiled)->time_waits = on != 0; }); }
+int vkrh_tiled_wait_times(void* tiled, float* ms5) {
+  return guarded([&] {
+    if (!tiled || !ms5) throw std::runtime_error{"vkrh_tiled_wait_times: NULL argument"};
+    ((TiledFrame*)tiled)->collect_waits(ms5);
   });
 }
 int vkrh_balance_rows(const float* ms, const uint32_t* bounds_in, uint32_t world, uint32_t align, uint32_t min_rows, uint32_t* bounds_out) {

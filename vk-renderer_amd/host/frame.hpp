@@ -155,6 +155,12 @@ int   vkrh_tiled_flush(void* tiled);                 /* completes the halo refre
 int   vkrh_tiled_phase(void* tiled, uint32_t phase);
 int   vkrh_tiled_gather_parts(void* tiled, uint32_t which, vkr_gather_part* out, uint32_t capacity, uint32_t* count);
 int   vkrh_tiled_halo_peers(void* tiled, uint32_t surface, vkr_halo_peer* out, uint32_t capacity, uint32_t* count);
+/* Diagnostics: how long the compute stream stood still for each exchange.  vkrh_tiled_time_waits(on) brackets every wait
+ * with an event pair (≈7 us of queue time per frame: for a calibration run, not for the timed one);
+ * vkrh_tiled_wait_times returns the totals since the last call in ms — [0] Hi-Z gather, [1] albedo gather, [2] TAA halo,
+ * [3] AO halo, [4] SSR halo — and synchronises the compute stream.                                                    */
+int   vkrh_tiled_time_waits(void* tiled, uint32_t on);
+int   vkrh_tiled_wait_times(void* tiled, float* ms5);
 /* New strip bounds from the compute time every rank measured with the current ones (ms[r] over rows
  * [bounds_in[r], bounds_in[r + 1]); cost taken as uniform inside a strip): cuts the frame where the cumulative cost
  * reaches r / world of the total, rounded to `align` rows, no strip below `min_rows`.  Pure host arithmetic.        */
