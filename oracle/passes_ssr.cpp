@@ -79,6 +79,12 @@ struct TraceCtx {
   const vkr_trace_params& p;
 };
 
+// instrumentation for tools/trace_sim.py (lane-utilisation studies of the product kernel's schedule): when a sink is
+// set, the march stores the number of steps every ray took (row pitch = sink_pitch bytes, window coordinates)
+uint8_t* g_step_sink = nullptr;
+int g_step_sink_pitch = 0;
+thread_local uint32_t t_last_steps = 0;
+
 // trace.comp:206-268
 vec3 hierarchical_raymarch_find_hor(const TraceCtx& c, vec3 origin, vec3 direction, int most_detailed_mip,
                                     uint32_t max_traversal_intersections, bool& valid_hit, vec3 w0,
@@ -112,10 +118,13 @@ vec3 hierarchical_raymarch_find_hor(const TraceCtx& c, vec3 origin, vec3 directi
     }
   }
   valid_hit = (i <= max_traversal_intersections);
+  t_last_steps = i;
   return position;
 }
 
 }  // namespace
+
+extern "C" void vkr_ref_set_step_sink(uint8_t* sink, int pitch_bytes) { g_step_sink = sink; g_step_sink_pitch = pitch_bytes; }
 
 // trace.comp:41-141
 extern "C" int vkr_ref_sssr_trace(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
@@ -173,6 +182,7 @@ extern "C" int vkr_ref_sssr_trace(const vkr_img* depth, const vkr_img* normal, c
       vec3 w0 = -normalize(view_vec);
 
       vec3 out_r = hierarchical_raymarch_find_hor(c, ray_start, ray_dir, 0, 80, valid_hit, pixel_normal, view_vec, h);
+      if (g_step_sink) g_step_sink[(size_t)ly * g_step_sink_pitch + lx] = (uint8_t)t_last_steps;
 
       if (valid_hit) {
         vec2 ray_step = abs(out_r.xy() - ray_start.xy()) * tex_size;

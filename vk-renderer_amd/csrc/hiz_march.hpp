@@ -24,6 +24,16 @@ struct MarchEnv {
   int min_mip = 0;   // most_detailed_mip: the march ends when it would refine below it; uv_offset_abs carries its 2^min_mip
 };
 
+// The horizon update of trace.comp:253-262: v = reconstruct_view_vec(uv, surface_z) - camera_start, h = max(h, cos) iff
+// |v| < 0.3.  z stays on the exact quotient (div_normal): v is a small difference of two view-space positions, so a
+// 2^-22 relative error of z (v_rcp_f32 instead of the refined quotient) is an error of |P| / |v| * 2^-22 — 1e-4 to 1e-3 —
+// in the cosine, measured as 49 texels of the 4K `raw` image outside tolerance.  Only the final 1 / |v| is approximate.
+VKR_DEV void horizon_gate(const MarchEnv& env, const RayConst& rc, RayState& st, f2 uv, float surface_z) {
+  const f3 v = reconstruct_view_vec(uv, surface_z, env.pr) - rc.view_vec;
+  const float d2 = dot(v, v);
+  if (d2 < env.horizon_d2) st.h = vmax(st.h, dot(rc.normal, v) * __builtin_amdgcn_rsqf(d2));  // length(v) < 0.3, decided exactly on the squared length
+}
+
 // One step of the march; returns false when the ray is finished.  HORIZON / PIN_STEPS = 15 / max 80 is
 // hierarchical_raymarch_find_hor (trace.comp:206-268); no horizon / PIN_STEPS = 0 is the generic
 // hierarchical_raymarch (screen_trace.glsl:51-100).
@@ -61,19 +71,32 @@ VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, i
   if (st.i >= PIN_STEPS) st.mip += skipped_tile ? 1 : -1;
   ++st.i;
   // trace.comp:253-262: horizon tracking around the new position
-  if (HORIZON && st.mip <= 1) {
-    const f3 np = madd(rc.origin, st.t, rc.direction);
-    const f3 v = reconstruct_view_vec(xy(np), surface_z, env.pr) - rc.view_vec;
-    const float d2 = dot(v, v);
-    if (d2 < env.horizon_d2) {  // length(v) < 0.3, decided exactly on the squared length
-      // h only feeds acos() of the (smooth) occlusion term: the hardware rsq is accurate enough
-      const float h2 = dot(rc.normal, v) * __builtin_amdgcn_rsqf(d2);
-      st.h = vmax(st.h, h2);
-    }
-  }
+  if (HORIZON && st.mip <= 1) horizon_gate(env, rc, st, madd(xy(rc.origin), st.t, xy(rc.direction)), surface_z);
   return st.i < max_steps && st.mip >= env.min_mip;
 }
 
+
+// One of the PINNED steps of hierarchical_raymarch_find_hor (trace.comp:245-250: while i < 15 the march stays on its
+// mip): march_step<true, 15> for a ray with st.mip == 0 and st.i < 15, with everything that is then known folded in —
+// the level scale is 2^0 (res = screen_size, the same floats), the mip does not change, the horizon update always
+// runs (mip 0 <= 1), the ray cannot end.  fetch0(tx, ty) returns texel (tx, ty) of pyramid level 0, 0 outside it.
+template <class Fetch0>
+VKR_DEV void march_step_pinned0(const MarchEnv& env, const RayConst& rc, RayState& st, const Fetch0& fetch0) {
+  const f3 position = madd(rc.origin, st.t, rc.direction);
+  const f2 mip_pos = env.screen_size * xy(position);
+  const float surface_z = fetch0(f2i(mip_pos.x), f2i(mip_pos.y));
+  const f2 uv_offset = mk2(rc.direction.x < 0.0f ? -env.uv_offset_abs.x : env.uv_offset_abs.x,
+                           rc.direction.y < 0.0f ? -env.uv_offset_abs.y : env.uv_offset_abs.y);
+  const f2 floor_offset = mk2(rc.direction.x < 0.0f ? 0.0f : 1.0f, rc.direction.y < 0.0f ? 0.0f : 1.0f);
+  f2 xy_plane = mk2(floorf(mip_pos.x), floorf(mip_pos.y)) + floor_offset;
+  xy_plane = mk2(cfma(xy_plane.x, env.screen_size_inv.x, uv_offset.x), cfma(xy_plane.y, env.screen_size_inv.y, uv_offset.y));
+  f3 t = (mk3(xy_plane.x, xy_plane.y, surface_z) - rc.origin) * rc.inv_direction;
+  t.z = rc.direction.z > 0.0f ? t.z : 3.402823466e+38f;
+  const float t_min = vmin(vmin(t.x, t.y), t.z);
+  st.t = surface_z > position.z ? t_min : st.t;
+  ++st.i;
+  horizon_gate(env, rc, st, madd(xy(rc.origin), st.t, xy(rc.direction)), surface_z);
+}
 
 // the LDS descriptor of one pyramid level
 VKR_DEV uint4 mip_descriptor(const Tex& m) {

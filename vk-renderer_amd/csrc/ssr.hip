@@ -53,6 +53,43 @@ struct TraceArgs {
   float f_over_fn;
 };
 
+#define TP_VEC 5  // uint4 per parked-ray record (18 dwords used): 80-byte stride, conflict-free for consecutive rays
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // one ds_read_b128
+VKR_DEV uint4 lds_load4(const uint4* p) { const u32x4 v = *(const u32x4*)p; return make_uint4(v.x, v.y, v.z, v.w); }
+// four scalar stores that the backend merges into one ds_write_b128 (a vector built in the source from struct members
+// makes the optimiser keep the struct in scratch memory)
+VKR_DEV void lds_store4(uint4* p, uint4 v) { *p = v; }
+VKR_DEV int wave_rank(uint64_t mask) {  // number of set bits of `mask` below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// record: vector k holds members k, k + 5, k + 10, k + 15 of (origin 0-2, direction 3-5, inv_direction 6-8, normal 9-11,
+// view_vec 12-14, t 15, h 16, mip | i << 8 17) — never four neighbours of the struct in one vector (see lds_store4)
+VKR_DEV void pool_store(uint4* p, const RayConst& c, const RayState& s) {
+  lds_store4(p + 0, make_uint4(__float_as_uint(c.origin.x), __float_as_uint(c.direction.z), __float_as_uint(c.normal.y), __float_as_uint(s.t)));
+  lds_store4(p + 1, make_uint4(__float_as_uint(c.origin.y), __float_as_uint(c.inv_direction.x), __float_as_uint(c.normal.z), __float_as_uint(s.h)));
+  lds_store4(p + 2, make_uint4(__float_as_uint(c.origin.z), __float_as_uint(c.inv_direction.y), __float_as_uint(c.view_vec.x), (uint32_t)(s.mip & 0xFF) | ((uint32_t)s.i << 8)));
+  lds_store4(p + 3, make_uint4(__float_as_uint(c.direction.x), __float_as_uint(c.inv_direction.z), __float_as_uint(c.view_vec.y), 0u));
+  lds_store4(p + 4, make_uint4(__float_as_uint(c.direction.y), __float_as_uint(c.normal.x), __float_as_uint(c.view_vec.z), 0u));
+}
+VKR_DEV void pool_load(const uint4* p, RayConst& c, RayState& s) {
+  const uint4 a = lds_load4(p), b = lds_load4(p + 1), d = lds_load4(p + 2), e = lds_load4(p + 3), f = lds_load4(p + 4);
+  c.origin = mk3(__uint_as_float(a.x), __uint_as_float(b.x), __uint_as_float(d.x));
+  c.direction = mk3(__uint_as_float(e.x), __uint_as_float(f.x), __uint_as_float(a.y));
+  c.inv_direction = mk3(__uint_as_float(b.y), __uint_as_float(d.y), __uint_as_float(e.y));
+  c.normal = mk3(__uint_as_float(f.y), __uint_as_float(a.z), __uint_as_float(b.z));
+  c.view_vec = mk3(__uint_as_float(d.z), __uint_as_float(e.z), __uint_as_float(f.z));
+  s.t = __uint_as_float(a.w); s.h = __uint_as_float(b.w);
+  s.mip = (int)(int8_t)(d.w & 0xFFu); s.i = (int)(d.w >> 8);
+}
+VKR_DEV void pool_store_state(uint4* p, const RayState& s) {
+  uint32_t* w = (uint32_t*)p;
+  w[3] = __float_as_uint(s.t); w[7] = __float_as_uint(s.h); w[11] = (uint32_t)(s.mip & 0xFF) | ((uint32_t)s.i << 8);
+}
+VKR_DEV void pool_load_result(const uint4* p, RayState& s) {
+  const uint32_t* w = (const uint32_t*)p;
+  s.t = __uint_as_float(w[3]); s.h = __uint_as_float(w[7]);
+}
+
 // One thread per ray in the prologue / epilogue; the march in between runs in rounds of
 // TRACE_ROUND steps with the block's unfinished rays compacted in LDS between rounds, because
 // rays of one 8x8 tile finish anywhere between 16 and 80 steps (mean 30, per-wave maximum mean 59
@@ -70,8 +107,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   const i2 blk = xcd_block<4, 8 / TRACE_WY>();  // chunks of 128 x 64 output pixels
   __shared__ uint4 s_mip[16];
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
-  __shared__ float s_rc[17][TRACE_THREADS];     // RayConst (15) + t + h of unfinished rays
-  __shared__ int s_mi[TRACE_THREADS];           // mip | i << 8
+  __shared__ uint4 s_ray[TRACE_THREADS * TP_VEC];  // record of ray (= owner thread) r: RayConst, t, h, mip | i << 8
   __shared__ uint16_t s_list[2][TRACE_THREADS];
   __shared__ int s_count[2];
   const int tid = threadIdx.x;
@@ -145,23 +181,26 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
     st.h = 0.0f;  // trace.comp:239
     st.mip = 0;
     st.i = 0;
-    // round 0: the first 15 steps never leave mip 0, so every ray runs exactly 16 steps here
-    running = true;
+    // round 0: the first 15 steps never leave mip 0 (specialised step), step 16 (i = 15) is the first that may
+    {
+      const auto fetch0 = [&](int x, int y) -> float {
+        return (x >= 0 && y >= 0 && x < depth0.w && y < depth0.h) ? d24_to_float(*(const uint32_t*)(depth0.p + toff(depth0, x, y, 4))) : 0.0f;
+      };
 #pragma unroll 1
-    for (int k = 0; k < TRACE_PIN_ROUND && running; k++) running = march_step<true, 15>(env, rc, st, 80);
+      for (int k = 0; k < 15; k++) march_step_pinned0(env, rc, st, fetch0);
+    }
+    running = march_step<true, 15>(env, rc, st, 80);
   }
-  // park the unfinished rays in LDS
-  if (running) {
-    const int slot = atomicAdd(&s_count[0], 1);
-    s_list[0][slot] = (uint16_t)tid;
-    float* p = &s_rc[0][tid];
-    p[0 * TRACE_THREADS] = rc.origin.x; p[1 * TRACE_THREADS] = rc.origin.y; p[2 * TRACE_THREADS] = rc.origin.z;
-    p[3 * TRACE_THREADS] = rc.direction.x; p[4 * TRACE_THREADS] = rc.direction.y; p[5 * TRACE_THREADS] = rc.direction.z;
-    p[6 * TRACE_THREADS] = rc.inv_direction.x; p[7 * TRACE_THREADS] = rc.inv_direction.y; p[8 * TRACE_THREADS] = rc.inv_direction.z;
-    p[9 * TRACE_THREADS] = rc.normal.x; p[10 * TRACE_THREADS] = rc.normal.y; p[11 * TRACE_THREADS] = rc.normal.z;
-    p[12 * TRACE_THREADS] = rc.view_vec.x; p[13 * TRACE_THREADS] = rc.view_vec.y; p[14 * TRACE_THREADS] = rc.view_vec.z;
-    p[15 * TRACE_THREADS] = st.t; p[16 * TRACE_THREADS] = st.h;
-    s_mi[tid] = st.mip | (st.i << 8);
+  // park the unfinished rays in LDS (one list reservation per wave: rank within the ballot)
+  {
+    const uint64_t rm = __ballot(running);
+    int base = 0;
+    if (lane == 0 && rm) base = atomicAdd(&s_count[0], __popcll(rm));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (running) {
+      s_list[0][base + wave_rank(rm)] = (uint16_t)tid;
+      pool_store(s_ray + tid * TP_VEC, rc, st);
+    }
   }
   // compacted rounds: thread k of the block advances the k-th unfinished ray by TRACE_ROUND steps
   for (int cur = 0;; cur ^= 1) {
@@ -170,32 +209,28 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
     if (n == 0) break;
     if (tid == 0) s_count[cur ^ 1] = 0;
     __syncthreads();
+    bool more = false;
+    int ray = 0;
     if (tid < n) {
-      const int ray = s_list[cur][tid];
-      const float* p = &s_rc[0][ray];
+      ray = s_list[cur][tid];
       RayConst q;
-      q.origin = mk3(p[0 * TRACE_THREADS], p[1 * TRACE_THREADS], p[2 * TRACE_THREADS]);
-      q.direction = mk3(p[3 * TRACE_THREADS], p[4 * TRACE_THREADS], p[5 * TRACE_THREADS]);
-      q.inv_direction = mk3(p[6 * TRACE_THREADS], p[7 * TRACE_THREADS], p[8 * TRACE_THREADS]);
-      q.normal = mk3(p[9 * TRACE_THREADS], p[10 * TRACE_THREADS], p[11 * TRACE_THREADS]);
-      q.view_vec = mk3(p[12 * TRACE_THREADS], p[13 * TRACE_THREADS], p[14 * TRACE_THREADS]);
       RayState rs;
-      rs.t = p[15 * TRACE_THREADS]; rs.h = p[16 * TRACE_THREADS];
-      const int mi = s_mi[ray];
-      rs.mip = (int)(int8_t)(mi & 0xFF); rs.i = mi >> 8;
-      bool more = true;
+      pool_load(s_ray + ray * TP_VEC, q, rs);
+      more = true;
 #pragma unroll 1
       for (int k = 0; k < TRACE_ROUND && more; k++) more = march_step<true, 15>(env, q, rs, 80);
-      s_rc[15][ray] = rs.t; s_rc[16][ray] = rs.h;
-      s_mi[ray] = (rs.mip & 0xFF) | (rs.i << 8);
-      if (more) {
-        const int slot = atomicAdd(&s_count[cur ^ 1], 1);
-        s_list[cur ^ 1][slot] = (uint16_t)ray;
-      }
+      pool_store_state(s_ray + ray * TP_VEC, rs);
+    }
+    const uint64_t mm = __ballot(more);
+    if (mm) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_count[cur ^ 1], __popcll(mm));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (more) s_list[cur ^ 1][base + wave_rank(mm)] = (uint16_t)ray;
     }
   }
   if (!active) return;
-  if (running) { st.t = s_rc[15][tid]; st.h = s_rc[16][tid]; }  // this thread's ray was finished by another lane
+  if (running) pool_load_result(s_ray + tid * TP_VEC, st);  // this thread's ray was finished by another lane
   const f3 out_ray = madd(rc.origin, st.t, rc.direction);
   const float h = st.h;
   const f3 pixel_normal = rc.normal, view_vec = rc.view_vec;
