@@ -163,12 +163,15 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
         want_torch = os.environ.get("VKR_EXCHANGE") == "torch"
-        if share_gpu:  # RCCL refuses two ranks on one device: host-staged gloo exchange through tiling.py
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            exchange = "torch.distributed gloo, host-staged (one-GPU rehearsal)"
-        elif want_torch:
+        # On a shared GPU real RCCL refuses two ranks on one device: the native wire then needs VKR_RCCL_LIBRARY to name a
+        # stand-in (tests/stub_rccl: host-staged through shared memory); without one the rehearsal goes through tiling.py on gloo.
+        native_possible = not share_gpu or bool(os.environ.get("VKR_RCCL_LIBRARY"))
+        if want_torch and not share_gpu:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
             exchange = "torch.distributed RCCL (VKR_EXCHANGE=torch)"
+        elif not native_possible or want_torch:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            exchange = "torch.distributed gloo, host-staged (one-GPU rehearsal)"
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
@@ -177,23 +180,35 @@ def main():
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
 
+            def agree(ok):  # collective AND on the control plane: every rank takes the same branch
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return int(t.item()) == 1
+
             why = ""
             try:
-                comm = abi.Comm(rank, world, share)
-            except Exception as e:  # noqa: BLE001 — whatever went wrong, every rank must take the same branch
+                comm = abi.Comm(rank, world, share, agree)
+            except Exception as e:  # noqa: BLE001 — Comm raises on every rank or on none (see its docstring)
                 why = f"{type(e).__name__}: {e}"
-            ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 1:
-                exchange = "native RCCL (C++ tiled frame: vkr_all_gather / vkr_halo_exchange)"
-            else:
-                print(f"[bench] native RCCL communicator unavailable ({why or 'failed on another rank'}): falling back to torch.distributed", file=sys.stderr)
-                if comm is not None:
+            if agree(comm is not None):
+                # one-time self check of the wire: known bytes through all three exchanges, verified on every rank
+                if not comm.self_check(device, agree):
+                    why = "self check failed" + (f": {comm.self_check_error}" if comm.self_check_error else " on another rank")
                     comm.close()
                     comm = None
-                dist.destroy_process_group()
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-                exchange = "torch.distributed RCCL (fallback: " + (why or "native communicator failed on another rank") + ")"
+            elif comm is not None:
+                comm.close()
+                comm = None
+            if comm is not None:
+                exchange = "native RCCL (C++ tiled frame: vkr_all_gather / vkr_halo_exchange)"
+                if os.environ.get("VKR_RCCL_LIBRARY"):
+                    exchange += f" through {os.path.basename(os.environ['VKR_RCCL_LIBRARY'])}"
+            else:
+                print(f"[bench] native RCCL communicator unavailable ({why or 'failed on another rank'}): falling back to torch.distributed", file=sys.stderr)
+                if not share_gpu:
+                    dist.destroy_process_group()
+                    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+                exchange = ("torch.distributed gloo, host-staged" if share_gpu else "torch.distributed RCCL") + " (fallback: " + (why or "native communicator failed on another rank") + ")"
 
     W, H = (int(v) for v in args.frame.lower().split("x"))
     cols, rows = grid_for(world)
@@ -254,7 +269,8 @@ def main():
     # (VKR_BALANCE_REBUILD=1, tests: the one-rank rehearsal goes through the same measure / share / rebuild sequence although
     # its single strip cannot move)
     force_rebuild = os.environ.get("VKR_BALANCE_REBUILD") == "1"
-    if ((world > 1 and args.config == "c4") or (args.rehearse_tiled and force_rebuild)) and comm is not None and os.environ.get("VKR_BALANCE", "1") != "0":
+    any_frame = os.environ.get("VKR_BALANCE_ANY_FRAME") == "1"  # tests: re-cut the strips of a small rehearsal frame too
+    if ((world > 1 and (args.config == "c4" or any_frame)) or (args.rehearse_tiled and force_rebuild)) and comm is not None and os.environ.get("VKR_BALANCE", "1") != "0":
         for _ in range(2):
             BAL_STEPS = 3
             frame.enable_task_timing(True)
@@ -307,6 +323,18 @@ def main():
         else:
             every = [mine]
         exchange_wait_ms = {k: [round(e[k], 4) for e in every] for k in mine}  # per rank
+    # bytes every rank RECEIVES per frame over the wire: the other ranks' shares of the gathered surfaces + its halo rows
+    exchange_bytes_per_rank = None
+    if tiled.native and frame.tiled_handle is not None and world > 1:
+        mine = {"hiz": sum(p[2] for p in frame.tiled_gather_parts(0)), "albedo": sum(p[2] for p in frame.tiled_gather_parts(1)),
+                "halo": sum(p[3] for s_ in range(3) for p in frame.tiled_halo_peers(s_))}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        exchange_bytes_per_rank = [{"hiz_gather_in": sum(e["hiz"] for e in every) - every[r]["hiz"],
+                                    "albedo_gather_in": sum(e["albedo"] for e in every) - every[r]["albedo"],
+                                    "halo_in": every[r]["halo"]} for r in range(world)]
+        for e in exchange_bytes_per_rank:
+            e["total_in"] = e["hiz_gather_in"] + e["albedo_gather_in"] + e["halo_in"]
     calibration = frame.collect_task_times()
     per_pass_ms = {k: v[0] / CAL_STEPS for k, v in calibration.items()}          # all executions of the task in one step
     launches_per_step = {k: v[1] / CAL_STEPS for k, v in calibration.items()}    # executions of the task per step (c5: 8 x SSR)
@@ -417,6 +445,7 @@ def main():
             "exchange_ms": tiled.exchange_ms(args.steps),
             # calibration run: ms per frame every rank's compute stream stood still for each exchange (None: no wire)
             "exchange_wait_ms": exchange_wait_ms,
+            "exchange_bytes_per_rank": exchange_bytes_per_rank,
             "measured_read_gbps": measured_read,
         }
         if step_ms:  # median of >= 50 hipEvent-timed frames, beside the contract's wall-clock mean

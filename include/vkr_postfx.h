@@ -414,6 +414,16 @@ int vkr_comm_unique_id(uint8_t* id_bytes /* [VKR_COMM_ID_BYTES] */);
 int vkr_comm_create(const uint8_t* id_bytes, int rank, int world, vkr_comm** out);
 int vkr_comm_destroy(vkr_comm* comm);
 int vkr_comm_rank(const vkr_comm* comm, int* rank, int* world);
+/* 0 when RCCL can be loaded in this process (nothing collective happens); a launcher checks this on EVERY rank and
+ * agrees on the result over its control plane before the collective vkr_comm_create, so that a rank without RCCL
+ * cannot leave the others blocked inside ncclCommInitRank                                                          */
+int vkr_comm_available(void);
+/* Start-up check of a fresh communicator, collective: every rank gathers a rank-tagged pattern through vkr_all_gather
+ * and vkr_all_gather_v (shares of different sizes, in place) and trades one with each neighbour rank through
+ * vkr_halo_exchange, on `stream`, then verifies every byte it received (synchronises the stream).  0 = the wire delivers
+ * what the tiled frame expects.  scratch: device memory of at least vkr_comm_selfcheck_bytes(world) bytes.          */
+uint64_t vkr_comm_selfcheck_bytes(int world);
+int vkr_comm_selfcheck(vkr_comm* comm, void* scratch, void* stream);
 /* all-gather of several surfaces at once: recv receives [rank][bytes] from every rank's send (out of place; with
  * horizontal strips a tile's rows of a surface are contiguous, so recv can be the whole-frame image itself)       */
 typedef struct vkr_gather_part { const void* send; void* recv; uint64_t bytes; } vkr_gather_part;

@@ -1,0 +1,195 @@
+"""The NATIVE wire of the tiled frame with real peer processes.
+
+Every rank is its own process on cuda:0 and drives the C++ tiled frame (host/frame.cpp: vkrh_tiled_step) over a native
+communicator (vkr_comm_*).  RCCL itself refuses two ranks on one device, so VKR_RCCL_LIBRARY points the C-ABI's dlopen at
+tests/stub_rccl/libstub_rccl.so: the same ten entry points, host-staged through POSIX shared memory, honouring the stream
+argument and the group semantics — what runs is csrc/rccl_exchange.hip (grouped launches, in-place gather offsets,
+broadcast-based all_gather_v), the event ordering between the compute and the exchange stream, pack / unpack of the halo
+rows and the strip re-cutting of bench.py, with >= 2 peers on every exchange.  Each rank compares its tile interior with
+the plain single-GPU frame it computes itself; a rank that hangs is killed by the stub's own timeout (exit 3) or by the
+test's, never silently.  The stub's log shows what crossed the wire."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = os.path.join(ROOT, "tests", "stub_rccl", "libstub_rccl.so")
+
+WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    import vk_renderer_amd
+    from vk_renderer_amd import abi, host
+    from vk_renderer_amd.camera import FrameSetup
+    from vk_renderer_amd.tiling import TiledFrame
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    device = torch.device('cuda', 0)
+    torch.cuda.set_device(device)
+    dist.init_process_group('gloo')
+    def share(ident):
+        box = [ident]; dist.broadcast_object_list(box, src=0); return box[0]
+    def agree(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32); dist.all_reduce(t, op=dist.ReduceOp.MIN); return int(t.item()) == 1
+    comm = abi.Comm(rank, world, share, agree)
+    assert comm.self_check(device, agree), comm.self_check_error
+    bounds = json.loads(os.environ['VKR_BOUNDS'])
+    moving = os.environ['VKR_MOVING'] == '1'
+    FRAMES = int(os.environ['VKR_FRAMES'])
+    W, H = 256, bounds[-1]
+
+    def camera(k):  # frame k looks from eye_k; its previous frame is camera k - 1
+        return FrameSetup(W, H, eye=(0.03 * k, 1.0, -1.0 + 0.02 * k), yaw=90.0 + 0.3 * k, prev_delta=(-0.03, 0.0, -0.02), prev_yaw_delta=-0.3)
+
+    def run(t, frames):
+        for k in range(frames):
+            if moving:
+                s = camera(k)
+                t.frame.set_camera(s.view, s.prev_view, s.proj, s.fazz)
+                t.frame.run(host.STAGE_GBUFFER | host.STAGE_PREV_DEPTH)
+            t.step()
+        t.flush()
+        t.backend.sync()
+
+    equal = all(bounds[r + 1] - bounds[r] == bounds[1] for r in range(world))
+    t = TiledFrame(FrameSetup(W, H), rank, world, 1, world, device, native=True, comm=comm, row_bounds=None if equal else bounds)
+    assert t.native and t.frame.tiled_handle
+    t.prepare()
+    run(t, FRAMES)
+    plain = TiledFrame(FrameSetup(W, H), 0, 1, 1, 1, device)
+    plain.prepare()
+    run(plain, FRAMES)
+    x0, y0, tw, th = t.tile
+    bad = 0
+    for name, dv in (('rays', 1), ('raw', 1), ('reflections', 1), ('filtered', 1), ('blurred_hist', 1), ('acc_hist', 1), ('taa_hist', 0), ('dn', 1), ('dv', 1)):
+        got, want = t.frame.download(name), plain.frame.download(name)
+        ox, oy = got.origin
+        a = got.raw(0)[(y0 >> dv) - oy:(y0 >> dv) - oy + (th >> dv), (x0 >> dv) - ox:(x0 >> dv) - ox + (tw >> dv)]
+        b = want.raw(0)[(y0 >> dv):(y0 >> dv) + (th >> dv), (x0 >> dv):(x0 >> dv) + (tw >> dv)]
+        n = int((a != b).any(axis=-1).sum())
+        if n:
+            print(f'rank {rank} {name}: {n} differing texels')
+        bad += n
+    # the history halo rows a rank holds after flush() are its neighbours' interior rows (ADVICE r02: they used to be
+    # unpacked into the image the next pass overwrites)
+    halo = t.halo
+    for name, dv in (('taa_hist', 0), ('acc_hist', 1), ('blurred_hist', 1)):
+        got, want = t.frame.download(name), plain.frame.download(name)
+        ox, oy = got.origin
+        rows = halo >> dv
+        for lo, hi in (((y0 >> dv) - rows, (y0 >> dv)), ((y0 + th) >> dv, ((y0 + th) >> dv) + rows)):
+            if lo < 0 or hi > (H >> dv):
+                continue
+            a = got.raw(0)[lo - oy:hi - oy]
+            b = want.raw(0)[lo:hi]
+            n = int((a != b).any(axis=-1).sum())
+            if n:
+                print(f'rank {rank} {name} halo rows {lo}..{hi}: {n} texels differ from the neighbour interior')
+            bad += n
+    dist.barrier()
+    torch.cuda.synchronize()
+    t.frame.close(); plain.frame.close()
+    comm.close()
+    dist.destroy_process_group()
+    sys.exit(1 if bad else 0)
+""") % ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _stub():
+    if not os.path.exists(STUB):
+        subprocess.check_call(["make", "-C", os.path.dirname(STUB)])
+    return STUB
+
+
+def _launch(world, script_args, env, timeout):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    # fresh child processes only; a rank that does not finish is killed with its whole group and the test fails
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        import signal
+
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        pytest.fail(f"ranks did not finish within {timeout} s\n{out[-2000:]}\n{err[-3000:]}")
+    return p.returncode, out, err
+
+
+def _wire_log(path, world):
+    rows = {}
+    for ln in open(path).read().splitlines():
+        f = ln.split()
+        rows[int(f[1])] = {f[i]: tuple(int(v) for v in f[i + 1].split("/")) for i in range(6, len(f), 2)}
+        assert int(f[3]) == world
+    assert sorted(rows) == list(range(world)), f"every rank logs once: {sorted(rows)}"
+    return rows
+
+
+@pytest.mark.parametrize("bounds,moving,frames", [
+    ([0, 160, 320], False, 3),              # two equal strips: vkr_all_gather (grouped ncclAllGather) + halo Send / Recv
+    ([0, 160, 320, 480, 640], True, 4),     # four equal strips, camera moving every frame
+    ([0, 160, 400, 480], True, 4),          # strips of different heights: vkr_all_gather_v (grouped ncclBroadcast), camera moving
+    ([0, 96, 168, 304, 480], False, 3),     # 168 = 8 * 21: only depth mips 1..3 travel
+])
+def test_native_tiled_frame_between_real_processes(bounds, moving, frames, tmp_path):
+    world = len(bounds) - 1
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    log = tmp_path / "wire.log"
+    env = dict(os.environ, VKR_RCCL_LIBRARY=_stub(), VKR_STUB_RCCL_LOG=str(log), VKR_STUB_RCCL_TIMEOUT_S="120", VKR_BOUNDS=json.dumps(bounds),
+               VKR_MOVING="1" if moving else "0", VKR_FRAMES=str(frames), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    rc, out, err = _launch(world, [str(script)], env, timeout=420)
+    assert rc == 0, out[-3000:] + err[-3000:]
+    rows = _wire_log(log, world)
+    equal = all(bounds[r + 1] - bounds[r] == bounds[1] for r in range(world))
+    for r, k in rows.items():
+        # per frame: two gather groups; the self check adds one of each kind
+        if equal:
+            assert k["allgather"][0] >= 2 * frames and k["allgather"][1] > 0
+        else:
+            assert k["broadcast"][0] >= 2 * frames * world - 2 and k["broadcast"][1] > 0
+        neighbours = (1 if r > 0 else 0) + (1 if r + 1 < world else 0)
+        assert k["send"][0] >= 3 * frames * neighbours and k["recv"][0] == k["send"][0]
+
+
+@pytest.mark.parametrize("world,balance", [(2, False), (4, True)])
+def test_bench_native_branch_between_real_processes(world, balance, tmp_path):
+    """bench.py --gpus N exactly as the driver launches it, every rank on cuda:0, the native communicator over the stub:
+    one well-formed JSON line, the exchange named, and with `balance` the strips re-cut by measured cost (the shares then
+    travel through vkr_all_gather_v)."""
+    log = tmp_path / "wire.log"
+    env = dict(os.environ, VKR_BENCH_REHEARSE_ON_ONE_GPU="1", VKR_RCCL_LIBRARY=_stub(), VKR_STUB_RCCL_LOG=str(log), VKR_STUB_RCCL_TIMEOUT_S="120",
+               VKR_BALANCE_ANY_FRAME="1" if balance else "0", VKR_BALANCE_REBUILD="1" if balance else "0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    H = 384 * world
+    rc, out, err = _launch(world, [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2", "--frame", f"512x{H}"], env, timeout=600)
+    assert rc == 0, out[-2000:] + err[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"exactly one line on stdout, got {len(lines)}: {lines[:3]}"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 4 and d["scaling"] == "strong"
+    assert d["config"]["exchange"].startswith("native RCCL") and "libstub_rccl.so" in d["config"]["exchange"]
+    assert sum(d["config"]["strip_rows"]) == H and len(d["config"]["strip_rows"]) == world
+    assert d["exchange_wait_ms"] is not None and all(len(v) == world for v in d["exchange_wait_ms"].values())
+    assert d["exchange_bytes_per_rank"] is not None and len(d["exchange_bytes_per_rank"]) == world
+    rows = _wire_log(log, world)
+    if balance:
+        assert len(d["config"]["strip_balance"]) >= 1
+        assert any(k["broadcast"][0] > 0 for k in rows.values()) or len(set(d["config"]["strip_rows"])) == 1
+    for k in rows.values():
+        assert k["send"][0] > 0 and k["recv"][0] > 0 and (k["allgather"][0] > 0 or k["broadcast"][0] > 0)

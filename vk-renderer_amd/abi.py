@@ -261,6 +261,8 @@ def product():
         lib.vkr_comm_unique_id.argtypes = [C.c_void_p]
         lib.vkr_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
         lib.vkr_comm_destroy.argtypes = [C.c_void_p]
+        lib.vkr_comm_available.argtypes = []
+        lib.vkr_comm_available.restype = C.c_int
         lib.vkr_copy_rects.restype = C.c_int
         lib.vkr_raster_scratch_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         lib.vkr_raster_scratch_bytes.restype = C.c_uint64
@@ -288,20 +290,53 @@ COMM_ID_BYTES = 128
 class Comm:
     """RCCL communicator of the C-ABI (include/vkr_postfx.h vkr_comm_*): the wire of the multi-GPU frame.  Rank 0 makes
     the id, `share` hands its bytes to every rank out of band (e.g. torch.distributed.broadcast_object_list over gloo),
-    then every rank creates the communicator collectively with its device current."""
+    then every rank creates the communicator collectively with its device current.
 
-    def __init__(self, rank, world, share):
+    Every rank takes the same branch whatever fails where (a mismatch would leave the others blocked in a collective):
+      * `agree(ok)` — optional, a collective AND over the ranks on the control plane — is asked whether RCCL loads on
+        EVERY rank before anything collective happens;
+      * every rank always calls `share` (rank 0 with None when it could not make the id) and raises after it;
+      * `self_check(agree)` verifies a fresh communicator by moving known bytes through all three exchanges."""
+
+    def __init__(self, rank, world, share, agree=None):
         lib = product()
-        ident = bytes(COMM_ID_BYTES)
+        self.handle, self.rank, self.world = None, rank, world
+        available = lib.vkr_comm_available() == 0
+        why = "" if available else (lib.vkr_last_error() or b"").decode()
+        if agree is not None and not agree(available):
+            raise RuntimeError("RCCL is not available on every rank" + (f" (this rank: {why})" if why else ""))
+        ident = None
         if rank == 0:
             buf = (C.c_uint8 * COMM_ID_BYTES)()
-            check(lib.vkr_comm_unique_id(buf), lib)
-            ident = bytes(buf)
-        ident = share(ident)
+            if available and lib.vkr_comm_unique_id(buf) == 0:
+                ident = bytes(buf)
+            else:
+                why = (lib.vkr_last_error() or b"").decode()
+        ident = share(ident)  # rank 0 always reaches this, so nobody waits for an id that never comes
+        if ident is None:
+            raise RuntimeError("rank 0 could not make a communicator id" + (f": {why}" if why else ""))
+        if not available:  # only without `agree`: the ranks that do have RCCL are about to block in vkr_comm_create — pass `agree`
+            raise RuntimeError(f"RCCL is not available on this rank: {why}")
         assert len(ident) == COMM_ID_BYTES
         h = C.c_void_p(0)
         check(lib.vkr_comm_create((C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(ident), rank, world, C.byref(h)), lib)
-        self.handle, self.rank, self.world = h.value, rank, world
+        self.handle = h.value
+
+    def self_check(self, device, agree=None):
+        """Moves rank-tagged patterns through vkr_all_gather, vkr_all_gather_v and vkr_halo_exchange and verifies every
+        received byte (vkr_comm_selfcheck).  Returns True when the wire delivers what the tiled frame expects — on
+        every rank, if `agree` (collective AND) is given."""
+        import torch
+
+        lib = product()
+        lib.vkr_comm_selfcheck_bytes.argtypes = [C.c_int]
+        lib.vkr_comm_selfcheck_bytes.restype = C.c_uint64
+        lib.vkr_comm_selfcheck.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        scratch = torch.empty(int(lib.vkr_comm_selfcheck_bytes(self.world)), dtype=torch.uint8, device=device)
+        stream = torch.cuda.current_stream(device)
+        ok = lib.vkr_comm_selfcheck(C.c_void_p(self.handle), C.c_void_p(scratch.data_ptr()), C.c_void_p(stream.cuda_stream)) == 0
+        self.self_check_error = "" if ok else (lib.vkr_last_error() or b"").decode()
+        return agree(ok) if agree is not None else ok
 
     def close(self):
         if self.handle:

@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 
 #include <mutex>
+#include <vector>
 
 #include "vkr_host.hpp"
 
@@ -118,6 +119,8 @@ extern "C" int vkr_comm_rank(const vkr_comm* comm, int* rank, int* world) {
   return vkr::VKR_OK;
 }
 
+extern "C" int vkr_comm_available(void) { return rccl_ready("comm_available") ? vkr::VKR_OK : vkr::VKR_ERR_LAYOUT; }
+
 extern "C" int vkr_all_gather(vkr_comm* comm, const vkr_gather_part* parts, uint32_t count, void* stream) {
   if (count == 0) return vkr::VKR_OK;
   if (!comm || !parts) { vkr::set_error("all_gather: NULL argument"); return vkr::VKR_ERR_NULL; }
@@ -175,4 +178,62 @@ extern "C" int vkr_halo_exchange(vkr_comm* comm, const vkr_halo_peer* peers, uin
   const ncclResult_t e = g_rccl.GroupEnd();
   if (r != ncclSuccess) return fail("halo_exchange", r);
   return e == ncclSuccess ? vkr::VKR_OK : fail("halo_exchange", e);
+}
+
+// ---- start-up self check -------------------------------------------------------------------------------------------
+// Shares of SELF_UNIT * (r + 1) bytes for the all-gather-v (so every offset differs), SELF_UNIT for the uniform gather and
+// the halo trade; byte k of what rank r contributes to test t is pattern(t, r, k).
+namespace {
+constexpr uint64_t SELF_UNIT = 4096;
+inline uint8_t self_pattern(int test, int rank, uint64_t k) { return (uint8_t)(0x5Au ^ (uint32_t)(test * 61 + rank * 37) ^ (uint32_t)(k * 7u + (k >> 8))); }
+uint64_t self_v_offset(int r) { return SELF_UNIT * (uint64_t)r * (uint64_t)(r + 1) / 2; }  // sum of (i + 1) for i < r
+}  // namespace
+
+extern "C" uint64_t vkr_comm_selfcheck_bytes(int world) {
+  if (world < 1) world = 1;
+  // [gather send | gather recv world] [gather_v frame (in place)] [halo: 2 send, 2 recv]
+  return SELF_UNIT * (1 + (uint64_t)world) + self_v_offset(world) + 4 * SELF_UNIT;
+}
+
+extern "C" int vkr_comm_selfcheck(vkr_comm* comm, void* scratch, void* stream) {
+  using vkr::VKR_OK;
+  if (!comm || !scratch) { vkr::set_error("comm_selfcheck: NULL argument"); return vkr::VKR_ERR_NULL; }
+  const int rank = comm->rank, world = comm->world;
+  const uint64_t total = vkr_comm_selfcheck_bytes(world);
+  std::vector<uint8_t> host(total, 0xEE);
+  uint8_t* const dev = (uint8_t*)scratch;
+  const uint64_t g_send = 0, g_recv = SELF_UNIT, v_frame = g_recv + SELF_UNIT * world, h_base = v_frame + self_v_offset(world);
+  for (uint64_t k = 0; k < SELF_UNIT; k++) host[g_send + k] = self_pattern(0, rank, k);
+  for (uint64_t k = 0; k < SELF_UNIT * (rank + 1); k++) host[v_frame + self_v_offset(rank) + k] = self_pattern(1, rank, k);  // my share, in place
+  for (int nb = 0; nb < 2; nb++)
+    for (uint64_t k = 0; k < SELF_UNIT; k++) host[h_base + nb * SELF_UNIT + k] = self_pattern(2 + nb, rank, k);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemcpyAsync(dev, host.data(), total, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) { vkr::set_error("comm_selfcheck: %s", hipGetErrorString(e)); return (int)e; }
+  const vkr_gather_part gp {dev + g_send, dev + g_recv, SELF_UNIT};
+  VKR_TRY(vkr_all_gather(comm, &gp, 1, stream));
+  std::vector<uint64_t> offs(world + 1);
+  for (int r = 0; r <= world; r++) offs[r] = self_v_offset(r);
+  const vkr_gather_v_part vp {dev + v_frame + offs[rank], dev + v_frame, offs.data()};
+  VKR_TRY(vkr_all_gather_v(comm, &vp, 1, stream));
+  vkr_halo_peer peers[2];
+  uint32_t np = 0;
+  // slot 0 travels up (to rank - 1), slot 1 down (to rank + 1); what arrives from above was that rank's slot 1
+  if (rank > 0) peers[np++] = vkr_halo_peer {rank - 1, 0u, dev + h_base, SELF_UNIT, dev + h_base + 2 * SELF_UNIT, SELF_UNIT};
+  if (rank + 1 < world) peers[np++] = vkr_halo_peer {rank + 1, 0u, dev + h_base + SELF_UNIT, SELF_UNIT, dev + h_base + 3 * SELF_UNIT, SELF_UNIT};
+  VKR_TRY(vkr_halo_exchange(comm, peers, np, stream));
+  e = hipMemcpyAsync(host.data(), dev, total, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { vkr::set_error("comm_selfcheck: %s", hipGetErrorString(e)); return (int)e; }
+  for (int r = 0; r < world; r++) {
+    for (uint64_t k = 0; k < SELF_UNIT; k++)
+      if (host[g_recv + SELF_UNIT * r + k] != self_pattern(0, r, k)) { vkr::set_error("comm_selfcheck: all_gather: share of rank %d wrong at byte %llu on rank %d", r, (unsigned long long)k, rank); return vkr::VKR_ERR_EXTENT; }
+    for (uint64_t k = 0; k < SELF_UNIT * (r + 1); k++)
+      if (host[v_frame + offs[r] + k] != self_pattern(1, r, k)) { vkr::set_error("comm_selfcheck: all_gather_v: share of rank %d wrong at byte %llu on rank %d", r, (unsigned long long)k, rank); return vkr::VKR_ERR_EXTENT; }
+  }
+  for (uint64_t k = 0; k < SELF_UNIT; k++) {
+    if (rank > 0 && host[h_base + 2 * SELF_UNIT + k] != self_pattern(3, rank - 1, k)) { vkr::set_error("comm_selfcheck: halo from rank %d wrong at byte %llu", rank - 1, (unsigned long long)k); return vkr::VKR_ERR_EXTENT; }
+    if (rank + 1 < world && host[h_base + 3 * SELF_UNIT + k] != self_pattern(2, rank + 1, k)) { vkr::set_error("comm_selfcheck: halo from rank %d wrong at byte %llu", rank + 1, (unsigned long long)k); return vkr::VKR_ERR_EXTENT; }
+  }
+  return vkr::VKR_OK;
 }

@@ -267,7 +267,12 @@ struct TiledFrame {
         }
     }
   }
+  void drop_wait_marks() {
+    for (auto& v : wait_marks) { for (auto& m : v) { (void)hipEventDestroy(m.first); (void)hipEventDestroy(m.second); } v.clear(); }
+  }
   ~TiledFrame() {
+    if (compute) (void)hipStreamSynchronize(compute);
+    drop_wait_marks();
     if (xchg) { (void)hipStreamSynchronize(xchg); (void)hipStreamDestroy(xchg); }
     for (auto e : ev_ready) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_done) if (e) (void)hipEventDestroy(e);
@@ -287,9 +292,15 @@ struct TiledFrame {
     const auto id = s == VKRH_HALO_TAA ? frame->taa_pass.get_output() : s == VKRH_HALO_AO ? frame->gtao.accumulated_ao : frame->ssr.get_blurred();
     return frame->graph.get_image(id)->describe(0, 1);
   }
-  // pack (to_buffers) / unpack the halo rows of surface s: one vkr_copy_rects launch on the compute stream
+  // pack (to_buffers) / unpack the halo rows of surface s: one vkr_copy_rects launch on the compute stream.  A refresh is
+  // packed right after the pass that wrote the surface and unpacked in the NEXT frame (or in flush()), i.e. after
+  // end_frame() has swapped output and history: by then the output id names the old history image, which the pass is
+  // about to overwrite.  The rows belong into the very image they were packed from — now the history the pass reads —
+  // so the descriptor is taken at pack time and kept for the unpack.
+  vkr_img packed_from[3] {};
   void copy_halo(int s, bool to_buffers) {
-    const vkr_img d = surface(s);
+    if (to_buffers) packed_from[s] = surface(s);
+    const vkr_img d = packed_from[s];
     const uint32_t dv = halo_dv(s), bpp = vkr_format_bytes(d.format), rows = cfg.halo >> dv, row_bytes = d.width * bpp;
     const uint32_t ty0 = (y0 >> dv) - uint32_t(d.origin_y), tth = th >> dv;  // the tile's first row inside the window image
     vkr_rect_copy rc[2];
@@ -741,7 +752,16 @@ int vkrh_tiled_halo_peers(void* tiled, uint32_t surface, vkr_halo_peer* out, uin
     *count = ((TiledFrame*)tiled)->halo_peers((int)surface, out);
   });
 }
-int vkrh_tiled_time_waits(void* tiled, uint32_t on) { return guarded([&] { ((TiledFrame*)tiled)->time_waits = on != 0; }); }
+int vkrh_tiled_time_waits(void* tiled, uint32_t on) {
+  return guarded([&] {
+    auto* t = (TiledFrame*)tiled;
+    t->time_waits = on != 0;
+    if (!on) {  // marks nobody collected: their events must not pile up
+      TiledFrame::check(hipStreamSynchronize(t->compute), "synchronize");
+      t->drop_wait_marks();
+    }
+  });
+}
 int vkrh_tiled_wait_times(void* tiled, float* ms5) {
   return guarded([&] {
     if (!tiled || !ms5) throw std::runtime_error{"vkrh_tiled_wait_times: NULL argument"};
