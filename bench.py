@@ -326,15 +326,18 @@ def main():
     # bytes every rank RECEIVES per frame over the wire: the other ranks' shares of the gathered surfaces + its halo rows
     exchange_bytes_per_rank = None
     if tiled.native and frame.tiled_handle is not None and world > 1:
-        mine = {"hiz": sum(p[2] for p in frame.tiled_gather_parts(0)), "albedo": sum(p[2] for p in frame.tiled_gather_parts(1)),
-                "halo": sum(p[3] for s_ in range(3) for p in frame.tiled_halo_peers(s_))}
+        by_gather = frame.albedo_by_gather
+        mine = {"hiz": sum(p[2] for p in frame.tiled_gather_parts(0)), "albedo": sum(p[2] for p in frame.tiled_gather_parts(1)) if by_gather else 0,
+                "halo": sum(p[3] for s_ in range(3) for p in frame.tiled_halo_peers(s_)), "hit": 0 if by_gather else frame.tiled_hit_bytes()}
         every = [None] * world
         dist.all_gather_object(every, mine)
+        # hit colours: by request / reply (8-byte requests in + 8-byte replies in, last frame's count) or the all-gathered albedo
         exchange_bytes_per_rank = [{"hiz_gather_in": sum(e["hiz"] for e in every) - every[r]["hiz"],
-                                    "albedo_gather_in": sum(e["albedo"] for e in every) - every[r]["albedo"],
+                                    "hit_colours_in": (sum(e["albedo"] for e in every) - every[r]["albedo"]) if by_gather else every[r]["hit"],
+                                    "hit_colours": "all-gather of the albedo" if by_gather else "request / reply",
                                     "halo_in": every[r]["halo"]} for r in range(world)]
         for e in exchange_bytes_per_rank:
-            e["total_in"] = e["hiz_gather_in"] + e["albedo_gather_in"] + e["halo_in"]
+            e["total_in"] = e["hiz_gather_in"] + e["hit_colours_in"] + e["halo_in"]
     calibration = frame.collect_task_times()
     per_pass_ms = {k: v[0] / CAL_STEPS for k, v in calibration.items()}          # all executions of the task in one step
     launches_per_step = {k: v[1] / CAL_STEPS for k, v in calibration.items()}    # executions of the task per step (c5: 8 x SSR)

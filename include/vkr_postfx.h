@@ -439,6 +439,23 @@ int vkr_all_gather_v(vkr_comm* comm, const vkr_gather_v_part* parts, uint32_t co
 typedef struct vkr_halo_peer { int32_t peer; uint32_t reserved; const void* send; uint64_t send_bytes; void* recv; uint64_t recv_bytes; } vkr_halo_peer;
 int vkr_halo_exchange(vkr_comm* comm, const vkr_halo_peer* peers, uint32_t count, void* stream);
 
+/* ---- hit colours by request / reply (multi-GPU; instead of all-gathering the albedo of the whole frame) -----------
+ * filter.comp:112-134 reads the albedo bilinearly at the hit position of every valid ray, anywhere in the frame.  A rank
+ * asks the owning ranks for exactly the footprint rows it does not hold, and writes the answers into its whole-frame
+ * albedo image where an all-gather would have put them (csrc/hit_exchange.hip; host/frame.hpp drives the three steps and
+ * moves requests and replies with vkr_halo_exchange).  Strips: rank r owns frame rows [row_bounds[r], row_bounds[r + 1]). */
+typedef struct vkr_hit_request { uint32_t row, x; } vkr_hit_request; /* frame row; left texel of the texel pair (<= W - 2) */
+/* out == NULL: counts[o] += number of requests this rank has for owner o (counts: device, world entries, zeroed by the
+ * caller).  out != NULL: writes them, owner o's from out[segments[o]] on (segments: host, world entries; cursors: device,
+ * world entries, zeroed by the caller).  The window is frame rows [window_row0, window_row1) of the full-res albedo.   */
+int vkr_hit_requests(const vkr_img* rays, uint32_t albedo_width, uint32_t albedo_height, const uint32_t* row_bounds, uint32_t world,
+                     uint32_t window_row0, uint32_t window_row1, uint32_t* counts, uint32_t* cursors, const uint32_t* segments,
+                     vkr_hit_request* out, void* stream);
+/* replies[i] = the two texels of requests[i] from this rank's albedo window; a request for texels the window does not
+ * hold answers 0 and increments *error_counter (device uint32)                                                        */
+int vkr_hit_reply(const vkr_img* albedo, const vkr_hit_request* requests, uint32_t count, uint64_t* replies, uint32_t* error_counter, void* stream);
+int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_hit_request* requests, const uint64_t* replies, uint32_t count, void* stream);
+
 /* float4 streaming-read microbenchmark: the measured-roofline denominator of
  * SURVEY.md 8(d).  Reads `bytes` from `src`, writes one float per block to `sink`.      */
 int vkr_stream_read(const void* src, uint64_t bytes, float* sink, uint32_t sink_len, void* stream);

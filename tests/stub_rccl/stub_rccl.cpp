@@ -5,10 +5,11 @@
 //
 // Semantics kept: calls between ncclGroupStart / ncclGroupEnd form one operation that is enqueued on the caller's stream
 // and completes in stream order; nothing blocks the host.  Transport: every rank's outgoing bytes are copied to pinned
-// host memory on the stream, a host function (hipLaunchHostFunc, i.e. in stream order) publishes them in a POSIX
-// shared-memory segment named after the unique id and collects what its peers published, and the incoming bytes are
-// copied back to the device on the stream.  Group g of one rank pairs with group g of every other rank — the same
-// requirement real RCCL has (all ranks issue the same sequence of collectives per communicator).
+// host memory on the stream, a host function (hipLaunchHostFunc, i.e. in stream order) moves them through per-pair
+// mailboxes in a POSIX shared-memory segment named after the unique id, and the incoming bytes are copied back to the
+// device on the stream.  Point-to-point messages of a pair arrive in the order they were sent and collectives are sets of
+// such messages in rank order — so, as with real RCCL, the ranks must issue matching sends / receives / collectives in
+// the same order per communicator, but a rank with nothing to exchange in a group need not take part in it.
 //
 // A peer that does not show up within VKR_STUB_RCCL_TIMEOUT_S (default 120) makes the waiting rank print what it was
 // waiting for and _exit(3): a hung exchange ends as a failed process, never as a hung test.
@@ -31,21 +32,21 @@
 namespace {
 
 constexpr int MAX_RANKS = 16;
-constexpr int MAX_ENTRIES = 256;
-constexpr int DST_ALL = -1;
 
-struct Entry { int32_t dst; uint32_t pad; uint64_t offset, bytes; };
-struct RankBox {
-  std::atomic<uint64_t> posted;    // generation of the group whose bytes are in the outbox
-  std::atomic<uint64_t> consumed;  // generation this rank has finished reading from everybody
-  uint32_t entry_count, pad;
-  Entry entries[MAX_ENTRIES];
+// One mailbox per directed pair (s -> d): a single slot of `slot_bytes` and two sequence numbers.  Point-to-point
+// messages of a pair are delivered in order (RCCL's rule); a message larger than the slot travels in chunks.  The ranks'
+// groups need not line up: a rank whose group is empty simply does not touch any mailbox.
+struct Mailbox {
+  std::atomic<uint64_t> sent;      // chunks written by the sender
+  std::atomic<uint64_t> consumed;  // chunks read by the receiver
+  uint64_t chunk_bytes;            // size of the chunk in the slot
+  uint64_t pad[5];
 };
 struct Header {
   std::atomic<uint32_t> attached, detached;
   uint32_t world, pad;
-  uint64_t outbox_bytes;
-  RankBox box[MAX_RANKS];
+  uint64_t slot_bytes;
+  Mailbox box[MAX_RANKS][MAX_RANKS];
 };
 
 double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
@@ -57,22 +58,23 @@ struct Comm {
   int rank = 0, world = 1;
   std::string name;
   Header* hdr = nullptr;
-  uint8_t* outbox_base = nullptr;  // world outboxes of hdr->outbox_bytes each, after the header
+  uint8_t* slots = nullptr;  // world x world slots of hdr->slot_bytes each, after the header
   size_t map_bytes = 0;
-  uint64_t generation = 0;
+  uint64_t groups = 0;
   uint64_t stats[4] = {0, 0, 0, 0};  // bytes moved per kind
   uint64_t calls[4] = {0, 0, 0, 0};
-  uint8_t* outbox(int r) const { return outbox_base + (size_t)r * hdr->outbox_bytes; }
+  uint8_t* slot(int s, int d) const { return slots + ((size_t)s * world + d) * hdr->slot_bytes; }
 };
 
-struct Landing { void* dst; size_t bytes; size_t staging_offset; int from; int match; };  // match: k-th entry of `from` addressed to me / to all
+struct Message { int peer; size_t staging_offset, bytes, done; };  // one point-to-point transfer; `done` bytes so far
+struct Copy { void* dst; const void* src; size_t bytes; };
 struct Group {
   Comm* comm;
-  uint64_t generation;
-  uint8_t* out_staging = nullptr; size_t out_bytes = 0;  // pinned: my outgoing bytes, in op order
-  std::vector<Entry> out_entries;
-  uint8_t* in_staging = nullptr; size_t in_bytes = 0;    // pinned: what I receive, in landing order
-  std::vector<Landing> landings;
+  uint8_t* out_staging = nullptr; size_t out_bytes = 0;  // pinned: my outgoing bytes
+  uint8_t* in_staging = nullptr; size_t in_bytes = 0;    // pinned: what I receive
+  std::vector<Message> sends, recvs;                     // in issue order: per peer they are served first in, first out
+  std::vector<Copy> self;                                // my own share of an all-gather / broadcast: staging to staging
+  std::vector<Copy> landings;                            // in_staging -> device
   hipEvent_t done = nullptr;
 };
 
@@ -82,58 +84,63 @@ thread_local hipStream_t t_stream = nullptr;
 std::mutex g_retired_mutex;
 std::vector<Group*> g_retired;
 
-[[noreturn]] void die(const Comm* c, const char* what, int peer, uint64_t gen) {
-  fprintf(stderr, "[stub_rccl] rank %d/%d: timed out after %.0f s waiting for %s of rank %d (group %llu)\n", c->rank, c->world, timeout_s(), what,
-          peer, (unsigned long long)gen);
+[[noreturn]] void die(const Comm* c, const Group* g) {
+  fprintf(stderr, "[stub_rccl] rank %d/%d: no progress for %.0f s;", c->rank, c->world, timeout_s());
+  for (const Message& m : g->sends) if (m.done < m.bytes) fprintf(stderr, " send->%d %zu/%zu", m.peer, m.done, m.bytes);
+  for (const Message& m : g->recvs) if (m.done < m.bytes) fprintf(stderr, " recv<-%d %zu/%zu", m.peer, m.done, m.bytes);
+  fprintf(stderr, "\n");
   fflush(stderr);
   _exit(3);
 }
 
-void wait_at_least(const Comm* c, const std::atomic<uint64_t>& v, uint64_t want, const char* what, int peer) {
-  const double t0 = now_s();
-  unsigned spins = 0;
-  while (v.load(std::memory_order_acquire) < want) {
-    if (++spins > 64) { usleep(50); if (now_s() - t0 > timeout_s()) die(c, what, peer, want); }
-  }
-}
-
-// runs in stream order on the exchange stream: my bytes are in out_staging, the device is waiting for in_staging
+// runs in stream order on the exchange stream: my bytes are in out_staging, the device is waiting for in_staging.
+// Progress engine: every directed pair is served first in, first out; sends and receives advance whenever their mailbox
+// allows, so two ranks that both send before they receive (or send more than a slot holds) cannot block each other.
 void host_exchange(void* arg) {
   Group* g = (Group*)arg;
   Comm* c = g->comm;
   Header* h = c->hdr;
-  const uint64_t gen = g->generation;
-  // 1. everybody has read my previous outbox
-  for (int r = 0; r < c->world; r++) wait_at_least(c, h->box[r].consumed, gen - 1, "the previous group to be consumed", r);
-  // 2. publish
-  RankBox& mine = h->box[c->rank];
-  if (g->out_bytes > h->outbox_bytes || g->out_entries.size() > MAX_ENTRIES) {
-    fprintf(stderr, "[stub_rccl] rank %d: group of %zu bytes / %zu entries exceeds the outbox (VKR_STUB_RCCL_MB)\n", c->rank, g->out_bytes, g->out_entries.size());
-    _exit(4);
-  }
-  if (g->out_bytes) std::memcpy(c->outbox(c->rank), g->out_staging, g->out_bytes);
-  mine.entry_count = (uint32_t)g->out_entries.size();
-  for (size_t i = 0; i < g->out_entries.size(); i++) mine.entries[i] = g->out_entries[i];
-  mine.posted.store(gen, std::memory_order_release);
-  // 3. collect
-  for (const Landing& l : g->landings) {
-    const RankBox& src = h->box[l.from];
-    wait_at_least(c, src.posted, gen, "a group to be posted", l.from);
-    int seen = 0;
-    const Entry* hit = nullptr;
-    for (uint32_t i = 0; i < src.entry_count; i++) {
-      const Entry& e = src.entries[i];
-      if (e.dst == DST_ALL || e.dst == c->rank) { if (seen == l.match) { hit = &e; break; } ++seen; }
+  for (const Copy& s : g->self) std::memcpy(s.dst, s.src, s.bytes);
+  size_t open = 0;
+  for (const Message& m : g->sends) open += m.bytes ? 1 : 0;
+  for (const Message& m : g->recvs) open += m.bytes ? 1 : 0;
+  double last_progress = now_s();
+  unsigned idle = 0;
+  while (open) {
+    bool moved = false;
+    bool busy_to[MAX_RANKS] = {false}, busy_from[MAX_RANKS] = {false};  // only the oldest unfinished message of a pair may move
+    for (Message& m : g->sends) {
+      if (m.done == m.bytes || busy_to[m.peer]) continue;
+      busy_to[m.peer] = true;
+      Mailbox& b = h->box[c->rank][m.peer];
+      if (b.sent.load(std::memory_order_relaxed) != b.consumed.load(std::memory_order_acquire)) continue;  // slot still full
+      const size_t n = m.bytes - m.done < h->slot_bytes ? m.bytes - m.done : h->slot_bytes;
+      std::memcpy(c->slot(c->rank, m.peer), g->out_staging + m.staging_offset + m.done, n);
+      b.chunk_bytes = n;
+      b.sent.store(b.sent.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+      m.done += n;
+      if (m.done == m.bytes) --open;
+      moved = true;
     }
-    if (!hit || hit->bytes != l.bytes) {
-      fprintf(stderr, "[stub_rccl] rank %d: group %llu: rank %d published %s for landing %d (want %zu bytes, got %llu): the ranks' call sequences differ\n",
-              c->rank, (unsigned long long)gen, l.from, hit ? "a different size" : "nothing", l.match, l.bytes, hit ? (unsigned long long)hit->bytes : 0ull);
-      _exit(5);
+    for (Message& m : g->recvs) {
+      if (m.done == m.bytes || busy_from[m.peer]) continue;
+      busy_from[m.peer] = true;
+      Mailbox& b = h->box[m.peer][c->rank];
+      if (b.sent.load(std::memory_order_acquire) == b.consumed.load(std::memory_order_relaxed)) continue;  // nothing there yet
+      const size_t n = b.chunk_bytes;
+      if (n > m.bytes - m.done) {
+        fprintf(stderr, "[stub_rccl] rank %d: rank %d sent %zu bytes where %zu were expected: the ranks' call sequences differ\n", c->rank, m.peer, n, m.bytes - m.done);
+        _exit(5);
+      }
+      std::memcpy(g->in_staging + m.staging_offset + m.done, c->slot(m.peer, c->rank), n);
+      b.consumed.store(b.consumed.load(std::memory_order_relaxed) + 1, std::memory_order_release);
+      m.done += n;
+      if (m.done == m.bytes) --open;
+      moved = true;
     }
-    std::memcpy(g->in_staging + l.staging_offset, c->outbox(l.from) + hit->offset, l.bytes);
+    if (moved) { last_progress = now_s(); idle = 0; continue; }
+    if (++idle > 64) { usleep(50); if (now_s() - last_progress > timeout_s()) die(c, g); }
   }
-  // 4. done with everybody's outbox of this generation
-  mine.consumed.store(gen, std::memory_order_release);
 }
 
 void reap_retired() {
@@ -160,50 +167,52 @@ ncclResult_t run_group(hipStream_t stream) {
   reap_retired();
   Group* g = new Group;
   g->comm = c;
-  g->generation = ++c->generation;
-  // layout of my outbox and of my landings; in-place operation (send inside recv) is fine: all sends are staged first
+  c->groups++;
+  // Every collective is decomposed into point-to-point messages in the order every rank decomposes it, so the pairwise
+  // first-in-first-out rule matches them up.  In-place operation (send inside recv) is fine: all sends are staged first.
   struct Out { const void* src; size_t bytes; size_t off; };
+  struct In { void* dst; size_t bytes; size_t off; };
   std::vector<Out> outs;
-  std::vector<int> seen_from(c->world, 0);  // entries of rank r addressed to me (or all) matched so far
+  std::vector<In> ins;
+  auto stage_out = [&](const void* src, size_t bytes) { outs.push_back({src, bytes, g->out_bytes}); g->out_bytes += bytes; return outs.back().off; };
+  auto stage_in = [&](void* dst, size_t bytes) { ins.push_back({dst, bytes, g->in_bytes}); g->in_bytes += bytes; return ins.back().off; };
+  struct SelfCopy { size_t in_off, out_off, bytes; };
+  std::vector<SelfCopy> selfs;
   for (auto& po : t_ops) {
     const Op& o = po.second;
     c->calls[o.kind]++; c->stats[o.kind] += o.bytes;
     if (o.kind == 0) {  // all-gather: my share to everybody, everybody's share to me at [rank][bytes]
-      outs.push_back({o.send, o.bytes, g->out_bytes});
-      g->out_entries.push_back({DST_ALL, 0, g->out_bytes, o.bytes});
-      g->out_bytes += o.bytes;
+      const size_t so = stage_out(o.send, o.bytes);
       for (int r = 0; r < c->world; r++) {
-        g->landings.push_back({(uint8_t*)o.recv + (size_t)r * o.bytes, o.bytes, g->in_bytes, r, seen_from[r]++});
-        g->in_bytes += o.bytes;
+        const size_t io = stage_in((uint8_t*)o.recv + (size_t)r * o.bytes, o.bytes);
+        if (r == c->rank) { selfs.push_back({io, so, o.bytes}); continue; }
+        g->sends.push_back({r, so, o.bytes, 0});
+        g->recvs.push_back({r, io, o.bytes, 0});
       }
     } else if (o.kind == 1) {  // broadcast from root o.peer
+      const size_t io = stage_in(o.recv, o.bytes);
       if (c->rank == o.peer) {
-        outs.push_back({o.send, o.bytes, g->out_bytes});
-        g->out_entries.push_back({DST_ALL, 0, g->out_bytes, o.bytes});
-        g->out_bytes += o.bytes;
+        const size_t so = stage_out(o.send, o.bytes);
+        selfs.push_back({io, so, o.bytes});
+        for (int r = 0; r < c->world; r++) if (r != c->rank) g->sends.push_back({r, so, o.bytes, 0});
+      } else {
+        g->recvs.push_back({o.peer, io, o.bytes, 0});
       }
-      g->landings.push_back({o.recv, o.bytes, g->in_bytes, o.peer, seen_from[o.peer]++});
-      g->in_bytes += o.bytes;
     } else if (o.kind == 2) {
-      outs.push_back({o.send, o.bytes, g->out_bytes});
-      g->out_entries.push_back({o.peer, 0, g->out_bytes, o.bytes});
-      g->out_bytes += o.bytes;
+      g->sends.push_back({o.peer, stage_out(o.send, o.bytes), o.bytes, 0});
     } else {
-      g->landings.push_back({o.recv, o.bytes, g->in_bytes, o.peer, seen_from[o.peer]++});
-      g->in_bytes += o.bytes;
+      g->recvs.push_back({o.peer, stage_in(o.recv, o.bytes), o.bytes, 0});
     }
   }
-  // NOTE on `match`: an all-gather / broadcast entry counts for every reader, a send only for its destination, and each
-  // reader counts the entries it can see in the publisher's order — both sides walk the same list, so the k-th landing
-  // from rank r is the k-th visible entry of rank r.
   t_ops.clear();
   if (g->out_bytes && hipHostMalloc((void**)&g->out_staging, g->out_bytes, hipHostMallocDefault) != hipSuccess) return ncclSystemError;
   if (g->in_bytes && hipHostMalloc((void**)&g->in_staging, g->in_bytes, hipHostMallocDefault) != hipSuccess) return ncclSystemError;
+  for (const SelfCopy& s : selfs) g->self.push_back({g->in_staging + s.in_off, g->out_staging + s.out_off, s.bytes});
   for (const Out& o : outs)
-    if (hipMemcpyAsync(g->out_staging + o.off, o.src, o.bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return ncclUnhandledCudaError;
+    if (o.bytes && hipMemcpyAsync(g->out_staging + o.off, o.src, o.bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return ncclUnhandledCudaError;
   if (hipLaunchHostFunc(stream, host_exchange, g) != hipSuccess) return ncclUnhandledCudaError;
-  for (const Landing& l : g->landings)
-    if (hipMemcpyAsync(l.dst, g->in_staging + l.staging_offset, l.bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
+  for (const In& l : ins)
+    if (l.bytes && hipMemcpyAsync(l.dst, g->in_staging + l.off, l.bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
   if (hipEventCreateWithFlags(&g->done, hipEventDisableTiming) != hipSuccess || hipEventRecord(g->done, stream) != hipSuccess) return ncclUnhandledCudaError;
   std::lock_guard<std::mutex> lock(g_retired_mutex);
   g_retired.push_back(g);
@@ -241,9 +250,9 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
   Comm* c = new Comm;
   c->rank = rank; c->world = nranks;
   c->name = std::string(id.internal, strnlen(id.internal, sizeof(id.internal)));
-  const char* mb = getenv("VKR_STUB_RCCL_MB");
-  const size_t outbox_bytes = (size_t)(mb ? atoi(mb) : 64) << 20;
-  c->map_bytes = sizeof(Header) + outbox_bytes * nranks;
+  const char* mb = getenv("VKR_STUB_RCCL_SLOT_MB");
+  const size_t slot_bytes = (size_t)(mb ? atoi(mb) : 8) << 20;
+  c->map_bytes = sizeof(Header) + slot_bytes * nranks * nranks;  // sparse: only the pages a run touches exist
   int fd = -1;
   if (rank == 0) {
     fd = shm_open(c->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
@@ -263,8 +272,8 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, int 
   close(fd);
   if (p == MAP_FAILED) { delete c; return ncclSystemError; }
   c->hdr = (Header*)p;  // a fresh segment is zero-filled: every counter starts at 0
-  c->outbox_base = (uint8_t*)p + sizeof(Header);
-  if (rank == 0) { c->hdr->world = (uint32_t)nranks; c->hdr->outbox_bytes = outbox_bytes; }
+  c->slots = (uint8_t*)p + sizeof(Header);
+  if (rank == 0) { c->hdr->world = (uint32_t)nranks; c->hdr->slot_bytes = slot_bytes; }
   c->hdr->attached.fetch_add(1);
   const double t0 = now_s();
   while (c->hdr->attached.load() < (uint32_t)nranks) {  // collective, like the real call
@@ -283,7 +292,7 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   if (const char* log = getenv("VKR_STUB_RCCL_LOG")) {  // what actually crossed the wire, for the tests to assert on
     if (FILE* f = fopen(log, "a")) {
       fprintf(f, "rank %d world %d groups %llu allgather %llu/%llu broadcast %llu/%llu send %llu/%llu recv %llu/%llu\n", c->rank, c->world,
-              (unsigned long long)c->generation, (unsigned long long)c->calls[0], (unsigned long long)c->stats[0], (unsigned long long)c->calls[1],
+              (unsigned long long)c->groups, (unsigned long long)c->calls[0], (unsigned long long)c->stats[0], (unsigned long long)c->calls[1],
               (unsigned long long)c->stats[1], (unsigned long long)c->calls[2], (unsigned long long)c->stats[2], (unsigned long long)c->calls[3],
               (unsigned long long)c->stats[3]);
       fclose(f);

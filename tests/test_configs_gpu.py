@@ -203,6 +203,23 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame(bounds):
     for t in ranks:
         t.flush()
     torch.cuda.synchronize()
+    # what every rank receives per frame: the other strips' shares of the gathered Hi-Z mips + normals, its halo rows and the
+    # hit colours it asked for (8-byte requests in + 8-byte replies in) — instead of the 464 MB of albedo
+    m = ranks[0].hit_matrix
+    assert all(t.frame.tiled_hit_errors() == 0 for t in ranks)
+    hiz_share = [sum(p[2] for p in t.frame.tiled_gather_parts(0)) for t in ranks]
+    wire = []
+    for r, t in enumerate(ranks):
+        asked_of_me = sum(m[q * world + r] for q in range(world))
+        i_ask = sum(m[r * world + o] for o in range(world))
+        wire.append({"hiz_gather_in": sum(hiz_share) - hiz_share[r], "hit_colours_in": 8 * (asked_of_me + i_ask),
+                     "hit_requests_out": i_ask, "halo_in": sum(p[3] for s_ in range(3) for p in t.frame.tiled_halo_peers(s_))})
+        wire[-1]["total_in"] = wire[-1]["hiz_gather_in"] + wire[-1]["hit_colours_in"] + wire[-1]["halo_in"]
+        assert t.frame.tiled_hit_bytes() == wire[-1]["hit_colours_in"]
+    print("[wire] " + json.dumps(wire))
+    # equal strips: <= 300 MB per rank and frame (measured 277-299 MB; it was 733 MB with the albedo all-gathered).  Balanced
+    # strips: the ranks with the short strips receive more of the gathered Hi-Z group (everybody else's share): 263-315 MB
+    assert max(w["total_in"] for w in wire) <= (300e6 if bounds is None else 320e6)
     history_fed = {"blurred_hist", "acc_hist", "taa_hist"}
     counts = {name: 0 for name, _ in OUTPUTS}
     texels = {name: 0 for name, _ in OUTPUTS}
@@ -223,7 +240,7 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame(bounds):
                 print(f"[deviation] rank {r} {name}: {n} texels differ from the one-GPU frame, e.g. tile row / column {where} (tile rows {t.th >> dv})")
         t.frame.close()
     report_d = {"frame": [W, H], "grid": [cols, rows], "strip_rows": [t.th for t in ranks], "halo_px": 48, "frames": frames,
-                "differing_texels": counts, "compared_texels": texels}
+                "differing_texels": counts, "compared_texels": texels, "wire_bytes_per_rank_and_frame": wire}
     print("[deviation] " + json.dumps(report_d))
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -233,6 +250,6 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame(bounds):
         pass
     for name, n in counts.items():
         if name in history_fed:
-            assert n <= 1e-4 * texels[name], f"{name}: {n} texels deviate from the one-GPU frame"
+            assert n <= 256, f"{name}: {n} texels deviate from the one-GPU frame (measured: 10 / 88 of 132.7 M)"
         else:
             assert n == 0, f"{name}: {n} texels differ (no history feeds this surface: it must be bit-identical)"

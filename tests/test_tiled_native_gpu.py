@@ -48,9 +48,13 @@ def _interiors_differ(t, want, tw, th):
     return bad
 
 
-@pytest.mark.parametrize("world,tile_h,gather", [(2, 160, 4), (4, 160, 4), (3, 136, 3)])  # 136 = 8 * 17: only depth mips 1..3 travel
-def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather):
+@pytest.mark.parametrize("world,tile_h,gather,by_gather", [(2, 160, 4, False), (4, 160, 4, False), (3, 136, 3, False), (4, 160, 4, True)])  # 136 = 8 * 17: only depth mips 1..3 travel
+def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather, by_gather, monkeypatch):
+    """by_gather False (the default): hit colours by request / reply (vkr_hit_requests / _reply / _scatter); True: the albedo of
+    the whole frame all-gathered into every rank.  Both must equal the plain frame on every tile interior."""
     import torch
+
+    monkeypatch.setenv("VKR_TILED_ALBEDO_GATHER", "1" if by_gather else "0")
 
     from vk_renderer_amd.camera import FrameSetup
     from vk_renderer_amd.tiling import TiledFrame
@@ -69,6 +73,12 @@ def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather):
         t.flush()
     torch.cuda.synchronize()
     bad = sum(_interiors_differ(t, want, tw, th) for t in ranks)
+    if not by_gather:
+        m = ranks[0].hit_matrix  # [requester][owner] of the last frame
+        assert sum(m) > 0 and all(m[r * world + r] == 0 for r in range(world)), f"hit footprints cross the strips of this frame: {m}"
+        assert all(t.frame.tiled_hit_errors() == 0 for t in ranks)
+        # far fewer bytes than the albedo of the other strips
+        assert 16 * sum(m) < 4 * W * H * (world - 1) // world
     for t in ranks:
         t.frame.close()
     assert bad == 0

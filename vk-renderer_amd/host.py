@@ -3,6 +3,7 @@
 a time.  Device memory for every graph image comes from torch through the allocator hook, so
 the launcher can hand the same memory to torch.distributed (RCCL) without copies."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -24,7 +25,7 @@ class HostConfig(C.Structure):
 
 class TiledConfig(C.Structure):
     _fields_ = [("full_width", C.c_uint32), ("full_height", C.c_uint32), ("rank", C.c_uint32), ("world", C.c_uint32),
-                ("halo", C.c_uint32), ("gathered_mips", C.c_uint32), ("force_tiled", C.c_uint32), ("reserved", C.c_uint32),
+                ("halo", C.c_uint32), ("gathered_mips", C.c_uint32), ("force_tiled", C.c_uint32), ("albedo_by_gather", C.c_uint32),
                 ("stream", C.c_void_p), ("comm", C.c_void_p), ("row_bounds", C.POINTER(C.c_uint32))]
 
 
@@ -98,6 +99,12 @@ def lib():
         l.vkrh_tiled_phase.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_tiled_gather_parts.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(GatherPart), C.c_uint32, C.POINTER(C.c_uint32)]
         l.vkrh_tiled_halo_peers.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(HaloPeer), C.c_uint32, C.POINTER(C.c_uint32)]
+        l.vkrh_tiled_hit_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        l.vkrh_tiled_hit_requests.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(HaloPeer), C.c_uint32, C.POINTER(C.c_uint32)]
+        l.vkrh_tiled_hit_replies.argtypes = [C.c_void_p, C.POINTER(HaloPeer), C.c_uint32, C.POINTER(C.c_uint32)]
+        l.vkrh_tiled_hit_finish.argtypes = [C.c_void_p]
+        l.vkrh_tiled_hit_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        l.vkrh_tiled_hit_errors.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         l.vkrh_tiled_time_waits.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_tiled_wait_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.vkrh_balance_rows.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -171,12 +178,14 @@ class HostFrame:
         if stream is None:
             stream = torch.cuda.current_stream(device).cuda_stream
         self.tiled_handle = None
+        self.albedo_by_gather = True  # only the C++ tiled frame has the hit-colour request / reply
         if native_tiled is not None:
             nt = native_tiled
             comm = nt.get("comm")
             bounds = nt.get("row_bounds")  # world + 1 strip boundaries (rows), or None for equal strips
             arr = (C.c_uint32 * len(bounds))(*bounds) if bounds is not None else None
-            tc = TiledConfig(W, H, nt["rank"], nt["world"], nt["halo"], nt["gathered_mips"], 1 if nt.get("force_tiled") else 0, 0,
+            self.albedo_by_gather = bool(nt.get("albedo_by_gather", os.environ.get("VKR_TILED_ALBEDO_GATHER") == "1"))
+            tc = TiledConfig(W, H, nt["rank"], nt["world"], nt["halo"], nt["gathered_mips"], 1 if nt.get("force_tiled") else 0, 1 if self.albedo_by_gather else 0,
                              C.c_void_p(stream), C.c_void_p(comm.handle if comm is not None else None),
                              C.cast(arr, C.POINTER(C.c_uint32)) if arr is not None else None)
             self.comm = comm  # keep the communicator alive as long as the frame
@@ -347,6 +356,40 @@ class HostFrame:
         n = C.c_uint32(0)
         self._check(lib().vkrh_tiled_halo_peers(self.tiled_handle, surface, out, 2, C.byref(n)))
         return [(out[i].peer, out[i].send, out[i].recv, out[i].send_bytes) for i in range(n.value)]
+
+    # the hit-colour request / reply of the C++ tiled frame, step by step (lockstep harness; frame.hpp)
+    def tiled_hit_counts(self, world):
+        row = (C.c_uint32 * world)()
+        self._check(lib().vkrh_tiled_hit_counts(self.tiled_handle, row))
+        return list(row)
+
+    def _peer_list(self, out, n):
+        return [(out[i].peer, out[i].send, out[i].send_bytes, out[i].recv, out[i].recv_bytes) for i in range(n.value)]
+
+    def tiled_hit_requests(self, matrix):
+        """matrix: world x world counts, row-major [requester][owner] -> [(peer, send address, send bytes, recv address, recv bytes)]"""
+        flat = (C.c_uint32 * len(matrix))(*matrix)
+        out, n = (HaloPeer * 16)(), C.c_uint32(0)
+        self._check(lib().vkrh_tiled_hit_requests(self.tiled_handle, flat, out, 16, C.byref(n)))
+        return self._peer_list(out, n)
+
+    def tiled_hit_replies(self):
+        out, n = (HaloPeer * 16)(), C.c_uint32(0)
+        self._check(lib().vkrh_tiled_hit_replies(self.tiled_handle, out, 16, C.byref(n)))
+        return self._peer_list(out, n)
+
+    def tiled_hit_finish(self):
+        self._check(lib().vkrh_tiled_hit_finish(self.tiled_handle))
+
+    def tiled_hit_errors(self):
+        e = C.c_uint32(0)
+        self._check(lib().vkrh_tiled_hit_errors(self.tiled_handle, C.byref(e)))
+        return int(e.value)
+
+    def tiled_hit_bytes(self):
+        b = C.c_uint64(0)
+        self._check(lib().vkrh_tiled_hit_bytes(self.tiled_handle, C.byref(b)))
+        return int(b.value)
 
     def close(self):
         if self.tiled_handle:

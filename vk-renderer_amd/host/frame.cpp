@@ -257,6 +257,7 @@ struct TiledFrame {
       check(hipStreamCreateWithPriority(&xchg, hipStreamNonBlocking, prio_high), "exchange stream");
       for (auto& e : ev_ready) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
       for (auto& e : ev_done) check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event");
+      if (by_request()) hit_init();
       for (int s = 0; s < 3; s++)
         for (int n = 0; n < 2; n++) {
           if (!neighbour(n, nullptr)) continue;
@@ -277,6 +278,7 @@ struct TiledFrame {
     for (auto e : ev_ready) if (e) (void)hipEventDestroy(e);
     for (auto e : ev_done) if (e) (void)hipEventDestroy(e);
     for (auto& s : halo) for (auto& b : s) { gpu::device_free(b.send); gpu::device_free(b.recv); }
+    hit_release();
   }
 
   // ---- geometry -------------------------------------------------------------------------------------------------
@@ -412,6 +414,123 @@ struct TiledFrame {
     halo_in_flight[s] = false;
   }
 
+  // ---- hit colours by request / reply (frame.hpp; csrc/hit_exchange.hip) ------------------------------------------------
+  struct HitState {
+    uint32_t* counts = nullptr;     // device: [world] counts, [world] cursors, [1] reply errors, [world * world] gathered matrix
+    uint32_t* host_counts = nullptr;  // pinned: world * world + 1
+    vkr_hit_request* req_out = nullptr; uint64_t* reply_in = nullptr; uint64_t cap_out = 0;   // what I ask / get back
+    vkr_hit_request* req_in = nullptr; uint64_t* reply_out = nullptr; uint64_t cap_in = 0;    // what I am asked / answer
+    std::vector<uint32_t> out_seg, in_seg;  // [world + 1]: my requests for owner o / the requests of rank r for me, as runs
+    uint64_t wire_bytes = 0;
+    bool counted = false;
+  } hit;
+  bool by_request() const { return tiled && cfg.world > 1 && !cfg.albedo_by_gather; }
+  vkr_img rays_img() { return frame->graph.get_image(frame->ssr.get_rays())->describe(0, 1); }
+  vkr_img albedo_img() { return frame->graph.get_image(frame->gbuffer.albedo)->describe(0, 1); }
+  vkr_img frame_albedo_img() { return frame->graph.get_image(frame->gbuffer.frame_albedo)->describe(0, 1); }
+  void hit_init() {
+    const uint32_t w = cfg.world;
+    hit.counts = (uint32_t*)gpu::device_alloc(sizeof(uint32_t) * (2 * w + 1 + w * w));
+    check(hipHostMalloc((void**)&hit.host_counts, sizeof(uint32_t) * (w * w + 1), hipHostMallocDefault), "pinned counts");
+    hit.out_seg.assign(w + 1, 0); hit.in_seg.assign(w + 1, 0);
+  }
+  void hit_release() {
+    gpu::device_free(hit.counts);
+    if (hit.host_counts) (void)hipHostFree(hit.host_counts);
+    gpu::device_free(hit.req_out); gpu::device_free(hit.reply_in); gpu::device_free(hit.req_in); gpu::device_free(hit.reply_out);
+  }
+  // own rows of the whole-frame albedo: the window's rows are copied where the all-gather would have put the tile's
+  void hit_local_rows(hipStream_t s) {
+    const vkr_img a = albedo_img(), f = frame_albedo_img();
+    if (a.pitch_bytes[0] != f.pitch_bytes[0] || a.width != f.width) throw std::runtime_error {"tiled frame: window and whole-frame albedo must share width and row pitch"};
+    check(hipMemcpyAsync((uint8_t*)f.base + uint64_t(a.origin_y) * f.pitch_bytes[0], a.base, uint64_t(a.height) * a.pitch_bytes[0], hipMemcpyDeviceToDevice, s), "albedo rows");
+  }
+  // pass 1, on the compute stream right after the trace
+  void hit_count() {
+    const uint32_t w = cfg.world;
+    check(hipMemsetAsync(hit.counts, 0, sizeof(uint32_t) * (2 * w + 1), compute), "memset");
+    const vkr_img r = rays_img();
+    if (vkr_hit_requests(&r, W, H, bounds.data(), w, wy0, wy0 + wh, hit.counts, nullptr, nullptr, nullptr, compute) != 0)
+      throw std::runtime_error {std::string {"hit_requests: "} + vkr_last_error()};
+    hit.counted = true;
+  }
+  static void grow(void** p, uint64_t* cap, uint64_t need, uint64_t elem) {
+    if (need <= *cap) return;
+    gpu::device_free(*p);
+    *cap = need + need / 4 + 1024;
+    *p = gpu::device_alloc(*cap * elem);
+  }
+  // pass 2 on stream s, given everybody's counts: fills req_out and returns the peer list of the request exchange
+  uint32_t hit_write(const uint32_t* matrix, hipStream_t s, vkr_halo_peer* peers) {
+    const uint32_t w = cfg.world, me = cfg.rank;
+    for (uint32_t o = 0; o < w; o++) hit.out_seg[o + 1] = hit.out_seg[o] + matrix[me * w + o];
+    for (uint32_t r = 0; r < w; r++) hit.in_seg[r + 1] = hit.in_seg[r] + matrix[r * w + me];
+    if (matrix[me * w + me]) throw std::runtime_error {"tiled frame: a rank requested hit colours from itself"};
+    uint64_t cap = hit.cap_out;
+    grow((void**)&hit.req_out, &cap, hit.out_seg[w], sizeof(vkr_hit_request));
+    grow((void**)&hit.reply_in, &hit.cap_out, hit.out_seg[w], sizeof(uint64_t));
+    cap = hit.cap_in;
+    grow((void**)&hit.req_in, &cap, hit.in_seg[w], sizeof(vkr_hit_request));
+    grow((void**)&hit.reply_out, &hit.cap_in, hit.in_seg[w], sizeof(uint64_t));
+    if (hit.out_seg[w]) {
+      const vkr_img r = rays_img();
+      if (vkr_hit_requests(&r, W, H, bounds.data(), w, wy0, wy0 + wh, hit.counts, hit.counts + w, hit.out_seg.data(), hit.req_out, s) != 0)
+        throw std::runtime_error {std::string {"hit_requests: "} + vkr_last_error()};
+    }
+    uint32_t n = 0;
+    hit.wire_bytes = 0;
+    for (uint32_t p = 0; p < w; p++) {
+      const uint64_t so = hit.out_seg[p + 1] - hit.out_seg[p], ri = hit.in_seg[p + 1] - hit.in_seg[p];
+      if (p == me || (so == 0 && ri == 0)) continue;
+      peers[n++] = vkr_halo_peer {int32_t(p), 0u, hit.req_out + hit.out_seg[p], so * sizeof(vkr_hit_request), hit.req_in + hit.in_seg[p], ri * sizeof(vkr_hit_request)};
+      hit.wire_bytes += (ri + so) * 8;  // requests in now, as many replies in later
+    }
+    return n;
+  }
+  // answers on stream s; returns the peer list of the way back
+  uint32_t hit_reply(hipStream_t s, vkr_halo_peer* peers) {
+    const uint32_t w = cfg.world, me = cfg.rank;
+    const vkr_img a = albedo_img();
+    if (vkr_hit_reply(&a, hit.req_in, hit.in_seg[w], hit.reply_out, hit.counts + 2 * w, s) != 0) throw std::runtime_error {std::string {"hit_reply: "} + vkr_last_error()};
+    uint32_t n = 0;
+    for (uint32_t p = 0; p < w; p++) {
+      const uint64_t so = hit.in_seg[p + 1] - hit.in_seg[p], ri = hit.out_seg[p + 1] - hit.out_seg[p];
+      if (p == me || (so == 0 && ri == 0)) continue;
+      peers[n++] = vkr_halo_peer {int32_t(p), 0u, hit.reply_out + hit.in_seg[p], so * sizeof(uint64_t), hit.reply_in + hit.out_seg[p], ri * sizeof(uint64_t)};
+    }
+    return n;
+  }
+  void hit_scatter(hipStream_t s) {
+    const vkr_img f = frame_albedo_img();
+    if (vkr_hit_scatter(&f, hit.req_out, hit.reply_in, hit.out_seg[cfg.world], s) != 0) throw std::runtime_error {std::string {"hit_scatter: "} + vkr_last_error()};
+    hit.counted = false;
+  }
+  // The native exchange: the counts of every rank cross the host once (the compute stream has GTAO queued meanwhile), the
+  // rest is enqueued on the exchange stream and ends in ev_done[VKRH_GATHER_ALBEDO], which the filter waits for.
+  void hit_exchange_native() {
+    const uint32_t w = cfg.world;
+    check(hipEventRecord(ev_ready[VKRH_GATHER_ALBEDO], compute), "event record");  // NOTE: recorded by the caller's order: after the count pass
+    check(hipStreamWaitEvent(xchg, ev_ready[VKRH_GATHER_ALBEDO], 0), "stream wait");
+    const vkr_gather_part part {hit.counts, hit.counts + 2 * w + 1, uint64_t(w) * sizeof(uint32_t)};
+    if (vkr_all_gather(cfg.comm, &part, 1, xchg) != 0) throw std::runtime_error {std::string {"exchange: "} + vkr_last_error()};
+    check(hipMemcpyAsync(hit.host_counts, hit.counts + 2 * w + 1, sizeof(uint32_t) * w * w, hipMemcpyDeviceToHost, xchg), "counts to host");
+    hit_pending = true;
+  }
+  bool hit_pending = false;
+  void hit_exchange_complete() {  // host-blocking: call with the next compute work already queued
+    if (!hit_pending) return;
+    hit_pending = false;
+    check(hipStreamSynchronize(xchg), "synchronize");
+    vkr_halo_peer peers[HIT_PEERS];
+    uint32_t n = hit_write(hit.host_counts, xchg, peers);
+    if (vkr_halo_exchange(cfg.comm, peers, n, xchg) != 0) throw std::runtime_error {std::string {"exchange: "} + vkr_last_error()};
+    n = hit_reply(xchg, peers);
+    if (vkr_halo_exchange(cfg.comm, peers, n, xchg) != 0) throw std::runtime_error {std::string {"exchange: "} + vkr_last_error()};
+    hit_scatter(xchg);
+    check(hipEventRecord(ev_done[VKRH_GATHER_ALBEDO], xchg), "event record");
+  }
+  static constexpr uint32_t HIT_PEERS = 16;
+
   // ---- the frame, in phases (an exchange may only start / must be complete at a phase boundary) ------------------------
   void phase(uint32_t p) {
     PostFxFrame& f = *frame;
@@ -419,7 +538,8 @@ struct TiledFrame {
       case 0:
         f.run(VKRH_STAGE_DOWNSAMPLE);
         start_gather(VKRH_GATHER_HIZ);
-        start_gather(VKRH_GATHER_ALBEDO);
+        if (!by_request()) start_gather(VKRH_GATHER_ALBEDO);
+        else hit_local_rows(compute);
         break;
       case 1:
         finish_halo(VKRH_HALO_TAA);
@@ -430,14 +550,20 @@ struct TiledFrame {
       case 2:
         wait(VKRH_GATHER_HIZ);
         f.run(VKRH_STAGE_HIZ_TAIL | VKRH_STAGE_SSR_TRACE);
+        if (by_request()) {
+          hit_count();
+          if (cfg.comm) hit_exchange_native();
+        }
         break;
       case 3:  // GTAO needs the trace's (occlusion, pdf) but not the albedo: it runs ahead of the reference's order to hide the second gather
         finish_halo(VKRH_HALO_AO);
         f.run(VKRH_STAGE_GTAO);
         copy_halo(VKRH_HALO_AO, true);
         start_halo(VKRH_HALO_AO);
+        if (by_request() && cfg.comm) hit_exchange_complete();  // the host waits for the counts here, with GTAO queued on the device
         break;
       case 4:
+        if (by_request() && !cfg.comm && hit.counted) throw std::runtime_error {"vkrh_tiled_phase: the harness must complete the hit-colour exchange before phase 4"};
         wait(VKRH_GATHER_ALBEDO);
         finish_halo(VKRH_HALO_SSR);
         f.run(VKRH_STAGE_SSR_RESOLVE);
@@ -750,6 +876,49 @@ int vkrh_tiled_halo_peers(void* tiled, uint32_t surface, vkr_halo_peer* out, uin
   return guarded([&] {
     if (!tiled || !out || !count || capacity < 2 || surface > 2) throw std::runtime_error{"vkrh_tiled_halo_peers: bad arguments (capacity >= 2)"};
     *count = ((TiledFrame*)tiled)->halo_peers((int)surface, out);
+  });
+}
+int vkrh_tiled_hit_counts(void* tiled, uint32_t* row) {
+  return guarded([&] {
+    auto* t = (TiledFrame*)tiled;
+    if (!t || !row || !t->by_request()) throw std::runtime_error{"vkrh_tiled_hit_counts: not a tiled frame with hit-colour requests"};
+    TiledFrame::check(hipMemcpyAsync(row, t->hit.counts, sizeof(uint32_t) * t->cfg.world, hipMemcpyDeviceToHost, t->compute), "counts");
+    TiledFrame::check(hipStreamSynchronize(t->compute), "synchronize");
+  });
+}
+int vkrh_tiled_hit_requests(void* tiled, const uint32_t* matrix, vkr_halo_peer* peers, uint32_t capacity, uint32_t* count) {
+  return guarded([&] {
+    auto* t = (TiledFrame*)tiled;
+    if (!t || !matrix || !peers || !count || capacity < TiledFrame::HIT_PEERS || !t->by_request()) throw std::runtime_error{"vkrh_tiled_hit_requests: bad arguments (capacity >= 16)"};
+    *count = t->hit_write(matrix, t->compute, peers);
+  });
+}
+int vkrh_tiled_hit_replies(void* tiled, vkr_halo_peer* peers, uint32_t capacity, uint32_t* count) {
+  return guarded([&] {
+    auto* t = (TiledFrame*)tiled;
+    if (!t || !peers || !count || capacity < TiledFrame::HIT_PEERS || !t->by_request()) throw std::runtime_error{"vkrh_tiled_hit_replies: bad arguments (capacity >= 16)"};
+    *count = t->hit_reply(t->compute, peers);
+  });
+}
+int vkrh_tiled_hit_finish(void* tiled) {
+  return guarded([&] {
+    auto* t = (TiledFrame*)tiled;
+    if (!t || !t->by_request()) throw std::runtime_error{"vkrh_tiled_hit_finish: not a tiled frame with hit-colour requests"};
+    t->hit_scatter(t->compute);
+  });
+}
+int vkrh_tiled_hit_errors(void* tiled, uint32_t* errors) {
+  return guarded([&] {
+    auto* t = (TiledFrame*)tiled;
+    if (!t || !errors || !t->by_request()) throw std::runtime_error{"vkrh_tiled_hit_errors: not a tiled frame with hit-colour requests"};
+    TiledFrame::check(hipDeviceSynchronize(), "synchronize");
+    TiledFrame::check(hipMemcpy(errors, t->hit.counts + 2 * t->cfg.world, sizeof(uint32_t), hipMemcpyDeviceToHost), "errors");
+  });
+}
+int vkrh_tiled_hit_bytes(void* tiled, uint64_t* bytes) {
+  return guarded([&] {
+    if (!tiled || !bytes) throw std::runtime_error{"vkrh_tiled_hit_bytes: NULL argument"};
+    *bytes = ((TiledFrame*)tiled)->hit.wire_bytes;
   });
 }
 int vkrh_tiled_time_waits(void* tiled, uint32_t on) {

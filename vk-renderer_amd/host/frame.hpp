@@ -119,11 +119,16 @@ int vkrh_set_async(void* frame, uint32_t on);
  * Rank r of `world` owns rows [r * H / world, (r + 1) * H / world) of the full_width x full_height frame and holds
  * them plus `halo` rows above / below (clipped to the frame).  One vkrh_tiled_step() is one frame:
  *
- *   downsample | all-gather(depth mips 1..k + downsampled normals) and all-gather(albedo) start on the exchange stream
+ *   downsample | all-gather(depth mips 1..k + downsampled normals) starts on the exchange stream
  *   TAA (needs neither)            | its halo refresh starts
- *   Hi-Z tail + SSR trace          (after the first gather)
- *   GTAO main, filter, accumulate  | its halo refresh starts
- *   SSR filter + blur              (after the second gather) | its halo refresh starts; history remaps
+ *   Hi-Z tail + SSR trace          (after the gather) | hit-colour requests are counted
+ *   GTAO main, filter, accumulate  | its halo refresh starts | request / reply for the hit colours on the exchange stream
+ *   SSR filter + blur              (after the replies are in place) | its halo refresh starts; history remaps
+ *
+ * Hit colours: the filter reads the albedo at the hit position of every valid ray, anywhere in the frame.  Each rank asks
+ * the owners for the footprint rows outside its window (vkr_hit_requests / _reply / _scatter, 8-byte requests and
+ * replies moved with vkr_halo_exchange) instead of receiving the albedo of the whole frame; the counts cross the host
+ * once per frame, while GTAO keeps the device busy.  albedo_by_gather = 1 restores the all-gather.
  *
  * Every exchange is one grouped RCCL launch (vkr_all_gather / vkr_halo_exchange) on the frame's own exchange stream,
  * ordered against the compute stream with events only: the host never blocks, and a halo refresh issued after the
@@ -136,7 +141,7 @@ typedef struct vkrh_tiled_config {
   uint32_t halo;            /* full-res pixels, even, a multiple of 2^gathered_mips                          */
   uint32_t gathered_mips;   /* depth image-mips 1..k travel by all-gather (the tile extent must divide by 2^k) */
   uint32_t force_tiled;     /* world == 1: still run the gathers and the staged frame (rehearsal)              */
-  uint32_t reserved;
+  uint32_t albedo_by_gather;/* 0 (default): hit colours by request / reply; 1: all-gather the albedo of the whole frame      */
   void*    stream;          /* compute stream                                                                */
   vkr_comm* comm;           /* RCCL communicator of include/vkr_postfx.h, or NULL (no wire: lockstep harness) */
   /* NULL: world strips of full_height / world rows.  Otherwise world + 1 increasing row numbers, [0] = 0 and [world] =
@@ -155,6 +160,21 @@ int   vkrh_tiled_flush(void* tiled);                 /* completes the halo refre
 int   vkrh_tiled_phase(void* tiled, uint32_t phase);
 int   vkrh_tiled_gather_parts(void* tiled, uint32_t which, vkr_gather_part* out, uint32_t capacity, uint32_t* count);
 int   vkrh_tiled_halo_peers(void* tiled, uint32_t surface, vkr_halo_peer* out, uint32_t capacity, uint32_t* count);
+/* The hit-colour request / reply (albedo_by_gather == 0), step by step for the lockstep harness — between phase 3 and phase 4
+ * of every rank, the harness moving the bytes of each peer list exactly as vkr_halo_exchange would:
+ *   vkrh_tiled_hit_counts    row[o] = the requests this rank has for owner o (counted on the device at the end of phase 2)
+ *   vkrh_tiled_hit_requests  matrix[r * world + o] = rank r's count for owner o, identical on every rank: writes the
+ *                            requests and returns who gets / sends which bytes
+ *   vkrh_tiled_hit_replies   answers the requests that arrived and returns the peer list of the way back
+ *   vkrh_tiled_hit_finish    writes the replies that arrived into the whole-frame albedo image                          */
+int   vkrh_tiled_hit_counts(void* tiled, uint32_t* row);
+int   vkrh_tiled_hit_requests(void* tiled, const uint32_t* matrix, vkr_halo_peer* peers, uint32_t capacity, uint32_t* count);
+int   vkrh_tiled_hit_replies(void* tiled, vkr_halo_peer* peers, uint32_t capacity, uint32_t* count);
+int   vkrh_tiled_hit_finish(void* tiled);
+/* bytes this rank received over the wire for the hit colours in the last frame (requests in + replies in)              */
+int   vkrh_tiled_hit_bytes(void* tiled, uint64_t* bytes);
+/* requests of the last frame that this rank could not answer from its window (0 unless the ranks' strips disagree); synchronises */
+int   vkrh_tiled_hit_errors(void* tiled, uint32_t* errors);
 /* Diagnostics: how long the compute stream stood still for each exchange.  vkrh_tiled_time_waits(on) brackets every wait
  * with an event pair (≈7 us of queue time per frame: for a calibration run, not for the timed one);
  * vkrh_tiled_wait_times returns the totals since the last call in ms — [0] Hi-Z gather, [1] albedo gather, [2] TAA halo,

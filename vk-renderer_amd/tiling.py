@@ -539,19 +539,46 @@ def _move_halo(ranks, surface):
             _bytes_at(ranks, recv, nbytes).copy_(_bytes_at(ranks, send, nbytes))
 
 
+def _move_p2p(ranks, lists):
+    """what vkr_halo_exchange delivers for arbitrary peer lists [(peer, send, send bytes, recv, recv bytes)] per rank: the
+    send of rank a to rank b lands in the receive buffer rank b names for a"""
+    for b, mine in enumerate(lists):
+        for peer, _, _, recv, recv_bytes in mine:
+            if not recv_bytes:
+                continue
+            send = [p for p in lists[peer] if p[0] == b]
+            assert len(send) == 1 and send[0][2] == recv_bytes, "the two ends of a hit-colour exchange disagree on its size"
+            _bytes_at(ranks, recv, recv_bytes).copy_(_bytes_at(ranks, send[0][1], recv_bytes))
+
+
+def _hit_exchange(ranks):
+    """the hit-colour request / reply of frame.hpp between in-process ranks: counts -> requests -> replies -> scatter"""
+    world = len(ranks)
+    matrix = [c for t in ranks for c in t.frame.tiled_hit_counts(world)]
+    _move_p2p(ranks, [t.frame.tiled_hit_requests(matrix) for t in ranks])
+    _move_p2p(ranks, [t.frame.tiled_hit_replies() for t in ranks])
+    for t in ranks:
+        t.frame.tiled_hit_finish()
+    return matrix
+
+
 def native_lockstep_frame(ranks):
     """One frame of every in-process rank of a strip grid (C++ tiled frames made with native=True, comm=None), advanced
     phase by phase; between phases the harness copies exactly the buffers the RCCL calls would move."""
+    by_gather = ranks[0].frame.albedo_by_gather or len(ranks) == 1
     for p in range(5):
         for t in ranks:
             t.frame.tiled_phase(p)
-        if p == 0:      # both gathers start after the downsample; the harness completes them at once
+        if p == 0:      # the gathers start after the downsample; the harness completes them at once
             _move_gather(ranks, 0)
-            _move_gather(ranks, 1)
+            if by_gather:
+                _move_gather(ranks, 1)
         elif p == 1:
             _move_halo(ranks, 0)
         elif p == 3:
             _move_halo(ranks, 1)
+            if not by_gather:
+                ranks[0].hit_matrix = _hit_exchange(ranks)
         elif p == 4:
             _move_halo(ranks, 2)
     for t in ranks:
