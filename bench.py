@@ -361,6 +361,25 @@ def main():
     frame.enable_task_timing(False)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)] if marks else []
 
+    # The headline depends on the frame's content: tiles of the blur / filter without a reflection / hit skip their taps
+    # (bit-identical output).  A second, short timed loop with the skips switched off gives the content-independent number.
+    noskip_ms = None
+    if world == 1 and args.config in ("c2", "c3", "c4", "c5"):
+        lib = abi.product()
+        before = lib.vkr_get_switches()
+        lib.vkr_set_switches(before | abi.SWITCH_BLUR_NO_SKIP | abi.SWITCH_FILTER_NO_SKIP)
+        NOSKIP_STEPS = max(10, min(args.steps, 20))
+        for _ in range(3):
+            tiled.step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(NOSKIP_STEPS):
+            tiled.step()
+        tiled.flush()
+        barrier()
+        noskip_ms = (time.perf_counter() - t1) / NOSKIP_STEPS * 1e3
+        lib.vkr_set_switches(before)
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -451,6 +470,19 @@ def main():
             "exchange_bytes_per_rank": exchange_bytes_per_rank,
             "measured_read_gbps": measured_read,
         }
+        if noskip_ms is not None:
+            out["ms_per_step_noskip"] = noskip_ms
+            out["value_noskip"] = px / (noskip_ms * 1e-3) / 1e6
+            out["noskip_note"] = "second timed loop with VKR_SWITCH_BLUR_NO_SKIP | VKR_SWITCH_FILTER_NO_SKIP: every tap evaluated, same output"
+        if world > 1 and (W, H) == (C4_W, C4_H):
+            # the denominator of the scaling curve: the SAME 15360x8640 frame on one GPU (python bench.py --config c4 --gpus 1)
+            ref_path = os.path.join(ROOT, "profiles", "r03_bench_c4_n1.json")
+            if os.path.exists(ref_path):
+                with open(ref_path) as f:
+                    ref = json.load(f)
+                out["single_gpu_same_frame_ms"] = ref["ms_per_step"]
+                out["single_gpu_same_frame_source"] = "profiles/r03_bench_c4_n1.json (python bench.py --config c4 --gpus 1 on one MI355X)"
+                out["speedup_vs_single_gpu_same_frame"] = ref["ms_per_step"] / (elapsed / args.steps * 1e3)
         if step_ms:  # median of >= 50 hipEvent-timed frames, beside the contract's wall-clock mean
             med = statistics.median(step_ms)
             out["ms_per_step_median"] = med

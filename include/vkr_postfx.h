@@ -456,6 +456,18 @@ int vkr_hit_requests(const vkr_img* rays, uint32_t albedo_width, uint32_t albedo
 int vkr_hit_reply(const vkr_img* albedo, const vkr_hit_request* requests, uint32_t count, uint64_t* replies, uint32_t* error_counter, void* stream);
 int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_hit_request* requests, const uint64_t* replies, uint32_t count, void* stream);
 
+/* Measurement switches — the library's only process-wide state.  The environment (VKR_BLUR_NO_SKIP, VKR_FILTER_NO_SKIP,
+ * VKR_TAA_GENERIC, VKR_SHADING_GENERIC) is read once, at the first launch that asks; afterwards only vkr_set_switches
+ * changes them.  NO_SKIP: evaluate every tap of the blur / filter even in tiles without a reflection / hit (a
+ * content-independent time; the stored texels are the same wherever every weight is finite).  GENERIC: the TAA /
+ * shading instantiations that do not assume equal window layouts.                                                  */
+#define VKR_SWITCH_BLUR_NO_SKIP    1u
+#define VKR_SWITCH_FILTER_NO_SKIP  2u
+#define VKR_SWITCH_TAA_GENERIC     4u
+#define VKR_SWITCH_SHADING_GENERIC 8u
+uint32_t vkr_get_switches(void);
+void vkr_set_switches(uint32_t mask);
+
 /* float4 streaming-read microbenchmark: the measured-roofline denominator of
  * SURVEY.md 8(d).  Reads `bytes` from `src`, writes one float per block to `sink`.      */
 int vkr_stream_read(const void* src, uint64_t bytes, float* sink, uint32_t sink_len, void* stream);

@@ -40,7 +40,8 @@ struct Mailbox {
   std::atomic<uint64_t> sent;      // chunks written by the sender
   std::atomic<uint64_t> consumed;  // chunks read by the receiver
   uint64_t chunk_bytes;            // size of the chunk in the slot
-  uint64_t pad[5];
+  uint64_t message_bytes;          // size of the message the chunk belongs to: must be what the receiver expects
+  uint64_t pad[4];
 };
 struct Header {
   std::atomic<uint32_t> attached, detached;
@@ -117,6 +118,7 @@ void host_exchange(void* arg) {
       const size_t n = m.bytes - m.done < h->slot_bytes ? m.bytes - m.done : h->slot_bytes;
       std::memcpy(c->slot(c->rank, m.peer), g->out_staging + m.staging_offset + m.done, n);
       b.chunk_bytes = n;
+      b.message_bytes = m.bytes;
       b.sent.store(b.sent.load(std::memory_order_relaxed) + 1, std::memory_order_release);
       m.done += n;
       if (m.done == m.bytes) --open;
@@ -128,8 +130,9 @@ void host_exchange(void* arg) {
       Mailbox& b = h->box[m.peer][c->rank];
       if (b.sent.load(std::memory_order_acquire) == b.consumed.load(std::memory_order_relaxed)) continue;  // nothing there yet
       const size_t n = b.chunk_bytes;
-      if (n > m.bytes - m.done) {
-        fprintf(stderr, "[stub_rccl] rank %d: rank %d sent %zu bytes where %zu were expected: the ranks' call sequences differ\n", c->rank, m.peer, n, m.bytes - m.done);
+      if (b.message_bytes != m.bytes || n > m.bytes - m.done) {
+        fprintf(stderr, "[stub_rccl] rank %d: rank %d sent a chunk of %zu of a %llu-byte message where %zu of %zu were expected: the ranks' call sequences differ\n",
+                c->rank, m.peer, n, (unsigned long long)b.message_bytes, m.bytes - m.done, m.bytes);
         _exit(5);
       }
       std::memcpy(g->in_staging + m.staging_offset + m.done, c->slot(m.peer, c->rank), n);

@@ -72,9 +72,11 @@ WORKER = textwrap.dedent("""
         ox, oy = got.origin
         a = got.raw(0)[(y0 >> dv) - oy:(y0 >> dv) - oy + (th >> dv), (x0 >> dv) - ox:(x0 >> dv) - ox + (tw >> dv)]
         b = want.raw(0)[(y0 >> dv):(y0 >> dv) + (th >> dv), (x0 >> dv):(x0 >> dv) + (tw >> dv)]
-        n = int((a != b).any(axis=-1).sum())
+        d = (a != b).any(axis=-1)
+        n = int(d.sum())
         if n:
-            print(f'rank {rank} {name}: {n} differing texels')
+            ys = np.flatnonzero(d.any(axis=1))
+            print(f'rank {rank} {name}: {n} differing texels, tile rows {ys[0]}..{ys[-1]} of {th >> dv}')
         bad += n
     # the history halo rows a rank holds after flush() are its neighbours' interior rows (ADVICE r02: they used to be
     # unpacked into the image the next pass overwrites)

@@ -138,11 +138,12 @@ def test_taa_generic_footprints(size, oracle_lib, monkeypatch):
     oracle's image, also with a camera that moves enough for the depth test to decide (|velocity| >= 0.005)."""
     from vk_renderer_amd.camera import FrameSetup
 
-    for generic in ("", "1"):
-        if generic:
-            monkeypatch.setenv("VKR_TAA_GENERIC", generic)
-        else:
-            monkeypatch.delenv("VKR_TAA_GENERIC", raising=False)
+    from vk_renderer_amd import abi
+
+    lib = abi.product()
+    before = lib.vkr_get_switches()
+    for generic in (False, True):
+        lib.vkr_set_switches((before | abi.SWITCH_TAA_GENERIC) if generic else (before & ~abi.SWITCH_TAA_GENERIC))
         ref, gpu = _pair(*size, oracle_lib, setup=FrameSetup(*size))
         ref.synth()
         ref.build_prev_hiz()
@@ -155,6 +156,7 @@ def test_taa_generic_footprints(size, oracle_lib, monkeypatch):
         moving = int(((vel[..., 0] ** 2 + vel[..., 1] ** 2) >= 0.005 ** 2).sum())
         print(f"[parity] taa generic={bool(generic)}: texels with |velocity| >= 0.005: {moving}")
         assert moving > 0, "the test frame never reaches the depth comparison of the resolve"
+    lib.vkr_set_switches(before)
 
 
 def test_gtao_only_config1(oracle_lib):
@@ -213,14 +215,17 @@ def test_defered_shading(size, oracle_lib):
         gpu.shading(show_ao=show_ao)
         _compare(ref, gpu, ("color_out",), budget=1e-4)
     # the instantiation without shared footprints / paired loads (windows that differ in geometry) gives the same image
-    import os
-    os.environ["VKR_SHADING_GENERIC"] = "1"
+    from vk_renderer_amd import abi
+
+    lib = abi.product()
+    before = lib.vkr_get_switches()
+    lib.vkr_set_switches(before | abi.SWITCH_SHADING_GENERIC)
     try:
         gpu.shading(show_ao=0)
         ref.shading(show_ao=0)
         _compare(ref, gpu, ("color_out",), budget=1e-4)
     finally:
-        del os.environ["VKR_SHADING_GENERIC"]
+        lib.vkr_set_switches(before)
     # TAA then resolves the shaded colour (main.cpp:390-391)
     ref.shading()
     gpu.shading()

@@ -262,6 +262,10 @@ def product():
         lib.vkr_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
         lib.vkr_comm_destroy.argtypes = [C.c_void_p]
         lib.vkr_comm_available.argtypes = []
+        lib.vkr_get_switches.argtypes = []
+        lib.vkr_get_switches.restype = C.c_uint32
+        lib.vkr_set_switches.argtypes = [C.c_uint32]
+        lib.vkr_set_switches.restype = None
         lib.vkr_comm_available.restype = C.c_int
         lib.vkr_copy_rects.restype = C.c_int
         lib.vkr_raster_scratch_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
@@ -285,6 +289,8 @@ def check(rc, lib=None):
 
 
 COMM_ID_BYTES = 128
+# measurement switches (include/vkr_postfx.h VKR_SWITCH_*): vkr_get_switches / vkr_set_switches
+SWITCH_BLUR_NO_SKIP, SWITCH_FILTER_NO_SKIP, SWITCH_TAA_GENERIC, SWITCH_SHADING_GENERIC = 1, 2, 4, 8
 
 
 class Comm:

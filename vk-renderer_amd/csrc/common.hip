@@ -1,6 +1,8 @@
 // common.hip — library-wide pieces of the C-ABI: version, last-error string, format table.
 #include "vkr_host.hpp"
+#include <atomic>
 #include <cstdarg>
+#include <cstdlib>
 
 namespace vkr {
 static thread_local char g_error[512] = "";
@@ -11,6 +13,26 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 }  // namespace vkr
+
+// Measurement switches: read from the environment ONCE (first launch that asks), changed afterwards only through vkr_set_switches().
+namespace vkr {
+static std::atomic<uint32_t> g_switches{0x80000000u};  // top bit: not initialised yet
+uint32_t switches() {
+  uint32_t v = g_switches.load(std::memory_order_relaxed);
+  if (v & 0x80000000u) {
+    v = 0u;
+    if (getenv("VKR_BLUR_NO_SKIP")) v |= VKR_SWITCH_BLUR_NO_SKIP;
+    if (getenv("VKR_FILTER_NO_SKIP")) v |= VKR_SWITCH_FILTER_NO_SKIP;
+    if (getenv("VKR_TAA_GENERIC")) v |= VKR_SWITCH_TAA_GENERIC;
+    if (getenv("VKR_SHADING_GENERIC")) v |= VKR_SWITCH_SHADING_GENERIC;
+    uint32_t expected = 0x80000000u;
+    if (!g_switches.compare_exchange_strong(expected, v)) v = expected;
+  }
+  return v;
+}
+}  // namespace vkr
+extern "C" uint32_t vkr_get_switches(void) { return vkr::switches(); }
+extern "C" void vkr_set_switches(uint32_t mask) { vkr::g_switches.store(mask & 0x7FFFFFFFu, std::memory_order_relaxed); }
 
 extern "C" const char* vkr_version(void) { return "vkr_postfx 0.2 (gfx950)"; }
 extern "C" uint32_t vkr_numeric_contract(void) { return VKR_CONTRACT; }

@@ -181,151 +181,6 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
   *dst = o;
 }
 
-// ---- lane-parallel horizon search (measurement for DESIGN.md section 3; VKR_GTAO_LANES=1) -------------------------------
-// north_star words the horizon search as a wavefront reduction.  This variant spends 16 lanes on one pixel: lane i takes
-// sample i of find_horizon (all 16 bilinear taps of a pixel in flight at once), the break index is the first set bit of a
-// ballot of the adjacent-sample test z_i > z_(i-1) + 0.1 (z_(i-1) arrives by a DPP row shift), and the horizon cosine is a
-// DPP max-scan over the lanes before it.  Same arithmetic per sample as the serial loop, so the same image; it trades the
-// serial loop's early exit and its once-per-pixel set-up for parallelism (4 pixels per wave and round, 16 rounds per block).
-VKR_DEV float dpp_row_shr1(float v, float fill) {  // value of the previous lane inside a row of 16; lane 0 of a row gets `fill`
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x111, 0xF, 0xF, false));
-}
-template <int SHIFT> VKR_DEV float dpp_row_shr_max(float v) {
-  const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-1.0f), __float_as_int(v), 0x110 + SHIFT, 0xF, 0xF, false));
-  return vmax(v, o);
-}
-
-__global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main_lanes(GtaoArgs a) {
-  const i2 blk = xcd_block<2, 4>();
-  __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
-  __shared__ float s_depth[GT_TW * GT_TH];
-  __shared__ float s_ray[10][GT_BX * GT_BY];  // per pixel: start.xy, camera_start.xyz, dir.xy, v.xyz
-  __shared__ float s_hcos[GT_BX * GT_BY];
-  __shared__ unsigned char s_live[GT_BX * GT_BY];
-  const int tid = threadIdx.y * GT_BX + threadIdx.x;
-  srgb_lut_stage(s_lut, tid, GT_BX * GT_BY);
-  DepthTile tile;
-  tile.d = s_depth;
-  tile.x0 = a.out.ox + blk.x * GT_BX - GT_R;
-  tile.y0 = a.out.oy + blk.y * GT_BY - GT_R;
-  tile.fw = (float)a.depth.fw; tile.fh = (float)a.depth.fh;
-  for (int t = tid; t < GT_TW * GT_TH; t += GT_BX * GT_BY)
-    s_depth[t] = fetch_clamped<FmtD24>(a.depth, tile.x0 + t % GT_TW, tile.y0 + t / GT_TW);
-  __syncthreads();
-  // ---- phase A: one thread per pixel, everything up to the horizon search (k_gtao_main, MIS branch, one direction) ----
-  const int lx = blk.x * GT_BX + threadIdx.x;
-  const int ly = blk.y * GT_BY + threadIdx.y;
-  const int gx = a.out.ox + lx, gy = a.out.oy + ly;
-  const bool inside = lx < a.out.w && ly < a.out.h && gx < a.tex_w && gy < a.tex_h;
-  const f2 screen_uv = mk2(((float)gx + 0.5f) / (float)a.tex_w, ((float)gy + 0.5f) / (float)a.tex_h);
-  const float pdf_uniform = 1.0f / (2.0f * VKR_PI);
-  float frag_depth = 1.0f, n = 0.0f, np_len = 0.0f;
-  f3 camera_pos = mk3(0, 0, 0), w0 = mk3(0, 0, 0), camera_normal = mk3(0, 0, 0), sample_end_pos = mk3(0, 0, 0);
-  bool search = false;
-  if (inside) {
-    frag_depth = tile_sample(tile, screen_uv);
-    if (frag_depth < 1.0f) {
-      camera_pos = reconstruct_view_vec(screen_uv, frag_depth, a.pr);
-      w0 = -normalize(camera_pos);
-      const f3 n_world = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
-      camera_normal = normalize(xyz(mul(a.normal_mat, mk4(n_world.x, n_world.y, n_world.z, 0.0f))));
-      const float rad = vmin(100.0f / length(camera_pos), 16.0f);
-      const f2 dir_radius = mk2(rad / (float)a.depth.fw, rad / (float)a.depth.fh);
-      const int dir_slot = (((gx + gy) & 3) << 2) + (gx & 3);
-      const f2 cs = mk2(a.slice_cs[0][dir_slot][0], a.slice_cs[0][dir_slot][1]);
-      const f2 sample_direction = dir_radius * cs;
-      sample_end_pos = reconstruct_view_vec(screen_uv + sample_direction, frag_depth, a.pr);
-      f3 slice_normal = normalize_fast(cross(w0, -sample_end_pos));
-      f3 normal_projected = madd(camera_normal, -dot(camera_normal, slice_normal), slice_normal);
-      f3 X = -normalize_fast(cross(slice_normal, w0));
-      const float np_len2 = dot(normal_projected, normal_projected);
-      np_len = fast_sqrt(np_len2);
-      float n_cos = dot(normal_projected, X) * fast_rsq(np_len2);
-      if (!(fabsf(n_cos) <= 0.9999f)) {  // acos cliff: the exact sequence (see k_gtao_main)
-        slice_normal = normalize(cross(w0, -sample_end_pos));
-        normal_projected = madd(camera_normal, -dot(camera_normal, slice_normal), slice_normal);
-        X = -normalize(cross(slice_normal, w0));
-        n_cos = dot(normalize(normal_projected), X);
-        np_len = length(normal_projected);
-      }
-      n = VKR_PI / 2.0f - acosf(n_cos);
-      search = true;
-      s_ray[0][tid] = screen_uv.x; s_ray[1][tid] = screen_uv.y;
-      s_ray[2][tid] = camera_pos.x; s_ray[3][tid] = camera_pos.y; s_ray[4][tid] = camera_pos.z;
-      s_ray[5][tid] = sample_direction.x; s_ray[6][tid] = sample_direction.y;
-      s_ray[7][tid] = w0.x; s_ray[8][tid] = w0.y; s_ray[9][tid] = w0.z;
-    }
-  }
-  s_live[tid] = search ? 1 : 0;
-  __syncthreads();
-  // ---- phase B: 16 lanes per pixel; round r handles pixels r * 64 .. r * 64 + 63 of the block (4 per wave) ----
-  const int lane = tid & 63, sub = lane & 15, wave = tid >> 6;
-#pragma unroll 1
-  for (int round = 0; round < (GT_BX * GT_BY) / 64; round++) {
-    const int p = round * 64 + wave * 4 + (lane >> 4);
-    float sample_cos = -1.0f, z = 0.0f;
-    const bool live = s_live[p] != 0;
-    const float start_z = live ? s_ray[4][p] : 0.0f;
-    if (live) {
-      const f2 start = mk2(s_ray[0][p], s_ray[1][p]);
-      const f3 camera_start = mk3(s_ray[2][p], s_ray[3][p], start_z);
-      const f2 dir = mk2(s_ray[5][p], s_ray[6][p]);
-      const f3 v = mk3(s_ray[7][p], s_ray[8][p], s_ray[9][p]);
-      const f2 tc = madd(start, (float)(sub + 1) / 16.0f, dir);
-      const float sample_depth = tile_sample(tile, tc);
-      const f3 sample_pos = reconstruct_view_vec(tc, sample_depth, a.pr);
-      z = sample_pos.z;
-      const f3 sample_offset = sample_pos - camera_start;
-      sample_cos = dot(v, sample_offset) * fast_rsq(dot(sample_offset, sample_offset));
-    }
-    // main.comp:98: break at the first sample that rises by more than MAX_THIKNESS over the previous ACCEPTED one; every
-    // sample before the break was accepted, so "previous accepted" is simply the previous sample (the pixel itself for i = 1)
-    const float z_prev = dpp_row_shr1(z, start_z);
-    const unsigned long long brk = __ballot(live && z > z_prev + 0.1f);
-    const unsigned mine = (unsigned)(brk >> (lane & 48)) & 0xFFFFu;
-    const int first = mine ? __builtin_ctz(mine) : 16;
-    float h = sub < first ? sample_cos : -1.0f;
-    h = dpp_row_shr_max<1>(h); h = dpp_row_shr_max<2>(h); h = dpp_row_shr_max<4>(h); h = dpp_row_shr_max<8>(h);  // lane 15: max of the row
-    if (sub == 15) s_hcos[p] = h;
-  }
-  __syncthreads();
-  // ---- phase C: back to one thread per pixel (main.comp:244-273) ----
-  if (!inside) return;
-  float occ_x = 0.0f, occ_y = pdf_uniform;
-  uint2* dst = texel_ptr<uint2>(a.out, lx, ly);
-  if (!search) {
-    occ_x = 0.0f;
-    occ_y = 1.0f;  // sky, MIS
-  } else {
-    float h = acosf(s_hcos[tid]);
-    h = vmin(n + vmin(h - n, VKR_PI / 2.0f), h);
-    const float arc = vmax((-cosf(2.0f * h - n) + cosf(n)) + (2.0f * h) * sinf(n), 0.0f);
-    const float occlusion = (((1.0f / VKR_PI) * np_len) * 0.25f) * arc;
-    const f3 L = normalize(sample_end_pos - camera_pos);
-    const float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
-    const float pdf_ggx = sampleGGXdirPDF(a.pdf, w0, camera_normal, L, roughness * roughness);
-    const uint2 prev = *dst;
-    const float ao_x = half_bits_to_float(prev.x & 0xFFFFu), ao_y = half_bits_to_float(prev.x >> 16);
-    if (a.reflections_only != 0) {
-      float res = ao_x / ao_y;
-      occ_x = is_nan(res) ? 1.0f : res;
-      occ_y = 1.0f;
-    } else {
-      const float alpha = 1.0f / (a.weight_ratio + 1.0f);
-      const float betta = 1.0f - alpha;
-      const float mis_weight1 = alpha * fast_rcp(alpha * ao_y + betta * pdf_uniform);
-      const float mis_weight2 = betta * fast_rcp(alpha * pdf_ggx + betta * pdf_uniform);
-      const float mis_ao = ao_x * mis_weight1 + occlusion * mis_weight2;
-      occ_x = is_nan(mis_ao) ? occlusion / pdf_uniform : mis_ao;
-      occ_y = 1.0f;
-    }
-  }
-  uint2 o;
-  o.x = float_to_half_bits(occ_x) | (float_to_half_bits(occ_y) << 16);
-  o.y = 0u;
-  *dst = o;
-}
-
 // filter.comp:17-51: 4x4 taps at offsets -2..+1, depth-weighted mean of raw.r.  The block stages
 // {linearised depth, raw.r} of its pixels plus the (-2..+1) apron in LDS; out-of-frame taps read 0
 // like the shader's texelFetch (linearize(0) = -znear, raw = 0).
@@ -454,10 +309,7 @@ extern "C" int vkr_gtao_main(const vkr_img* depth, const vkr_gtao_params* params
     }
   }
   dim3 block(GT_BX, GT_BY);
-  static const bool lanes = getenv("VKR_GTAO_LANES") && atoi(getenv("VKR_GTAO_LANES")) != 0;  // measurement switch, DESIGN.md section 3
-  if (lanes && a.use_mis && a.tex_w == a.out.fw && a.tex_h == a.out.fh && same_window(a.depth, a.out))
-    hipLaunchKernelGGL(k_gtao_main_lanes, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
-  else if (a.tex_w == a.out.fw && a.tex_h == a.out.fh && same_window(a.depth, a.out))
+  if (a.tex_w == a.out.fw && a.tex_h == a.out.fh && same_window(a.depth, a.out))
     hipLaunchKernelGGL(k_gtao_main<true>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(k_gtao_main<false>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);

@@ -218,7 +218,7 @@ extern "C" int vkr_defered_shading(const vkr_img* albedo, const vkr_img* normal,
   a.max_roughness = push->min_max_roughness[1];
   a.show_ao = push->show_ao;
   const bool fast = same_layout(a.normal, a.albedo) && same_layout(a.normal, a.material) && same_layout(a.normal, a.depth0) && a.normal.w >= 2 &&
-                    a.depth1.w >= 2 && a.occlusion.w >= 2 && a.reflections.w >= 2 && a.brdf.w >= 2 && !getenv("VKR_SHADING_GENERIC");
+                    a.depth1.w >= 2 && a.occlusion.w >= 2 && a.reflections.w >= 2 && a.brdf.w >= 2 && !(switches() & VKR_SWITCH_SHADING_GENERIC);
   dim3 block(64, 4);
   if (fast) hipLaunchKernelGGL(k_defered_shading<true>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_defered_shading<false>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);

@@ -775,7 +775,7 @@ extern "C" int vkr_sssr_filter(const vkr_img* rays, const vkr_img* depth, const 
   load_mat(a.normal_mat, params->normal_mat);
   load_proj(a.pr, params->fovy, params->aspect, params->znear, params->zfar);
   a.render_flags = push->render_flags;
-  a.skip_empty_tiles = getenv("VKR_FILTER_NO_SKIP") ? 0u : 1u;  // measurement switch: identical output either way
+  a.skip_empty_tiles = (switches() & VKR_SWITCH_FILTER_NO_SKIP) ? 0u : 1u;  // measurement switch: identical output for finite weights (see the kernel)
   dim3 block(FILT_BX, FILT_BY);
   hipLaunchKernelGGL(k_sssr_filter, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_filter");
@@ -800,7 +800,7 @@ static int make_blur_args(BlurArgs& a, const vkr_img* depth, const vkr_img* norm
   a.max_roughness = push->max_roughness;
   a.accumulate = push->accumulate;
   a.disable_blur = push->disable_blur;
-  a.skip_empty_tiles = getenv("VKR_BLUR_NO_SKIP") ? 0u : 1u;  // measurement switch: identical output either way
+  a.skip_empty_tiles = (switches() & VKR_SWITCH_BLUR_NO_SKIP) ? 0u : 1u;  // measurement switch: identical output for finite weights
   if (a.max_roughness > 1.0f || a.max_roughness < 0.0f) {  // sigma <= 4 bounds the staged radius (blur.comp:45)
     set_error("sssr_blur: max_roughness must be in [0,1] (reference slider range, advanced_ssr.cpp:558)");
     return VKR_ERR_EXTENT;

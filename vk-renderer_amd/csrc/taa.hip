@@ -170,7 +170,7 @@ extern "C" int vkr_taa_resolve(const vkr_img* history_color, const vkr_img* hist
   a.pr.znear = params->fovy_aspect_znear_zfar[2];
   a.pr.zfar = params->fovy_aspect_znear_zfar[3];
   a.still_d2 = sqrt_threshold(0.005f);
-  const bool shared = same_layout(a.color, a.velocity) && same_layout(a.color, a.cur_depth) && !getenv("VKR_TAA_GENERIC");
+  const bool shared = same_layout(a.color, a.velocity) && same_layout(a.color, a.cur_depth) && !(switches() & VKR_SWITCH_TAA_GENERIC);
   dim3 block(64, 4);
   if (shared) hipLaunchKernelGGL(k_taa_resolve<true>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_taa_resolve<false>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);

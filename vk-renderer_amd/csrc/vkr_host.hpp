@@ -11,6 +11,7 @@
 namespace vkr {
 
 void set_error(const char* fmt, ...);
+uint32_t switches();  // VKR_SWITCH_* (common.hip): the environment read once, then vkr_set_switches()
 
 enum {
   VKR_OK = 0,
