@@ -103,7 +103,7 @@ def test_c3_8k_rasterised_through_scene_renderer(oracle_lib, parity_table):
     for hname, rimg in (("rays", ref.rays), ("reflections", ref.reflections), ("blurred", ref.blurred), ("filtered", ref.filtered),
                         ("acc_ao", ref.acc_ao), ("taa_target", ref.taa_target)):
         n, _ = report(hname, rimg.format, frame.download(hname).decode(), rimg.decode())
-        assert n <= 2e-4 * rimg.width * rimg.height, f"{hname}: {n} texels outside tolerance"
+        assert n <= 8, f"{hname}: {n} texels outside tolerance (measured: 0 - 1, profiles/parity_c3.json / parity_c5.json)"
     frame.close()
 
 
@@ -142,7 +142,7 @@ def test_c5_eight_rays_per_pixel_loop(oracle_lib, parity_table):
     for hname, rimg in (("rays", ref.rays), ("raw", ref.raw), ("reflections", ref.reflections), ("blurred", ref.blurred),
                         ("taa_target", ref.taa_target)):
         n, _ = report(hname, rimg.format, frame.download(hname).decode(), rimg.decode())
-        assert n <= 2e-4 * rimg.width * rimg.height, f"{hname}: {n} texels outside tolerance"
+        assert n <= 8, f"{hname}: {n} texels outside tolerance (measured: 0 - 1, profiles/parity_c3.json / parity_c5.json)"
     # the loop did cycle the Halton offset: the last trace used frame_random = 7, not 0
     ref.ssr_trace(frame_random=0)
     assert not np.array_equal(ref.rays.raw(0), frame.download("rays").raw(0))
@@ -250,6 +250,6 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame(bounds):
         pass
     for name, n in counts.items():
         if name in history_fed:
-            assert n <= 256, f"{name}: {n} texels deviate from the one-GPU frame (measured: 10 / 88 of 132.7 M)"
+            assert n <= 8, f"{name}: {n} texels deviate from the one-GPU frame (measured: 0 of 132.7 M since the halo rows land in the history image)"
         else:
             assert n == 0, f"{name}: {n} texels differ (no history feeds this surface: it must be bit-identical)"

@@ -59,7 +59,9 @@ def _compare(ref, gpu, names, budget):
             else:
                 nbad, _ = report(f"{name}.{mip}", r.format, g.decode(mip, hg), r.decode(mip))
                 total_bad += nbad
-                assert nbad <= budget * r.width * r.height, f"{name}: {nbad} texels outside tolerance"
+                # budget: a number of texels (>= 1: max(8, 4 x the measured count), so that a regression shows) or a fraction of the image
+                allowed = budget if budget >= 1 or budget == 0 else budget * r.width * r.height
+                assert nbad <= allowed, f"{name}: {nbad} texels outside tolerance (budget {allowed})"
     return total_bad
 
 
@@ -87,7 +89,7 @@ def test_pdf_lut(oracle_lib):
 
 
 @pytest.mark.parametrize("size", [(256, 144), (640, 360), (1920, 1080), (500, 282), (70, 38), (206, 226)])  # 206x226: half-res 103x113, floor-dispatch extent 96x112 (uv -> texel map stretched by 7 %)
-def test_chain_stagewise(size, oracle_lib, budget=1e-4):
+def test_chain_stagewise(size, oracle_lib, budget=8):
     """Each pass gets bit-identical inputs (the oracle's), so a failure names the pass."""
     ref, gpu = _pair(*size, oracle_lib)
     ref.synth()
@@ -99,7 +101,7 @@ def test_chain_stagewise(size, oracle_lib, budget=1e-4):
         getattr(ref, stage)()
         getattr(gpu, stage)()
         # a handful of texels may flip a hit / break decision through libm-vs-ocml ulps in the
-        # smooth part; the budget is 1e-4 of the image at the small / ragged sizes and the count is printed
+        # smooth part; the budget is 8 texels at the small / ragged sizes (measured: 0) and the count is printed
         _compare(ref, gpu, outs, budget=budget)
 
 
@@ -125,10 +127,10 @@ def test_chain_end_to_end(size, oracle_lib, parity_table):
             c.swap_histories()
     # after swap the freshest outputs sit in the *_hist slots.  With no resynchronisation a one-code difference of an
     # intermediate can push a downstream texel over the line: measured 2 of 2 073 600 texels of raw at 4K
-    # (profiles/parity_c2.json); the budget is 1e-5 of the image.
+    # (profiles/parity_c2.json); the budget is 8 texels = max(8, 4 x measured).
     _compare(ref, gpu, ("dn", "dv", "depth"), budget=0)
-    _compare(ref, gpu, ("rays", "raw", "reflections", "filtered"), budget=1e-5 if size[0] >= 3840 else 2e-4)
-    _compare(ref, gpu, ("blurred_hist", "acc_hist", "taa_hist"), budget=1e-5 if size[0] >= 3840 else 2e-4)
+    _compare(ref, gpu, ("rays", "raw", "reflections", "filtered"), budget=8)
+    _compare(ref, gpu, ("blurred_hist", "acc_hist", "taa_hist"), budget=8)
 
 
 @pytest.mark.parametrize("size", [(640, 360), (206, 226)])
@@ -159,18 +161,20 @@ def test_taa_generic_footprints(size, oracle_lib, monkeypatch):
     lib.vkr_set_switches(before)
 
 
-def test_gtao_only_config1(oracle_lib):
-    """BASELINE config 1: GTAO main pass only, non-MIS (use_mis = 0), single and two directions."""
+@pytest.mark.parametrize("size", [(640, 360), (1920, 1080)])
+def test_gtao_only_config1(size, oracle_lib):
+    """BASELINE config 1: GTAO main pass only, non-MIS (use_mis = 0), single and two directions — also at the
+    configuration's own 1920x1080."""
     from vk_renderer_amd.camera import FrameSetup
 
     for two in (0, 255):
-        ref, gpu = _pair(640, 360, oracle_lib, setup=FrameSetup(640, 360, use_mis=0))
+        ref, gpu = _pair(*size, oracle_lib, setup=FrameSetup(*size, use_mis=0))
         ref.synth()
         ref.downsample()
         _sync_inputs(ref, gpu)
         ref.gtao_main(two_directions=two)
         gpu.gtao_main(two_directions=two)
-        _compare(ref, gpu, ("raw",), budget=1e-4)
+        _compare(ref, gpu, ("raw",), budget=8)
 
 
 @pytest.mark.parametrize("size", [(256, 144), (640, 360)])
@@ -269,5 +273,5 @@ def test_host_mirror_frame_with_shading(size, oracle_lib):
         got = frame.download(hname)
         bad = int(mismatches(rimg.format, got.decode(0), rimg.decode(0)).sum())
         print(f"[parity] host {hname:13s} outside-tol {bad}")
-        assert bad <= 2e-4 * rimg.width * rimg.height, f"host frame {hname}: {bad} texels outside tolerance"
+        assert bad <= 8, f"host frame {hname}: {bad} texels outside tolerance (measured: 0)"
     frame.close()

@@ -301,6 +301,7 @@ struct TiledFrame {
   // so the descriptor is taken at pack time and kept for the unpack.
   vkr_img packed_from[3] {};
   void copy_halo(int s, bool to_buffers) {
+    gpu::TraceRange range {to_buffers ? "halo pack" : "halo unpack"};
     if (to_buffers) packed_from[s] = surface(s);
     const vkr_img d = packed_from[s];
     const uint32_t dv = halo_dv(s), bpp = vkr_format_bytes(d.format), rows = cfg.halo >> dv, row_bytes = d.width * bpp;
@@ -394,6 +395,7 @@ struct TiledFrame {
     }
   }
   void start_gather(int which) {
+    gpu::TraceRange range {which == VKRH_GATHER_HIZ ? "all-gather Hi-Z + normals" : "all-gather albedo"};
     start(which, [&] {
       vkr_gather_part p[8];
       const uint32_t n = gather_parts(which, p);
@@ -404,6 +406,7 @@ struct TiledFrame {
     });
   }
   void start_halo(int s) {
+    gpu::TraceRange range {"halo exchange"};
     halo_in_flight[s] = true;
     start(2 + s, [&] { vkr_halo_peer p[2]; const uint32_t n = halo_peers(s, p); return vkr_halo_exchange(cfg.comm, p, n, xchg); });
   }
@@ -519,6 +522,7 @@ struct TiledFrame {
   bool hit_pending = false;
   void hit_exchange_complete() {  // host-blocking: call with the next compute work already queued
     if (!hit_pending) return;
+    gpu::TraceRange range {"hit colours: counts -> requests -> replies -> scatter"};
     hit_pending = false;
     check(hipStreamSynchronize(xchg), "synchronize");
     vkr_halo_peer peers[HIT_PEERS];
@@ -534,6 +538,9 @@ struct TiledFrame {
   // ---- the frame, in phases (an exchange may only start / must be complete at a phase boundary) ------------------------
   void phase(uint32_t p) {
     PostFxFrame& f = *frame;
+    static const char* const names[VKRH_TILED_PHASES] = {"tiled: downsample | start gathers", "tiled: TAA | halo", "tiled: Hi-Z tail + trace",
+                                                        "tiled: GTAO | halo | hit colours", "tiled: SSR filter + blur | halo"};
+    gpu::TraceRange range {p < VKRH_TILED_PHASES ? names[p] : "tiled: ?"};
     switch (p) {
       case 0:
         f.run(VKRH_STAGE_DOWNSAMPLE);

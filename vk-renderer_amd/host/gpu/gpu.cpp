@@ -1,6 +1,7 @@
 // gpu/gpu.cpp — implementation of the HIP-backed gpu:: layer and the program table that maps
 // the reference's program names (src/shaders/config.json) onto C-ABI entry points.
 #include "gpu.hpp"
+#include <dlfcn.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -36,6 +37,26 @@ void* device_alloc(size_t bytes) {
   return p;
 }
 void device_free(void* ptr) { if (ptr) g_free(ptr, g_alloc_user); }
+
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    for (const char* n : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so.4"}) {
+      if (void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) return;
+        push = nullptr; pop = nullptr;
+      }
+    }
+  }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void trace_push(const char* name) { if (roctx().push) roctx().push(name); }
+void trace_pop() { if (roctx().pop) roctx().pop(); }
 
 void check_status(int rc, const char* what) {
   if (rc != 0) throw std::runtime_error{std::string{what} + ": " + vkr_last_error() + " (code " + std::to_string(rc) + ")"};

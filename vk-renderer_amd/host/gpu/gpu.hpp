@@ -33,6 +33,10 @@ using AllocFn = void* (*)(size_t bytes, void* user);
 using FreeFn = void (*)(void* ptr, void* user);
 void set_device_allocator(AllocFn alloc, FreeFn free_fn, void* user);
 void* device_alloc(size_t bytes);
+// roctx ranges (libroctx64, loaded on first use; no-ops when it is absent)
+void trace_push(const char* name);
+void trace_pop();
+struct TraceRange { explicit TraceRange(const char* name) { trace_push(name); } ~TraceRange() { trace_pop(); } TraceRange(const TraceRange&) = delete; };
 void device_free(void* ptr);
 
 // ---- images --------------------------------------------------------------------------------------
@@ -299,8 +303,10 @@ struct CmdContext {
   // vkCmdUpdateBuffer of a small POD value, ordered on the stream
   void update_buffer_bytes(VkBuffer dst, uint64_t offset, const void* data, uint64_t size);
   template <typename T> void update_buffer(VkBuffer dst, uint64_t offset, const T& value) { update_buffer_bytes(dst, offset, &value, sizeof(T)); }
-  void push_label(const char*) {}
-  void pop_label() {}
+  // cmd_buffers.hpp:212-213 (vkCmdBeginDebugUtilsLabelEXT): here a roctx range, so that a rocprofv3 --marker-trace timeline
+  // names every rendergraph task (rendergraph.cpp:289-304 labels each task) and every phase of the tiled frame
+  void push_label(const char* name) { trace_push(name); }
+  void pop_label() { trace_pop(); }
 
   UniformBufferPool& get_ubo_pool() { return ubo_pool; }
   template <typename T> UboBlock<T> allocate_ubo() { return ubo_pool.allocate_ubo<T>(); }
