@@ -478,6 +478,10 @@ int vkr_selftest_division(uint32_t* device_counters5, float znear, float zfar, v
 /* Test hook: counts (into one device uint32, zeroed by the caller) the pixel centres g < size, size = 1..max_size (<= 65535),
  * whose uv = (g + 0.5) / size differs between the kernels' normal-range division and IEEE '/'.     */
 int vkr_selftest_pixel_uv(uint32_t* device_counter, uint32_t max_size, void* stream);
+/* Test hook: [0] counts the floats x in [2^-96, FLT_MAX] — all of them — whose cheap exact square root (vkr_device.hpp
+ * sqrt_ieee) differs from sqrtf(x); [1] the floats s in [2^-48, 2^64] whose cheap exact reciprocal differs from 1.0f / s
+ * (two device uint32, zeroed by the caller)                                                                       */
+int vkr_selftest_sqrt(uint32_t* device_counters2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,21 @@ def test_device_division_and_decodes_are_exact():
     assert counter.item() == 0
 
 
+@pytest.mark.gpu
+def test_device_square_root_and_reciprocal_are_exact():
+    """On the GPU, exhaustively: vkr_device.hpp sqrt_ieee (v_sqrt_f32 + two exact residuals) against sqrtf for EVERY float in
+    [2^-96, FLT_MAX], and normalize()'s reciprocal against 1.0f / s for every float in [2^-48, 2^64] — the two correctly
+    rounded operations of the numeric contract on the forms the kernels execute."""
+    import torch
+
+    lib = abi.product()
+    lib.vkr_selftest_sqrt.argtypes = [C.c_void_p, C.c_void_p]
+    counters = torch.zeros(2, dtype=torch.int32, device="cuda")
+    abi.check(lib.vkr_selftest_sqrt(counters.data_ptr(), torch.cuda.current_stream().cuda_stream), lib)
+    torch.cuda.synchronize()
+    assert counters.tolist() == [0, 0], counters.tolist()
+
+
 def test_half_roundtrip_all_codes(oracle_lib):
     lib = oracle_lib
     lib.vkr_ref_half_to_float.restype = C.c_float

@@ -156,9 +156,30 @@ __global__ __launch_bounds__(256) void k_selftest_pixel_uv(uint32_t* counter, ui
   if (div_normal(a, b) != a / b) atomicAdd(counter, 1u);
 }
 
+// counters[0]: floats x in [2^-96, FLT_MAX] (ALL of them: bit patterns 0x0F800000 .. 0x7F7FFFFF) whose sqrt_ieee(x) differs
+// from sqrtf(x); counters[1]: the same for normalize()'s reciprocal, rcp_ieee_normal(s) vs 1.0f / s over every float s in
+// [2^-48, 2^64]
+__global__ __launch_bounds__(256) void k_selftest_sqrt(uint32_t* counters) {
+  const uint64_t first = 0x0F800000ull, last = 0x7F7FFFFFull;
+  uint32_t bad = 0u, bad_rcp = 0u;
+  for (uint64_t b = first + (uint64_t)blockIdx.x * 256u + threadIdx.x; b <= last; b += (uint64_t)gridDim.x * 256u) {
+    const float x = __uint_as_float((uint32_t)b);
+    if (sqrt_ieee(x) != sqrtf(x)) ++bad;
+    if (x >= 0x1p-48f && x <= 0x1p64f && rcp_ieee_normal(x) != 1.0f / x) ++bad_rcp;
+  }
+  if (bad) atomicAdd(&counters[0], bad);
+  if (bad_rcp) atomicAdd(&counters[1], bad_rcp);
+}
+
 }  // namespace vkr
 
 using namespace vkr;
+
+extern "C" int vkr_selftest_sqrt(uint32_t* device_counters2, void* stream) {
+  if (!device_counters2) { set_error("selftest_sqrt: NULL counters"); return VKR_ERR_NULL; }
+  hipLaunchKernelGGL(k_selftest_sqrt, dim3(8192), dim3(256), 0, (hipStream_t)stream, device_counters2);
+  return launch_status("selftest_sqrt");
+}
 
 extern "C" int vkr_selftest_pixel_uv(uint32_t* device_counter, uint32_t max_size, void* stream) {
   if (!device_counter || max_size == 0 || max_size > 65535u) { set_error("selftest_pixel_uv: bad arguments"); return VKR_ERR_NULL; }

@@ -82,9 +82,43 @@ VKR_DEV float dot(f3 a, f3 b) { return cfma(a.z, b.z, cfma(a.y, b.y, a.x * b.x))
 // a + s * b: ray positions, sample positions, projections off a normal
 VKR_DEV f2 madd(f2 a, float s, f2 b) { return mk2(cfma(s, b.x, a.x), cfma(s, b.y, a.y)); }
 VKR_DEV f3 madd(f3 a, float s, f3 b) { return mk3(cfma(s, b.x, a.x), cfma(s, b.y, a.y), cfma(s, b.z, a.z)); }
-VKR_DEV float length(f2 a) { return sqrtf(dot(a, a)); }
-VKR_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
-VKR_DEV f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+// a / b for finite operands in the normal range (no scaling, no special cases): the refinement
+// sequence the compiler emits for IEEE division minus v_div_scale / v_div_fixup — same correctly
+// rounded result (vkr_selftest_division checks it on the GPU), ~24 instead of ~43 cycles.
+VKR_DEV float div_normal(float a, float b) {
+  float r = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  float q = a * r;
+  const float e2 = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(e2, r, q);
+  const float e3 = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(e3, r, q);
+}
+// sqrtf(x), correctly rounded, without the compiler's input scaling (v_sqrt_f32 does not take denormals) and class checks:
+// v_sqrt_f32 is within 1 ulp, the two neighbours are tried with exact residuals (the compiler's own refinement).  Valid for
+// x >= 2^-96 (the results of every dot product of this path); anything else — 0, tiny, negative, NaN — takes the library
+// sequence.  vkr_selftest_sqrt compares it with sqrtf on EVERY float of the fast range.
+VKR_DEV float sqrt_ieee(float x) {
+  if (__builtin_expect(!(x >= 0x1p-96f), 0)) return sqrtf(x);
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float e_dn = __builtin_fmaf(-s_dn, s, x), e_up = __builtin_fmaf(-s_up, s, x);
+  s = e_dn <= 0.0f ? s_dn : s;
+  s = e_up > 0.0f ? s_up : s;
+  return s;
+}
+// 1.0f / s for the s = sqrt_ieee(x) of a vector length (2^-48 <= s <= 2^64: operands and quotient are normal)
+VKR_DEV float rcp_ieee_normal(float s) { return div_normal(1.0f, s); }
+VKR_DEV float length(f2 a) { return sqrt_ieee(dot(a, a)); }
+VKR_DEV float length(f3 a) { return sqrt_ieee(dot(a, a)); }
+// v * (1 / sqrt(v . v)): the two correctly rounded operations of the contract on their cheap exact forms; a zero or
+// denormal-length vector (never on this path) keeps the IEEE special cases
+VKR_DEV f3 normalize(f3 a) {
+  const float d = dot(a, a);
+  if (__builtin_expect(!(d >= 0x1p-96f && d <= 0x1p96f), 0)) return a * (1.0f / sqrtf(d));
+  return a * rcp_ieee_normal(sqrt_ieee(d));
+}
 // Hardware reciprocal / rsqrt / sqrt (1 ulp): ONLY for values that never feed a comparison — weights,
 // shading terms, horizon cosines that are max()-reduced — where 1e-7 relative noise is irrelevant.
 VKR_DEV float fast_rcp(float a) { return __builtin_amdgcn_rcpf(a); }
@@ -391,19 +425,6 @@ VKR_DEV f3 decode_normal(f2 uv) {
   }
   return normalize(v);
 }
-// a / b for finite operands in the normal range (no scaling, no special cases): the refinement
-// sequence the compiler emits for IEEE division minus v_div_scale / v_div_fixup — same correctly
-// rounded result (vkr_selftest_division checks it on the GPU), ~24 instead of ~43 cycles.
-VKR_DEV float div_normal(float a, float b) {
-  float r = __builtin_amdgcn_rcpf(b);
-  const float e = __builtin_fmaf(-b, r, 1.0f);
-  r = __builtin_fmaf(e, r, r);
-  float q = a * r;
-  const float e2 = __builtin_fmaf(-b, q, a);
-  q = __builtin_fmaf(e2, r, q);
-  const float e3 = __builtin_fmaf(-b, q, a);
-  return __builtin_fmaf(e3, r, q);
-}
 // uv of the centre of pixel g of an extent of `size` pixels, (g + 0.5) / size with 0 <= g < size <= 65535: both operands
 // and the quotient are normal, so div_normal gives the IEEE quotient (vkr_selftest_pixel_uv checks every pair)
 VKR_DEV float pixel_centre_uv(int g, float size) { return div_normal((float)g + 0.5f, size); }
@@ -476,9 +497,9 @@ VKR_DEV float sampleGGXdirPDF(const Tex& pdf_tex, f3 V, f3 N, f3 L, float alpha)
   f3 Lproj = normalize(L - V * dot(V, L));
   float cos_theta = dot(X, Lproj);
   const float cos_phin = dot(N, X);
-  const float sin_phin = sqrtf(1.0f - cos_phin * cos_phin);
+  const float sin_phin = sqrt_ieee(1.0f - cos_phin * cos_phin);
   const float alpha2 = alpha * alpha;
-  const float coef = sqrtf(1.0f - alpha2);
+  const float coef = sqrt_ieee(1.0f - alpha2);
   const float a = ((0.5f * coef) * cos_phin) * cos_theta + 0.5f;
   const float b = coef * sin_phin;
   return alpha2 / ((2.0f * VKR_PI) * coef) * sample<FmtR32F>(pdf_tex, mk2(a, b));
