@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--frame", type=str, default=None,
                     help=f"whole frame, WxH.  Default: {TILE_W}x{TILE_H} at N = 1 (c2), {C4_W}x{C4_H} at N > 1 (c4: N strips of W x H/N)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-noskip", action="store_true", help="leave out the second timed loop with the empty-tile skips off (profiling runs: one population of launches)")
     ap.add_argument("--overlap", action="store_true",
                     help="let the rendergraph spread independent passes of a frame over several streams (measured slower: "
                          "the passes are VALU-bound, see DESIGN.md section 3)")
@@ -364,7 +365,7 @@ def main():
     # The headline depends on the frame's content: tiles of the blur / filter without a reflection / hit skip their taps
     # (bit-identical output).  A second, short timed loop with the skips switched off gives the content-independent number.
     noskip_ms = None
-    if world == 1 and args.config in ("c2", "c3", "c4", "c5"):
+    if world == 1 and args.config in ("c2", "c3", "c4", "c5") and not args.no_noskip:
         lib = abi.product()
         before = lib.vkr_get_switches()
         lib.vkr_set_switches(before | abi.SWITCH_BLUR_NO_SKIP | abi.SWITCH_FILTER_NO_SKIP)

@@ -7,7 +7,7 @@ N=${1:-kstats}; shift || true
 O=$R/gpurun_out/$N
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 3 "$@" > $O.log 2>&1 || { tail -5 $O.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --no-cpu-baseline --no-noskip --steps 20 --warmup 3 "$@" > $O.log 2>&1 || { tail -5 $O.log; exit 1; }
 find $O -type f ! -name '*kernel_stats.csv' -delete 2>/dev/null
 python3 - "$O" <<'PY'
 import csv, glob, sys

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "$@"; do
   i=$((i+1)); O=$R/gpurun_out/pmcp_$i; rm -rf $O
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O.log 2>&1 || { echo "pass $i failed"; tail -5 $O.log; continue; }
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --no-cpu-baseline --no-noskip --steps 5 --warmup 2 > $O.log 2>&1 || { echo "pass $i failed"; tail -5 $O.log; continue; }
   python3 - "$O" <<'PY'
 import csv, glob, sys
 from collections import defaultdict

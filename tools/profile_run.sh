@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline"
+B="python3 $R/bench.py --no-cpu-baseline --no-noskip"
 rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_sqa $O/pmc_sqb
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- $B --steps 20 --warmup 3 > $O/prof.log 2>&1 && echo stats_ok &&
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B --steps 5 --warmup 2 > $O/pmc_fetch.log 2>&1 && echo fetch_ok &&

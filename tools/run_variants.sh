@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for n in "$@"; do
   V=$R/vk-renderer_amd/csrc/variants/$n
-  LD_LIBRARY_PATH=$V:${LD_LIBRARY_PATH:-} VKR_POSTFX_LIB=$V/libvkr_postfx.so python3 $R/bench.py --no-cpu-baseline --steps 100 > $R/gpurun_out/var_$n.json 2> $R/gpurun_out/var_$n.err || { echo "$n FAILED"; tail -3 $R/gpurun_out/var_$n.err; continue; }
+  LD_LIBRARY_PATH=$V:${LD_LIBRARY_PATH:-} VKR_POSTFX_LIB=$V/libvkr_postfx.so python3 $R/bench.py --no-cpu-baseline --no-noskip --steps 100 > $R/gpurun_out/var_$n.json 2> $R/gpurun_out/var_$n.err || { echo "$n FAILED"; tail -3 $R/gpurun_out/var_$n.err; continue; }
   python3 - "$n" "$R/gpurun_out/var_$n.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[2]))

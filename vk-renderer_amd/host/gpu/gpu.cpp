@@ -43,7 +43,8 @@ struct Roctx {
   int (*push)(const char*) = nullptr;
   int (*pop)() = nullptr;
   Roctx() {
-    for (const char* n : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so.4"}) {
+    // rocprofv3 --marker-trace records the ranges of rocprofiler-sdk's ROCTx; libroctx64 is roctracer's (rocprof v1 / v2)
+    for (const char* n : {"librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so.4"}) {
       if (void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
         push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
         pop = (int (*)())dlsym(h, "roctxRangePop");
