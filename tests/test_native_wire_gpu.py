@@ -47,13 +47,26 @@ WORKER = textwrap.dedent("""
     def camera(k):  # frame k looks from eye_k; its previous frame is camera k - 1
         return FrameSetup(W, H, eye=(0.03 * k, 1.0, -1.0 + 0.02 * k), yaw=90.0 + 0.3 * k, prev_delta=(-0.03, 0.0, -0.02), prev_yaw_delta=-0.3)
 
-    def run(t, frames):
+    def run(t, frames, shadow=None):
         for k in range(frames):
-            if moving:
-                s = camera(k)
-                t.frame.set_camera(s.view, s.prev_view, s.proj, s.fazz)
-                t.frame.run(host.STAGE_GBUFFER | host.STAGE_PREV_DEPTH)
-            t.step()
+            for f in (t, shadow) if shadow is not None else (t,):
+                if moving:
+                    s = camera(k)
+                    f.frame.set_camera(s.view, s.prev_view, s.proj, s.fazz)
+                    f.frame.run(host.STAGE_GBUFFER | host.STAGE_PREV_DEPTH)
+                f.step()
+            if shadow is not None:  # VKR_WIRE_DEBUG: which frame and surface diverges first (synchronises every frame)
+                t.backend.sync()
+                x0, y0, tw, th = t.tile
+                for name, dv in (('rays', 1), ('reflections', 1), ('blurred_hist', 1), ('albedo', 0), ('dv', 1)):
+                    got, want = t.frame.download(name), shadow.frame.download(name)
+                    ox, oy = got.origin
+                    a = got.raw(0)[(y0 >> dv) - oy:(y0 >> dv) - oy + (th >> dv)]
+                    b = want.raw(0)[(y0 >> dv):(y0 >> dv) + (th >> dv)]
+                    d = (a != b).any(axis=-1)
+                    if d.any():
+                        ys = np.flatnonzero(d.any(axis=1))
+                        print(f'[debug] rank {rank} frame {k} {name}: {int(d.sum())} texels, tile rows {ys[0]}..{ys[-1]}')
         t.flush()
         t.backend.sync()
 
@@ -61,10 +74,15 @@ WORKER = textwrap.dedent("""
     t = TiledFrame(FrameSetup(W, H), rank, world, 1, world, device, native=True, comm=comm, row_bounds=None if equal else bounds)
     assert t.native and t.frame.tiled_handle
     t.prepare()
-    run(t, FRAMES)
-    plain = TiledFrame(FrameSetup(W, H), 0, 1, 1, 1, device)
-    plain.prepare()
-    run(plain, FRAMES)
+    if os.environ.get('VKR_WIRE_DEBUG') == '1':
+        plain = TiledFrame(FrameSetup(W, H), 0, 1, 1, 1, device)
+        plain.prepare()
+        run(t, FRAMES, shadow=plain)
+    else:
+        run(t, FRAMES)
+        plain = TiledFrame(FrameSetup(W, H), 0, 1, 1, 1, device)
+        plain.prepare()
+        run(plain, FRAMES)
     x0, y0, tw, th = t.tile
     bad = 0
     for name, dv in (('rays', 1), ('raw', 1), ('reflections', 1), ('filtered', 1), ('blurred_hist', 1), ('acc_hist', 1), ('taa_hist', 0), ('dn', 1), ('dv', 1)):

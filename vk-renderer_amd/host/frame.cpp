@@ -436,6 +436,16 @@ struct TiledFrame {
     hit.counts = (uint32_t*)gpu::device_alloc(sizeof(uint32_t) * (2 * w + 1 + w * w));
     check(hipHostMalloc((void**)&hit.host_counts, sizeof(uint32_t) * (w * w + 1), hipHostMallocDefault), "pinned counts");
     hit.out_seg.assign(w + 1, 0); hit.in_seg.assign(w + 1, 0);
+    // worst case of what this rank can ask for: two footprint rows per ray of its window, + the texel pair at (0, 0); the
+    // same room for what it may be asked (a rank asked for more grows, see grow())
+    const uint64_t worst = 2ull * (W / 2) * (wh / 2) + 2;
+    uint64_t cap = 0;
+    grow((void**)&hit.req_out, &cap, worst, sizeof(vkr_hit_request));
+    grow((void**)&hit.reply_in, &hit.cap_out, worst, sizeof(uint64_t));
+    cap = 0;
+    grow((void**)&hit.req_in, &cap, worst, sizeof(vkr_hit_request));
+    grow((void**)&hit.reply_out, &hit.cap_in, worst, sizeof(uint64_t));
+    grew = false;  // before the first frame: the caller synchronises after set-up (prepare), nothing is in flight
   }
   void hit_release() {
     gpu::device_free(hit.counts);
@@ -457,11 +467,24 @@ struct TiledFrame {
       throw std::runtime_error {std::string {"hit_requests: "} + vkr_last_error()};
     hit.counted = true;
   }
-  static void grow(void** p, uint64_t* cap, uint64_t need, uint64_t elem) {
+  // An allocator may initialise what it hands out asynchronously on the COMPUTE stream (the torch-backed one zero-fills
+  // there).  Buffers the exchange stream writes are therefore allocated before the first frame, for the worst case of
+  // this rank's own requests; should a rank ever be asked for more than that, the exchange stream is ordered behind the
+  // compute stream once, so that a late fill cannot wipe what the exchange has already landed (found by the 4-process
+  // wire test under load: replies zeroed in the frame that allocated them).
+  bool grew = false;
+  void grow(void** p, uint64_t* cap, uint64_t need, uint64_t elem) {
     if (need <= *cap) return;
     gpu::device_free(*p);
     *cap = need + need / 4 + 1024;
     *p = gpu::device_alloc(*cap * elem);
+    grew = true;
+  }
+  void order_exchange_behind_allocations(hipStream_t s) {
+    if (!grew || s == compute) { grew = false; return; }
+    grew = false;
+    check(hipEventRecord(ev_ready[VKRH_GATHER_ALBEDO], compute), "event record");
+    check(hipStreamWaitEvent(s, ev_ready[VKRH_GATHER_ALBEDO], 0), "stream wait");
   }
   // pass 2 on stream s, given everybody's counts: fills req_out and returns the peer list of the request exchange
   uint32_t hit_write(const uint32_t* matrix, hipStream_t s, vkr_halo_peer* peers) {
@@ -475,6 +498,7 @@ struct TiledFrame {
     cap = hit.cap_in;
     grow((void**)&hit.req_in, &cap, hit.in_seg[w], sizeof(vkr_hit_request));
     grow((void**)&hit.reply_out, &hit.cap_in, hit.in_seg[w], sizeof(uint64_t));
+    order_exchange_behind_allocations(s);
     if (hit.out_seg[w]) {
       const vkr_img r = rays_img();
       if (vkr_hit_requests(&r, W, H, bounds.data(), w, wy0, wy0 + wh, hit.counts, hit.counts + w, hit.out_seg.data(), hit.req_out, s) != 0)
