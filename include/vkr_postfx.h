@@ -108,6 +108,8 @@ typedef struct vkr_trace_params {
 
 typedef struct vkr_trace_push  { float max_roughness; } vkr_trace_push;     /* trace.comp:24-26  */
 typedef struct vkr_filter_push { uint32_t render_flags; } vkr_filter_push;  /* filter.comp:28-30 */
+/* multi-GPU trace: `normal` holds frame rows [normal_row0, normal_row1) only when the march ends (vkr_sssr_trace_windowed) */
+typedef struct vkr_trace_window_push { float max_roughness; uint32_t normal_row0, normal_row1; } vkr_trace_window_push;
 #define VKR_NORMALIZE_REFLECTIONS  1u   /* filter.comp:22-24 */
 #define VKR_ACCUMULATE_REFLECTIONS 2u
 #define VKR_BILATERAL_FILTER       4u
@@ -253,6 +255,20 @@ int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const vkr_img* m
                    const vkr_trace_params* params, const float* halton_vec4 /*device, 128 x vec4*/,
                    const vkr_img* out_ray, const vkr_img* out_occlusion, const vkr_img* pdf_tex,
                    const vkr_trace_push* push, void* stream);
+
+/* Multi-GPU variant of "sssr_trace" (no reference counterpart; host/frame.hpp): `normal` is the whole-frame image but only
+ * frame rows [normal_row0, normal_row1) of it are in memory when the march ends (the rank's window).  A ray that passes
+ * every other validity test and whose hit-normal footprint (trace.comp:103-109) has a row outside them is stored as a
+ * provisional hit: pending_mask (R8, the rays' extent; written for every pixel: 1 = pending) marks it and pending_data
+ * (RGBA32F, twice the rays' width: two texels per pixel) keeps R and the hit uv.  Once the missing rows have arrived
+ * (vkr_hit_requests / _reply / _scatter below) vkr_sssr_validate runs the deferred test and turns the rays that fail it
+ * into misses — the stored rays are then bit-identical to vkr_sssr_trace's on a complete `normal`.                    */
+int vkr_sssr_trace_windowed(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                            const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                            const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_img* pending_mask,
+                            const vkr_img* pending_data, const vkr_trace_window_push* push, void* stream);
+int vkr_sssr_validate(const vkr_img* rays, const vkr_img* pending_mask, const vkr_img* pending_data, const vkr_img* frame_normals,
+                      const vkr_trace_params* params, void* stream);
 
 /* program "sssr_filter": advanced_ssr.cpp:308-369 + filter.comp (bindings 0..6)          */
 int vkr_sssr_filter(const vkr_img* rays, const vkr_img* depth, const vkr_img* albedo,
@@ -439,22 +455,40 @@ int vkr_all_gather_v(vkr_comm* comm, const vkr_gather_v_part* parts, uint32_t co
 typedef struct vkr_halo_peer { int32_t peer; uint32_t reserved; const void* send; uint64_t send_bytes; void* recv; uint64_t recv_bytes; } vkr_halo_peer;
 int vkr_halo_exchange(vkr_comm* comm, const vkr_halo_peer* peers, uint32_t count, void* stream);
 
-/* ---- hit colours by request / reply (multi-GPU; instead of all-gathering the albedo of the whole frame) -----------
- * filter.comp:112-134 reads the albedo bilinearly at the hit position of every valid ray, anywhere in the frame.  A rank
- * asks the owning ranks for exactly the footprint rows it does not hold, and writes the answers into its whole-frame
- * albedo image where an all-gather would have put them (csrc/hit_exchange.hip; host/frame.hpp drives the three steps and
- * moves requests and replies with vkr_halo_exchange).  Strips: rank r owns frame rows [row_bounds[r], row_bounds[r + 1]). */
-typedef struct vkr_hit_request { uint32_t row, x; } vkr_hit_request; /* frame row; left texel of the texel pair (<= W - 2) */
+/* ---- hit colours and hit normals by request / reply (multi-GPU; instead of all-gathering whole-frame surfaces) --------
+ * filter.comp:112-134 reads the albedo bilinearly at the hit position of every valid ray, trace.comp:103-109 the downsampled
+ * normal at the hit position of every candidate — anywhere in the frame.  A rank asks the owning ranks for exactly the
+ * footprint rows it does not hold and writes the answers into its whole-frame images where an all-gather would have put
+ * them (csrc/hit_exchange.hip; host/frame.hpp drives the steps and moves requests and replies with vkr_halo_exchange).
+ * Strips: rank r owns full-res frame rows [row_bounds[r], row_bounds[r + 1]) (even numbers) and the half-res rows at half
+ * of them.  A request is 4 bytes — bits 0..13 the frame row, 14..27 the left texel of the texel pair (<= width - 2),
+ * VKR_HIT_BOTH_ROWS: also the row below (the two rows of a footprint usually have one owner), VKR_HIT_NORMAL: the
+ * half-res normal image instead of the full-res albedo — and is answered with 16 bytes: the pair of the row and of the row
+ * below it.  Frames up to 16384 x 16384.                                                                                */
+typedef uint32_t vkr_hit_request;
+#define VKR_HIT_BOTH_ROWS 0x10000000u
+#define VKR_HIT_NORMAL    0x20000000u
+typedef struct vkr_hit_sources {
+  const vkr_img* rays;            /* RGBA16_UNORM, the rank's half-res window: albedo rows for every ray with w != 1           */
+  uint32_t albedo_width, albedo_height;
+  uint32_t window_row0, window_row1;   /* the full-res frame rows this rank holds                                             */
+  const vkr_img* pending_mask;    /* or NULL: no normal requests.  R8 + RGBA32F of vkr_sssr_trace_windowed: normal rows for   */
+  const vkr_img* pending_data;    /* every pending ray, outside half-res rows [normal_row0, normal_row1)                       */
+  uint32_t normal_width, normal_height, normal_row0, normal_row1;
+} vkr_hit_sources;
 /* out == NULL: counts[o] += number of requests this rank has for owner o (counts: device, world entries, zeroed by the
  * caller).  out != NULL: writes them, owner o's from out[segments[o]] on (segments: host, world entries; cursors: device,
- * world entries, zeroed by the caller).  The window is frame rows [window_row0, window_row1) of the full-res albedo.   */
-int vkr_hit_requests(const vkr_img* rays, uint32_t albedo_width, uint32_t albedo_height, const uint32_t* row_bounds, uint32_t world,
-                     uint32_t window_row0, uint32_t window_row1, uint32_t* counts, uint32_t* cursors, const uint32_t* segments,
-                     vkr_hit_request* out, void* stream);
-/* replies[i] = the two texels of requests[i] from this rank's albedo window; a request for texels the window does not
- * hold answers 0 and increments *error_counter (device uint32)                                                        */
-int vkr_hit_reply(const vkr_img* albedo, const vkr_hit_request* requests, uint32_t count, uint64_t* replies, uint32_t* error_counter, void* stream);
-int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_hit_request* requests, const uint64_t* replies, uint32_t count, void* stream);
+ * world entries, zeroed by the caller).                                                                                */
+int vkr_hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* cursors,
+                     const uint32_t* segments, vkr_hit_request* out, void* stream);
+/* replies (device, 16 bytes each, 16-byte aligned): the texel pair(s) of requests[i] from this rank's albedo / downsampled-
+ * normal window (normals may be NULL when no normal request can arrive); a request for texels the window does not hold
+ * answers 0 and increments *error_counter                                                                              */
+#define VKR_HIT_REPLY_BYTES 16u
+int vkr_hit_reply(const vkr_img* albedo, const vkr_img* normals, const vkr_hit_request* requests, uint32_t count, void* replies,
+                  uint32_t* error_counter, void* stream);
+int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_img* frame_normals, const vkr_hit_request* requests, const void* replies,
+                    uint32_t count, void* stream);
 
 /* Measurement switches — the library's only process-wide state.  The environment (VKR_BLUR_NO_SKIP, VKR_FILTER_NO_SKIP,
  * VKR_TAA_GENERIC, VKR_SHADING_GENERIC) is read once, at the first launch that asks; afterwards only vkr_set_switches

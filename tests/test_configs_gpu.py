@@ -203,8 +203,9 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame(bounds):
     for t in ranks:
         t.flush()
     torch.cuda.synchronize()
-    # what every rank receives per frame: the other strips' shares of the gathered Hi-Z mips + normals, its halo rows and the
-    # hit colours it asked for (8-byte requests in + 8-byte replies in) — instead of the 464 MB of albedo
+    # what every rank receives per frame: the other strips' shares of the gathered Hi-Z mips, its halo rows and the hit
+    # colours / hit normals it asked for (4-byte requests in + 16-byte replies in) — instead of the
+    # 464 MB of albedo and 116 MB of downsampled normals
     m = ranks[0].hit_matrix
     assert all(t.frame.tiled_hit_errors() == 0 for t in ranks)
     hiz_share = [sum(p[2] for p in t.frame.tiled_gather_parts(0)) for t in ranks]
@@ -212,14 +213,14 @@ def test_c4_eight_strips_of_15360x8640_against_one_gpu_frame(bounds):
     for r, t in enumerate(ranks):
         asked_of_me = sum(m[q * world + r] for q in range(world))
         i_ask = sum(m[r * world + o] for o in range(world))
-        wire.append({"hiz_gather_in": sum(hiz_share) - hiz_share[r], "hit_colours_in": 8 * (asked_of_me + i_ask),
+        wire.append({"hiz_gather_in": sum(hiz_share) - hiz_share[r], "hit_colours_in": 4 * asked_of_me + 16 * i_ask,  # 4-byte requests in, 16-byte replies in
                      "hit_requests_out": i_ask, "halo_in": sum(p[3] for s_ in range(3) for p in t.frame.tiled_halo_peers(s_))})
         wire[-1]["total_in"] = wire[-1]["hiz_gather_in"] + wire[-1]["hit_colours_in"] + wire[-1]["halo_in"]
         assert t.frame.tiled_hit_bytes() == wire[-1]["hit_colours_in"]
     print("[wire] " + json.dumps(wire))
-    # equal strips: <= 300 MB per rank and frame (measured 277-299 MB; it was 733 MB with the albedo all-gathered).  Balanced
-    # strips: the ranks with the short strips receive more of the gathered Hi-Z group (everybody else's share): 263-315 MB
-    assert max(w["total_in"] for w in wire) <= (300e6 if bounds is None else 320e6)
+    # with the hit normals by request too the gathered group is the depth mips alone: <= 220 MB per rank and frame (round 2:
+    # 733 MB with albedo and normals all-gathered; 277-315 MB with only the albedo by request)
+    assert max(w["total_in"] for w in wire) <= 215e6
     history_fed = {"blurred_hist", "acc_hist", "taa_hist"}
     counts = {name: 0 for name, _ in OUTPUTS}
     texels = {name: 0 for name, _ in OUTPUTS}

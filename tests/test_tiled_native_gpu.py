@@ -48,13 +48,15 @@ def _interiors_differ(t, want, tw, th):
     return bad
 
 
-@pytest.mark.parametrize("world,tile_h,gather,by_gather", [(2, 160, 4, False), (4, 160, 4, False), (3, 136, 3, False), (4, 160, 4, True)])  # 136 = 8 * 17: only depth mips 1..3 travel
-def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather, by_gather, monkeypatch):
-    """by_gather False (the default): hit colours by request / reply (vkr_hit_requests / _reply / _scatter); True: the albedo of
-    the whole frame all-gathered into every rank.  Both must equal the plain frame on every tile interior."""
+@pytest.mark.parametrize("world,tile_h,gather,mode", [(2, 160, 4, 0), (4, 160, 4, 0), (3, 136, 3, 0), (4, 160, 4, 1), (4, 160, 4, 2)])  # 136 = 8 * 17: only depth mips 1..3 travel
+def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather, mode, monkeypatch):
+    """mode 0 (the default): hit colours AND hit normals by request / reply (vkr_sssr_trace_windowed, vkr_hit_requests /
+    _reply / _scatter, vkr_sssr_validate); 1: the albedo and the downsampled normals of the whole frame all-gathered into
+    every rank (round 2); 2: albedo by request, normals gathered.  All must equal the plain frame on every tile interior."""
     import torch
 
-    monkeypatch.setenv("VKR_TILED_ALBEDO_GATHER", "1" if by_gather else "0")
+    monkeypatch.setenv("VKR_TILED_GATHER_MODE", str(mode))
+    by_gather = mode == 1
 
     from vk_renderer_amd.camera import FrameSetup
     from vk_renderer_amd.tiling import TiledFrame
@@ -78,7 +80,13 @@ def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather, 
         assert sum(m) > 0 and all(m[r * world + r] == 0 for r in range(world)), f"hit footprints cross the strips of this frame: {m}"
         assert all(t.frame.tiled_hit_errors() == 0 for t in ranks)
         # far fewer bytes than the albedo of the other strips
-        assert 16 * sum(m) < 4 * W * H * (world - 1) // world
+        assert 20 * sum(m) < 4 * W * H * (world - 1) // world
+    # the gathered group: depth mips only when the hit normals travel by request
+    assert all(len(t.frame.tiled_gather_parts(0)) == gather + (0 if mode == 0 else 1) for t in ranks)
+    if mode == 0:
+        pending = sum(int(t.frame.download("pend_mask").raw(0).astype(bool).sum()) for t in ranks)
+        assert pending > 0, "no ray of this frame ends on another rank's rows: the deferred hit-normal test was never exercised"
+        print(f"[tiled] pending hit-normal tests in the last frame: {pending}")
     for t in ranks:
         t.frame.close()
     assert bad == 0

@@ -7,8 +7,9 @@
 //   vkr_hit_requests   per valid ray of the rank's window: the two texel rows of the bilinear footprint of
 //                      texture(albedo, hit uv) — the very rows vkr_device.hpp sample_srgb_rgb() touches — that lie outside
 //                      the window, binned by owning rank.  Pass 1 (out == NULL) counts per owner, pass 2 writes the
-//                      requests segment by segment.  A request is {frame row, left texel of the pair}: 8 bytes.
-//   vkr_hit_reply      the owner reads the two texels of every request it received from its own albedo: 8 bytes back.
+//                      requests segment by segment.  A request is 4 bytes: frame row, left texel of the pair, "and the row
+//                      below" (both rows of a footprint usually belong to one owner), which surface.
+//   vkr_hit_reply      the owner reads the texel pair(s) of every request it received from its own window: 16 bytes back.
 //   vkr_hit_scatter    the requester writes the replies into its whole-frame albedo image at their frame positions; the
 //                      filter kernel is unchanged — it finds the texels where the all-gather would have put them.
 //
@@ -22,9 +23,14 @@ namespace vkr {
 struct HitReqArgs {
   Tex rays;                 // RGBA16_UNORM, half-res window
   int aw, ah;               // albedo frame extent (full-res)
-  uint32_t bounds[HIT_MAX_WORLD + 1];  // strip r owns frame rows [bounds[r], bounds[r + 1])
+  uint32_t bounds[HIT_MAX_WORLD + 1];  // strip r owns full-res frame rows [bounds[r], bounds[r + 1])
   uint32_t world;
-  uint32_t win0, win1;      // the rows this rank holds: [win0, win1)
+  uint32_t win0, win1;      // the full-res rows this rank holds: [win0, win1)
+  // normals (pending rays of the windowed trace); has_normals == 0: none
+  uint32_t has_normals;
+  Tex pend_mask, pend_data;
+  int nw, nh;               // downsampled-normal frame extent (half-res)
+  uint32_t nrow0, nrow1;    // the half-res rows held
   uint32_t* counts;         // pass 1: per owner
   uint32_t* cursors;        // pass 2: per owner, zeroed by the caller
   uint32_t seg[HIT_MAX_WORLD];  // pass 2: first request of owner o's segment
@@ -38,33 +44,44 @@ __global__ __launch_bounds__(256) void k_hit_requests(HitReqArgs a) {
   if (tid < HIT_MAX_WORLD) s_n[tid] = 0u;
   __syncthreads();
   const int lx = blockIdx.x * 64 + threadIdx.x, ly = blockIdx.y * 4 + threadIdx.y;
-  // up to two rows per ray
-  uint32_t row[2], x = 0u, owner[2], slot[2];
+  // per ray and surface one request (both footprint rows from one owner) or two (the rows belong to different strips)
+  uint32_t code[4], owner[4], slot[4];
   int n = 0;
-  bool have = false;
+  bool have = false, pending = false;
   f2 uv = mk2(0.0f, 0.0f);
-  if (lx < a.rays.w && ly < a.rays.h && blockIdx.y != gridDim.y - 1) {
+  const bool inside = lx < a.rays.w && ly < a.rays.h && blockIdx.y != gridDim.y - 1;
+  if (inside) {
     const uint2 v = *(const uint2*)(a.rays.p + toff(a.rays, lx, ly, 8));
     if ((v.y >> 16) != 0xFFFFu) { have = true; uv = mk2(unorm16_to_float(v.x & 0xFFFFu), unorm16_to_float(v.x >> 16)); }  // filter.comp:93-95: w != 1
+    if (a.has_normals) pending = *texel_ptr<uint8_t>(a.pend_mask, lx, ly) != 0u;
   }
   // the grid has one block row more than the window: its first thread stands for the ray texels OUTSIDE the frame that the
   // filter's apron reads at the frame's left / right edge — they read 0, i.e. uv (0, 0) with w = 0 != 1: a hit
   if (blockIdx.y == gridDim.y - 1 && blockIdx.x == 0 && tid == 0) { have = true; uv = mk2(0.0f, 0.0f); }
+  // rows r0 <= r1 <= r0 + 1 of a footprint, [lo, hi) the rows held, shift: strips are cut at even full-res rows
+  auto emit = [&](uint32_t r0, uint32_t r1, uint32_t x, uint32_t lo, uint32_t hi, uint32_t tag, uint32_t shift) {
+    const bool want0 = r0 < lo || r0 >= hi, want1 = r1 != r0 && (r1 < lo || r1 >= hi);
+    uint32_t o0 = 0, o1 = 0;
+    while (o0 + 1 < a.world && (r0 << shift) >= a.bounds[o0 + 1]) ++o0;
+    while (o1 + 1 < a.world && (r1 << shift) >= a.bounds[o1 + 1]) ++o1;
+    if (want0 && want1 && o0 == o1) { code[n] = r0 | (x << 14) | VKR_HIT_BOTH_ROWS | tag; owner[n++] = o0; return; }
+    if (want0) { code[n] = r0 | (x << 14) | tag; owner[n++] = o0; }
+    if (want1) { code[n] = r1 | (x << 14) | tag; owner[n++] = o1; }
+  };
   if (have) {
     // texture(albedo, uv): vkr_device.hpp bilinear_taps_u32 — texel rows clamp(y0, y0 + 1), pair (xs, xs + 1)
     const float fx = cfma(uv.x, (float)a.aw, -0.5f), fy = cfma(uv.y, (float)a.ah, -0.5f);
     const int x0 = f2i(floorf(fx)), y0 = f2i(floorf(fy));
-    x = (uint32_t)iclamp(x0, 0, a.aw - 2);
-    const uint32_t r0 = (uint32_t)iclamp(y0, 0, a.ah - 1), r1 = (uint32_t)iclamp(y0 + 1, 0, a.ah - 1);
-    if (r0 < a.win0 || r0 >= a.win1) row[n++] = r0;
-    if (r1 != r0 && (r1 < a.win0 || r1 >= a.win1)) row[n++] = r1;
+    emit((uint32_t)iclamp(y0, 0, a.ah - 1), (uint32_t)iclamp(y0 + 1, 0, a.ah - 1), (uint32_t)iclamp(x0, 0, a.aw - 2), a.win0, a.win1, 0u, 0u);
   }
-  for (int k = 0; k < n; k++) {
-    uint32_t o = 0;
-    while (o + 1 < a.world && row[k] >= a.bounds[o + 1]) ++o;
-    owner[k] = o;
-    slot[k] = atomicAdd(&s_n[o], 1u);
+  if (pending) {
+    // texture(normal, hit uv) of the deferred test: sample<FmtRG16U>() on the half-res frame, the uv as the trace had it
+    const float4 hv = texel_ptr<float4>(a.pend_data, 2 * lx, ly)[1];
+    const float fx = cfma(hv.x, (float)a.nw, -0.5f), fy = cfma(hv.y, (float)a.nh, -0.5f);
+    const int x0 = f2i(floorf(fx)), y0 = f2i(floorf(fy));
+    emit((uint32_t)iclamp(y0, 0, a.nh - 1), (uint32_t)iclamp(y0 + 1, 0, a.nh - 1), (uint32_t)iclamp(x0, 0, a.nw - 2), a.nrow0, a.nrow1, VKR_HIT_NORMAL, 1u);
   }
+  for (int k = 0; k < n; k++) slot[k] = atomicAdd(&s_n[owner[k]], 1u);
   __syncthreads();
   if (tid < (int)a.world && s_n[tid]) {
     if (a.out) s_base[tid] = a.seg[tid] + atomicAdd(&a.cursors[tid], s_n[tid]);
@@ -72,55 +89,81 @@ __global__ __launch_bounds__(256) void k_hit_requests(HitReqArgs a) {
   }
   if (!a.out) return;
   __syncthreads();
-  for (int k = 0; k < n; k++) {
-    vkr_hit_request r;
-    r.row = row[k]; r.x = x;
-    a.out[s_base[owner[k]] + slot[k]] = r;
+  for (int k = 0; k < n; k++) a.out[s_base[owner[k]] + slot[k]] = code[k];
+}
+
+// the texel pair of the requested row — and of the row below it for a two-row request — from the owner's window image of
+// the surface the request names: 16 bytes back
+__global__ __launch_bounds__(256) void k_hit_reply(Tex albedo, Tex normals, uint32_t has_normals, const vkr_hit_request* req, uint32_t count,
+                                                   uint4* replies, uint32_t* errors) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t r = req[i];
+  const bool nrm = (r & VKR_HIT_NORMAL) != 0u, both = (r & VKR_HIT_BOTH_ROWS) != 0u;
+  const Tex& t = nrm ? normals : albedo;
+  const int ly = (int)(r & 0x3FFFu) - t.oy, lx = (int)((r >> 14) & 0x3FFFu) - t.ox;
+  if ((nrm && !has_normals) || ly < 0 || ly + (both ? 1 : 0) >= t.h || lx < 0 || lx + 1 >= t.w) {  // not mine: the ranks' strips disagree
+    atomicAdd(errors, 1u);
+    replies[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
   }
+  const U32x2 v0 = load_u32x2(t.p + toff(t, lx, ly, 4));
+  const U32x2 v1 = both ? load_u32x2(t.p + toff(t, lx, ly + 1, 4)) : v0;
+  replies[i] = make_uint4(v0.x, v0.y, v1.x, v1.y);
 }
 
-// two texels (8 bytes) per request, from the owner's window image
-__global__ __launch_bounds__(256) void k_hit_reply(Tex albedo, const vkr_hit_request* req, uint32_t count, uint64_t* replies, uint32_t* errors) {
+__global__ __launch_bounds__(256) void k_hit_scatter(Tex frame_albedo, Tex frame_normals, const vkr_hit_request* req, const uint4* replies, uint32_t count) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= count) return;
-  const vkr_hit_request r = req[i];
-  const int ly = (int)r.row - albedo.oy, lx = (int)r.x - albedo.ox;
-  if (ly < 0 || ly >= albedo.h || lx < 0 || lx + 1 >= albedo.w) { atomicAdd(errors, 1u); replies[i] = 0ull; return; }  // not mine: the row bounds of the ranks disagree
-  const U32x2 t = load_u32x2(albedo.p + toff(albedo, lx, ly, 4));
-  replies[i] = (uint64_t)t.x | ((uint64_t)t.y << 32);
-}
-
-__global__ __launch_bounds__(256) void k_hit_scatter(Tex frame_albedo, const vkr_hit_request* req, const uint64_t* replies, uint32_t count) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= count) return;
-  const vkr_hit_request r = req[i];
-  const uint64_t v = replies[i];
-  uint32_t* dst = (uint32_t*)(const_cast<uint8_t*>(frame_albedo.p) + toff(frame_albedo, (int)r.x, (int)r.row, 4));
-  dst[0] = (uint32_t)v; dst[1] = (uint32_t)(v >> 32);
+  const uint32_t r = req[i];
+  const uint4 v = replies[i];
+  const Tex& t = (r & VKR_HIT_NORMAL) ? frame_normals : frame_albedo;
+  const int row = (int)(r & 0x3FFFu), x = (int)((r >> 14) & 0x3FFFu);
+  uint32_t* dst = (uint32_t*)(const_cast<uint8_t*>(t.p) + toff(t, x, row, 4));
+  dst[0] = v.x; dst[1] = v.y;
+  if (r & VKR_HIT_BOTH_ROWS) {
+    uint32_t* dst1 = (uint32_t*)(const_cast<uint8_t*>(t.p) + toff(t, x, row + 1, 4));
+    dst1[0] = v.z; dst1[1] = v.w;
+  }
 }
 
 }  // namespace vkr
 
 using namespace vkr;
 
-extern "C" int vkr_hit_requests(const vkr_img* rays, uint32_t albedo_width, uint32_t albedo_height, const uint32_t* row_bounds, uint32_t world,
-                                uint32_t window_row0, uint32_t window_row1, uint32_t* counts, uint32_t* cursors, const uint32_t* segments,
-                                vkr_hit_request* out, void* stream) {
-  if (!row_bounds || (!out && !counts) || (out && (!cursors || !segments))) { set_error("hit_requests: NULL argument"); return VKR_ERR_NULL; }
+extern "C" int vkr_hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* cursors,
+                                const uint32_t* segments, vkr_hit_request* out, void* stream) {
+  if (!src || !row_bounds || (!out && !counts) || (out && (!cursors || !segments))) { set_error("hit_requests: NULL argument"); return VKR_ERR_NULL; }
   if (world < 1 || world > HIT_MAX_WORLD) { set_error("hit_requests: world %u (1..%d)", world, HIT_MAX_WORLD); return VKR_ERR_EXTENT; }
-  if (albedo_width < 2 || albedo_height < 1 || row_bounds[0] != 0 || row_bounds[world] != albedo_height || window_row0 >= window_row1 || window_row1 > albedo_height) {
-    set_error("hit_requests: frame %ux%u, window rows [%u, %u), bounds [%u .. %u]", albedo_width, albedo_height, window_row0, window_row1, row_bounds[0], row_bounds[world]);
+  if (src->albedo_width > 16384 || src->albedo_height > 16384) { set_error("hit_requests: a request packs row and column into 14 bits each (frame <= 16384)"); return VKR_ERR_EXTENT; }
+  if (src->albedo_width < 2 || src->albedo_height < 1 || row_bounds[0] != 0 || row_bounds[world] != src->albedo_height ||
+      src->window_row0 >= src->window_row1 || src->window_row1 > src->albedo_height) {
+    set_error("hit_requests: frame %ux%u, window rows [%u, %u), bounds [%u .. %u]", src->albedo_width, src->albedo_height, src->window_row0,
+              src->window_row1, row_bounds[0], row_bounds[world]);
     return VKR_ERR_EXTENT;
   }
   HitReqArgs a;
-  VKR_TRY(make_tex(rays, 0, VKR_FMT_RGBA16_UNORM, "hit_requests.rays", &a.rays));
-  a.aw = (int)albedo_width; a.ah = (int)albedo_height;
+  VKR_TRY(make_tex(src->rays, 0, VKR_FMT_RGBA16_UNORM, "hit_requests.rays", &a.rays));
+  a.aw = (int)src->albedo_width; a.ah = (int)src->albedo_height;
   for (uint32_t r = 0; r <= world; r++) {
-    if (r && row_bounds[r] <= row_bounds[r - 1]) { set_error("hit_requests: row bounds must increase"); return VKR_ERR_EXTENT; }
+    if ((r && row_bounds[r] <= row_bounds[r - 1]) || (row_bounds[r] & 1u)) { set_error("hit_requests: row bounds must increase and be even"); return VKR_ERR_EXTENT; }
     a.bounds[r] = row_bounds[r];
   }
-  for (uint32_t r = world + 1; r <= HIT_MAX_WORLD; r++) a.bounds[r] = albedo_height;
-  a.world = world; a.win0 = window_row0; a.win1 = window_row1;
+  for (uint32_t r = world + 1; r <= HIT_MAX_WORLD; r++) a.bounds[r] = src->albedo_height;
+  a.world = world; a.win0 = src->window_row0; a.win1 = src->window_row1;
+  a.has_normals = src->pending_mask ? 1u : 0u;
+  a.pend_mask = a.rays; a.pend_data = a.rays; a.nw = 2; a.nh = 1; a.nrow0 = 0; a.nrow1 = 1;
+  if (a.has_normals) {
+    VKR_TRY(make_tex(src->pending_mask, 0, VKR_FMT_R8_UNORM, "hit_requests.pending_mask", &a.pend_mask));
+    VKR_TRY(make_tex(src->pending_data, 0, VKR_FMT_RGBA32_SFLOAT, "hit_requests.pending_data", &a.pend_data));
+    if (a.pend_mask.w != a.rays.w || a.pend_mask.h != a.rays.h || a.pend_data.w != 2 * a.rays.w || a.pend_data.h != a.rays.h ||
+        src->normal_width < 2 || src->normal_row0 >= src->normal_row1 || src->normal_row1 > src->normal_height ||
+        2 * src->normal_height > src->albedo_height) {
+      set_error("hit_requests: pending images / normal rows do not match the rays");
+      return VKR_ERR_EXTENT;
+    }
+    a.nw = (int)src->normal_width; a.nh = (int)src->normal_height; a.nrow0 = src->normal_row0; a.nrow1 = src->normal_row1;
+  }
   a.counts = counts; a.cursors = cursors; a.out = out;
   for (uint32_t r = 0; r < HIT_MAX_WORLD; r++) a.seg[r] = (out && r < world) ? segments[r] : 0u;
   const dim3 block(64, 4);
@@ -130,21 +173,30 @@ extern "C" int vkr_hit_requests(const vkr_img* rays, uint32_t albedo_width, uint
   return launch_status("hit_requests");
 }
 
-extern "C" int vkr_hit_reply(const vkr_img* albedo, const vkr_hit_request* requests, uint32_t count, uint64_t* replies, uint32_t* error_counter, void* stream) {
+extern "C" int vkr_hit_reply(const vkr_img* albedo, const vkr_img* normals, const vkr_hit_request* requests, uint32_t count, void* replies,
+                             uint32_t* error_counter, void* stream) {
   if (count == 0) return VKR_OK;
   if (!requests || !replies || !error_counter) { set_error("hit_reply: NULL argument"); return VKR_ERR_NULL; }
-  Tex t;
+  Tex t, n;
   VKR_TRY(make_tex(albedo, 0, VKR_FMT_RGBA8_SRGB, "hit_reply.albedo", &t));
-  hipLaunchKernelGGL(k_hit_reply, dim3((count + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, t, requests, count, replies, error_counter);
+  n = t;
+  if (normals) VKR_TRY(make_tex(normals, 0, VKR_FMT_RG16_UNORM, "hit_reply.normals", &n));
+  hipLaunchKernelGGL(k_hit_reply, dim3((count + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, t, n, normals ? 1u : 0u, requests, count, (uint4*)replies, error_counter);
   return launch_status("hit_reply");
 }
 
-extern "C" int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_hit_request* requests, const uint64_t* replies, uint32_t count, void* stream) {
+extern "C" int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_img* frame_normals, const vkr_hit_request* requests, const void* replies,
+                               uint32_t count, void* stream) {
   if (count == 0) return VKR_OK;
   if (!requests || !replies) { set_error("hit_scatter: NULL argument"); return VKR_ERR_NULL; }
-  Tex t;
+  Tex t, n;
   VKR_TRY(make_tex(frame_albedo, 0, VKR_FMT_RGBA8_SRGB, "hit_scatter.frame_albedo", &t));
   if (t.ox != 0 || t.oy != 0 || t.w != t.fw || t.h != t.fh) { set_error("hit_scatter: the destination must be the whole-frame image"); return VKR_ERR_EXTENT; }
-  hipLaunchKernelGGL(k_hit_scatter, dim3((count + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, t, requests, replies, count);
+  n = t;
+  if (frame_normals) {
+    VKR_TRY(make_tex(frame_normals, 0, VKR_FMT_RG16_UNORM, "hit_scatter.frame_normals", &n));
+    if (n.ox != 0 || n.oy != 0 || n.w != n.fw || n.h != n.fh) { set_error("hit_scatter: the destination must be the whole-frame image"); return VKR_ERR_EXTENT; }
+  }
+  hipLaunchKernelGGL(k_hit_scatter, dim3((count + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, t, n, requests, (const uint4*)replies, count);
   return launch_status("hit_scatter");
 }

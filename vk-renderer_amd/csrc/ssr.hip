@@ -51,6 +51,11 @@ struct TraceArgs {
   // 0.005 / screen_size (screen_trace.glsl:10,20 at most_detailed_mip 0) and zfar / (zfar - znear) (gbuffer_encode.glsl:77)
   f2 screen_size_inv, uv_offset_abs;
   float f_over_fn;
+  // windowed (multi-GPU, vkr_sssr_trace_windowed): `normal` holds only rows [nrm_row0, nrm_row1) of the frame when the march
+  // ends; a ray whose hit-normal footprint leaves them is stored as a provisional hit and its test is left to
+  // vkr_sssr_validate — pend_mask (R8, every pixel) says which, pend_data (two float4 per pixel) keeps R and the hit uv
+  int nrm_row0, nrm_row1;
+  Tex pend_mask, pend_data;
 };
 
 #define TP_VEC 5  // uint4 per parked-ray record (18 dwords used): 80-byte stride, conflict-free for consecutive rays
@@ -103,6 +108,7 @@ VKR_DEV void pool_load_result(const uint4* p, RayState& s) {
 #endif
 #define TRACE_PIN_ROUND 16  // round 0: the pinned steps, run by every ray
 #define TRACE_THREADS (256 * TRACE_WY)
+template <bool WINDOWED>
 __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   const i2 blk = xcd_block<4, 8 / TRACE_WY>();  // chunks of 128 x 64 output pixels
   __shared__ uint4 s_mip[16];
@@ -241,16 +247,45 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
     const f2 ray_step = mk2(fabsf(out_ray.x - ray_start.x) * tex_size.x, fabsf(out_ray.y - ray_start.y) * tex_size.y);
     if (vmax(ray_step.x, ray_step.y) < 2.0f) valid_hit = false;
   }
-  if (valid_hit) {
-    const f3 hnw = decode_normal(sample<FmtRG16U>(a.normal, xy(out_ray)));
-    const f3 hit_normal = xyz(mul(a.normal_mat, mk4(hnw.x, hnw.y, hnw.z, 0.0f)));
-    if (dot(hit_normal, R) > 0.0f || dot(pixel_normal, R) < 0.0f) valid_hit = false;
-  }
-  if (valid_hit) {
-    const float hit_depth = sample<FmtD24>(depth0, xy(out_ray));
-    const float hit_z = linearize_depth2_unorm(hit_depth, pr.znear, pr.zfar);
-    const float ray_z = linearize_depth2(out_ray.z, pr.znear, pr.zfar);
-    if (ray_z > hit_z + 0.3f || ray_z < hit_z - 0.1f) valid_hit = false;
+  if (!WINDOWED) {
+    if (valid_hit) {
+      const f3 hnw = decode_normal(sample<FmtRG16U>(a.normal, xy(out_ray)));
+      const f3 hit_normal = xyz(mul(a.normal_mat, mk4(hnw.x, hnw.y, hnw.z, 0.0f)));
+      if (dot(hit_normal, R) > 0.0f || dot(pixel_normal, R) < 0.0f) valid_hit = false;
+    }
+    if (valid_hit) {
+      const float hit_depth = sample<FmtD24>(depth0, xy(out_ray));
+      const float hit_z = linearize_depth2_unorm(hit_depth, pr.znear, pr.zfar);
+      const float ray_z = linearize_depth2(out_ray.z, pr.znear, pr.zfar);
+      if (ray_z > hit_z + 0.3f || ray_z < hit_z - 0.1f) valid_hit = false;
+    }
+  } else {
+    // The same conjunction with the tests that need nothing remote first (the pyramid is whole-frame): a ray is only left
+    // pending when every other test has passed and its hit-normal footprint has a row outside the rows of `normal` held here.
+    if (valid_hit && dot(pixel_normal, R) < 0.0f) valid_hit = false;
+    if (valid_hit) {
+      const float hit_depth = sample<FmtD24>(depth0, xy(out_ray));
+      const float hit_z = linearize_depth2_unorm(hit_depth, pr.znear, pr.zfar);
+      const float ray_z = linearize_depth2(out_ray.z, pr.znear, pr.zfar);
+      if (ray_z > hit_z + 0.3f || ray_z < hit_z - 0.1f) valid_hit = false;
+    }
+    bool pending = false;
+    if (valid_hit) {
+      // rows of the bilinear footprint of texture(normal, hit uv): sample<>() clamps y0 and y0 + 1 to the frame
+      const int y0 = f2i(floorf(cfma(out_ray.y, (float)a.normal.fh, -0.5f)));
+      const int r0 = iclamp(y0, 0, a.normal.fh - 1), r1 = iclamp(y0 + 1, 0, a.normal.fh - 1);
+      pending = r0 < a.nrm_row0 || r1 >= a.nrm_row1;
+      if (!pending) {
+        const f3 hnw = decode_normal(sample<FmtRG16U>(a.normal, xy(out_ray)));
+        const f3 hit_normal = xyz(mul(a.normal_mat, mk4(hnw.x, hnw.y, hnw.z, 0.0f)));
+        if (dot(hit_normal, R) > 0.0f) valid_hit = false;
+      } else {
+        float4* pd = texel_ptr<float4>(a.pend_data, 2 * lx, ly);
+        pd[0] = make_float4(R.x, R.y, R.z, 0.0f);
+        pd[1] = make_float4(out_ray.x, out_ray.y, 0.0f, 0.0f);
+      }
+    }
+    *texel_ptr<uint8_t>(a.pend_mask, lx, ly) = pending ? 1u : 0u;
   }
   {  // RGBA16_UNORM store (advanced_ssr.cpp:62)
     uint2 o;
@@ -279,6 +314,21 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
     o.y = 0u;
     *texel_ptr<uint2>(a.out_occ, lx, ly) = o;
   }
+}
+
+// ---- sssr_validate: the deferred hit-normal test of the windowed trace (trace.comp:103-109) -----------------------
+// For every pixel the windowed trace left pending (its hit-normal footprint was not in memory yet): the same sample, the
+// same dot product; a ray that fails becomes invalid (w = 1.0), exactly what the one-GPU trace would have stored.
+__global__ __launch_bounds__(256) void k_sssr_validate(Tex rays, Tex pend_mask, Tex pend_data, Tex normal, Mat4 normal_mat) {
+  const int lx = blockIdx.x * 64 + threadIdx.x, ly = blockIdx.y * 4 + threadIdx.y;
+  if (lx >= rays.w || ly >= rays.h) return;
+  if (*texel_ptr<uint8_t>(pend_mask, lx, ly) == 0u) return;
+  const float4* pd = texel_ptr<float4>(pend_data, 2 * lx, ly);
+  const float4 Rv = pd[0], hv = pd[1];
+  const f3 hnw = decode_normal(sample<FmtRG16U>(normal, mk2(hv.x, hv.y)));
+  const f3 hit_normal = xyz(mul(normal_mat, mk4(hnw.x, hnw.y, hnw.z, 0.0f)));
+  if (dot(hit_normal, mk3(Rv.x, Rv.y, Rv.z)) > 0.0f)
+    *(uint16_t*)(const_cast<uint8_t*>(rays.p) + toff(rays, lx, ly, 8) + 6u) = (uint16_t)0xFFFFu;  // w = 1.0: not a hit (filter.comp:93-95)
 }
 
 // ---- sssr_filter (filter.comp:36-149, FULL_RES 0) -----------------------------------------------
@@ -719,13 +769,11 @@ static void load_proj(Proj& pr, float fovy, float aspect, float znear, float zfa
   pr.aspect = aspect; pr.znear = znear; pr.zfar = zfar;
 }
 
-extern "C" int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
-                              const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
-                              const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_trace_push* push,
-                              void* stream) {
+static int make_trace_args(TraceArgs& a, const vkr_img* depth, const vkr_img* normal, const vkr_img* material, const vkr_trace_params* params,
+                           const float* halton_vec4, const vkr_img* out_ray, const vkr_img* out_occlusion, const vkr_img* pdf_tex,
+                           const vkr_trace_push* push) {
   if (!params || !push || !halton_vec4 || !depth) { set_error("sssr_trace: NULL argument"); return VKR_ERR_NULL; }
   if (((uintptr_t)halton_vec4 % 16) != 0) { set_error("sssr_trace: halton buffer must be 16-byte aligned"); return VKR_ERR_LAYOUT; }
-  TraceArgs a;
   if (depth->mip_count < 1 || depth->mip_count > VKR_MAX_MIPS) { set_error("sssr_trace: bad depth mip count"); return VKR_ERR_MIPS; }
   a.depth.count = (int)depth->mip_count;
   for (int i = 0; i < a.depth.count; i++) VKR_TRY(make_tex(depth, i, VKR_FMT_D24_UNORM_S8, "sssr_trace.depth", &a.depth.mip[i]));
@@ -755,10 +803,66 @@ extern "C" int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const
     a.uv_offset_abs.x = 0.005f / sw; a.uv_offset_abs.y = 0.005f / sh;
     a.f_over_fn = a.pr.zfar / (a.pr.zfar - a.pr.znear);
   }
+  a.nrm_row0 = 0; a.nrm_row1 = a.normal.fh;
+  a.pend_mask = a.out_ray; a.pend_data = a.out_ray;  // unused unless windowed
+  return VKR_OK;
+}
+
+extern "C" int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                              const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                              const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_trace_push* push,
+                              void* stream) {
+  TraceArgs a;
+  VKR_TRY(make_trace_args(a, depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, push));
   dim3 block(TRACE_THREADS, 1);
   dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 8 * TRACE_WY - 1) / (8 * TRACE_WY));
-  hipLaunchKernelGGL(k_sssr_trace, grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_sssr_trace<false>, grid, block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_trace");
+}
+
+extern "C" int vkr_sssr_trace_windowed(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                                       const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                                       const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_img* pending_mask,
+                                       const vkr_img* pending_data, const vkr_trace_window_push* push, void* stream) {
+  if (!push) { set_error("sssr_trace_windowed: NULL argument"); return VKR_ERR_NULL; }
+  TraceArgs a;
+  const vkr_trace_push base {push->max_roughness};
+  VKR_TRY(make_trace_args(a, depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, &base));
+  if (a.normal.ox != 0 || a.normal.oy != 0 || a.normal.w != a.normal.fw || a.normal.h != a.normal.fh) {
+    set_error("sssr_trace_windowed: `normal` must be the whole-frame image (rows outside the window are filled later)");
+    return VKR_ERR_EXTENT;
+  }
+  if (push->normal_row0 >= push->normal_row1 || push->normal_row1 > (uint32_t)a.normal.fh) {
+    set_error("sssr_trace_windowed: normal rows [%u, %u) of %d", push->normal_row0, push->normal_row1, a.normal.fh);
+    return VKR_ERR_EXTENT;
+  }
+  a.nrm_row0 = (int)push->normal_row0; a.nrm_row1 = (int)push->normal_row1;
+  VKR_TRY(make_tex(pending_mask, 0, VKR_FMT_R8_UNORM, "sssr_trace_windowed.pending_mask", &a.pend_mask));
+  VKR_TRY(make_tex(pending_data, 0, VKR_FMT_RGBA32_SFLOAT, "sssr_trace_windowed.pending_data", &a.pend_data));
+  if (a.pend_mask.w != a.out_ray.w || a.pend_mask.h != a.out_ray.h || a.pend_data.w != 2 * a.out_ray.w || a.pend_data.h != a.out_ray.h) {
+    set_error("sssr_trace_windowed: pending_mask must have the rays' extent, pending_data twice its width");
+    return VKR_ERR_EXTENT;
+  }
+  dim3 block(TRACE_THREADS, 1);
+  dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 8 * TRACE_WY - 1) / (8 * TRACE_WY));
+  hipLaunchKernelGGL(k_sssr_trace<true>, grid, block, 0, (hipStream_t)stream, a);
+  return launch_status("sssr_trace_windowed");
+}
+
+extern "C" int vkr_sssr_validate(const vkr_img* rays, const vkr_img* pending_mask, const vkr_img* pending_data, const vkr_img* frame_normals,
+                                 const vkr_trace_params* params, void* stream) {
+  if (!params) { set_error("sssr_validate: NULL argument"); return VKR_ERR_NULL; }
+  Tex r, m, pd, n;
+  VKR_TRY(make_tex(rays, 0, VKR_FMT_RGBA16_UNORM, "sssr_validate.rays", &r));
+  VKR_TRY(make_tex(pending_mask, 0, VKR_FMT_R8_UNORM, "sssr_validate.pending_mask", &m));
+  VKR_TRY(make_tex(pending_data, 0, VKR_FMT_RGBA32_SFLOAT, "sssr_validate.pending_data", &pd));
+  VKR_TRY(make_tex(frame_normals, 0, VKR_FMT_RG16_UNORM, "sssr_validate.normal", &n));
+  if (m.w != r.w || m.h != r.h || pd.w != 2 * r.w || pd.h != r.h) { set_error("sssr_validate: pending images do not match the rays"); return VKR_ERR_EXTENT; }
+  Mat4 nm;
+  load_mat(nm, params->normal_mat);
+  const dim3 block(64, 4);
+  hipLaunchKernelGGL(k_sssr_validate, grid2d(r.w, r.h, block), block, 0, (hipStream_t)stream, r, m, pd, n, nm);
+  return launch_status("sssr_validate");
 }
 
 extern "C" int vkr_sssr_filter(const vkr_img* rays, const vkr_img* depth, const vkr_img* albedo, const vkr_img* normal,

@@ -178,14 +178,20 @@ class HostFrame:
         if stream is None:
             stream = torch.cuda.current_stream(device).cuda_stream
         self.tiled_handle = None
-        self.albedo_by_gather = True  # only the C++ tiled frame has the hit-colour request / reply
+        self.albedo_by_gather, self.gather_mode = True, 1  # only the C++ tiled frame has the request / reply exchanges
         if native_tiled is not None:
             nt = native_tiled
             comm = nt.get("comm")
             bounds = nt.get("row_bounds")  # world + 1 strip boundaries (rows), or None for equal strips
             arr = (C.c_uint32 * len(bounds))(*bounds) if bounds is not None else None
-            self.albedo_by_gather = bool(nt.get("albedo_by_gather", os.environ.get("VKR_TILED_ALBEDO_GATHER") == "1"))
-            tc = TiledConfig(W, H, nt["rank"], nt["world"], nt["halo"], nt["gathered_mips"], 1 if nt.get("force_tiled") else 0, 1 if self.albedo_by_gather else 0,
+            # 0 (default): hit colours and hit normals by request / reply; 1: albedo and normals all-gathered (round 2);
+            # 2: albedo by request, normals gathered
+            mode = nt.get("gather_mode")
+            if mode is None:
+                mode = int(os.environ.get("VKR_TILED_GATHER_MODE", "1" if os.environ.get("VKR_TILED_ALBEDO_GATHER") == "1" else "0"))
+            self.gather_mode = int(mode)
+            self.albedo_by_gather = self.gather_mode == 1
+            tc = TiledConfig(W, H, nt["rank"], nt["world"], nt["halo"], nt["gathered_mips"], 1 if nt.get("force_tiled") else 0, self.gather_mode,
                              C.c_void_p(stream), C.c_void_p(comm.handle if comm is not None else None),
                              C.cast(arr, C.POINTER(C.c_uint32)) if arr is not None else None)
             self.comm = comm  # keep the communicator alive as long as the frame

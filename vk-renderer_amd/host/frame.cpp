@@ -163,6 +163,16 @@ struct PostFxFrame {
     for (uint32_t l : graph.last_submitted_lanes()) { task_lanes += std::to_string(l); task_lanes += ' '; }
   }
 
+  // TraceParams as run() hands them to the SSR passes (main.cpp:368-373), for the tiled frame's deferred hit-normal test
+  vkr_trace_params trace_params() const {
+    vkr_trace_params t {};
+    const glm::mat4 normal_mat = glm::transpose(glm::inverse(view));
+    std::memcpy(t.normal_mat.m, &normal_mat, sizeof(t.normal_mat.m));
+    const glm::vec4 fazz = draw_params.fovy_aspect_znear_zfar;
+    t.fovy = fazz.x; t.aspect = fazz.y; t.znear = fazz.z; t.zfar = fazz.w;
+    return t;
+  }
+
   void end_frame(bool swap_depth) {  // main.cpp:416-420
     if (swap_depth) graph.remap(gbuffer.depth, gbuffer.prev_depth);
     graph.remap(gtao.output, gtao.prev_frame);  // main.cpp:417: the reprojection variant's history (gtao.cpp:241-284)
@@ -179,7 +189,7 @@ struct PostFxFrame {
         {"raw", 8}, {"filtered", 9}, {"acc_ao", 10}, {"acc_hist", 11}, {"rays", 12}, {"reflections", 13}, {"blurred", 14},
         {"blurred_hist", 15}, {"pdf", 16}, {"taa_hist", 17}, {"taa_target", 18}, {"frame_hiz", 19}, {"frame_normals", 20},
         {"frame_albedo", 21}, {"color_out", 22}, {"brdf", 23}, {"ao_prev_frame", 24}, {"ao_output", 25}, {"deinterleaved_depth", 26},
-        {"st_raw", 27}, {"st_filtered", 28}, {"st_accumulated", 29}};
+        {"st_raw", 27}, {"st_filtered", 28}, {"st_accumulated", 29}, {"pend_mask", 30}};
     auto it = ids.find(name);
     if (it == ids.end()) throw std::runtime_error{"vkrh_image: unknown image '" + name + "'"};
     switch (it->second) {
@@ -192,7 +202,9 @@ struct PostFxFrame {
       case 19: return gbuffer.frame_hiz; case 20: return gbuffer.frame_normals; case 21: return gbuffer.frame_albedo;
       case 22: return color_out_tex; case 23: return ssr.get_preintegrated_brdf(); case 24: return gtao.prev_frame;
       case 25: return gtao.output; case 26: return gtao.deinterleaved_depth; case 27: return screen_trace.raw;
-      case 28: return screen_trace.filtered; default: return screen_trace.accumulated;
+      case 28: return screen_trace.filtered;
+      case 30: if (!gbuffer.normals_by_request) throw std::runtime_error{"vkrh_image: 'pend_mask' only exists with hit normals by request"}; return gbuffer.pend_mask;
+      default: return screen_trace.accumulated;
     }
   }
 };
@@ -250,6 +262,7 @@ struct TiledFrame {
     vkrh_config fc {W, H, 0, (int32_t)wy0, W, wh, tiled ? 1u : 0u, c.stream};
     frame.reset(new PostFxFrame(fc));
     frame->hiz_gathered_mips = tiled ? k : 4;
+    if (normals_by_request()) frame->gbuffer.enable_normal_requests(frame->graph, wy0 / 2, (wy0 + wh) / 2);
     if (tiled) {
       // the exchanges' kernels (a few workgroups each) must not queue behind a frame's worth of compute waves
       int prio_low = 0, prio_high = 0;
@@ -347,7 +360,7 @@ struct TiledFrame {
     auto& g = frame->gbuffer;
     if (which == VKRH_GATHER_HIZ) {
       for (uint32_t m = 1; m <= cfg.gathered_mips; m++) out[n++] = part(g.depth, m, g.frame_hiz, m - 1, m);
-      out[n++] = part(g.downsampled_normals, 0, g.frame_normals, 0, 1);
+      if (!normals_by_request()) out[n++] = part(g.downsampled_normals, 0, g.frame_normals, 0, 1);
     } else {
       out[n++] = part(g.albedo, 0, g.frame_albedo, 0, 0);
     }
@@ -395,7 +408,7 @@ struct TiledFrame {
     }
   }
   void start_gather(int which) {
-    gpu::TraceRange range {which == VKRH_GATHER_HIZ ? "all-gather Hi-Z + normals" : "all-gather albedo"};
+    gpu::TraceRange range {which == VKRH_GATHER_HIZ ? "all-gather Hi-Z" : "all-gather albedo"};
     start(which, [&] {
       vkr_gather_part p[8];
       const uint32_t n = gather_parts(which, p);
@@ -421,13 +434,29 @@ struct TiledFrame {
   struct HitState {
     uint32_t* counts = nullptr;     // device: [world] counts, [world] cursors, [1] reply errors, [world * world] gathered matrix
     uint32_t* host_counts = nullptr;  // pinned: world * world + 1
-    vkr_hit_request* req_out = nullptr; uint64_t* reply_in = nullptr; uint64_t cap_out = 0;   // what I ask / get back
-    vkr_hit_request* req_in = nullptr; uint64_t* reply_out = nullptr; uint64_t cap_in = 0;    // what I am asked / answer
+    vkr_hit_request* req_out = nullptr; uint8_t* reply_in = nullptr; uint64_t cap_out = 0;   // what I ask / get back
+    vkr_hit_request* req_in = nullptr; uint8_t* reply_out = nullptr; uint64_t cap_in = 0;    // what I am asked / answer
     std::vector<uint32_t> out_seg, in_seg;  // [world + 1]: my requests for owner o / the requests of rank r for me, as runs
     uint64_t wire_bytes = 0;
     bool counted = false;
   } hit;
-  bool by_request() const { return tiled && cfg.world > 1 && !cfg.albedo_by_gather; }
+  bool by_request() const { return tiled && cfg.world > 1 && cfg.albedo_by_gather != 1; }          // hit colours
+  bool normals_by_request() const { return tiled && cfg.world > 1 && cfg.albedo_by_gather == 0; }   // ... and hit normals
+  vkr_img dn_img() { return frame->graph.get_image(frame->gbuffer.downsampled_normals)->describe(0, 1); }
+  vkr_img frame_normals_img() { return frame->graph.get_image(frame->gbuffer.frame_normals)->describe(0, 1); }
+  vkr_img pend_mask_img() { return frame->graph.get_image(frame->gbuffer.pend_mask)->describe(0, 1); }
+  vkr_img pend_data_img() { return frame->graph.get_image(frame->gbuffer.pend_data)->describe(0, 1); }
+  // what vkr_hit_requests walks: the rays for the albedo rows, the pending rays of the windowed trace for the normal rows
+  struct HitSources { vkr_img rays, mask, data; vkr_hit_sources src; };
+  void hit_sources(HitSources& h) {
+    h.rays = rays_img();
+    h.src = vkr_hit_sources {&h.rays, W, H, wy0, wy0 + wh, nullptr, nullptr, 0, 0, 0, 0};
+    if (normals_by_request()) {
+      h.mask = pend_mask_img(); h.data = pend_data_img();
+      h.src.pending_mask = &h.mask; h.src.pending_data = &h.data;
+      h.src.normal_width = W / 2; h.src.normal_height = H / 2; h.src.normal_row0 = wy0 / 2; h.src.normal_row1 = (wy0 + wh) / 2;
+    }
+  }
   vkr_img rays_img() { return frame->graph.get_image(frame->ssr.get_rays())->describe(0, 1); }
   vkr_img albedo_img() { return frame->graph.get_image(frame->gbuffer.albedo)->describe(0, 1); }
   vkr_img frame_albedo_img() { return frame->graph.get_image(frame->gbuffer.frame_albedo)->describe(0, 1); }
@@ -436,15 +465,15 @@ struct TiledFrame {
     hit.counts = (uint32_t*)gpu::device_alloc(sizeof(uint32_t) * (2 * w + 1 + w * w));
     check(hipHostMalloc((void**)&hit.host_counts, sizeof(uint32_t) * (w * w + 1), hipHostMallocDefault), "pinned counts");
     hit.out_seg.assign(w + 1, 0); hit.in_seg.assign(w + 1, 0);
-    // worst case of what this rank can ask for: two footprint rows per ray of its window, + the texel pair at (0, 0); the
-    // same room for what it may be asked (a rank asked for more grows, see grow())
-    const uint64_t worst = 2ull * (W / 2) * (wh / 2) + 2;
+    // room for what this rank can ask for — every ray of its window ending on another strip — and the same for what it
+    // may be asked (anything beyond grows, see grow())
+    const uint64_t worst = (normals_by_request() ? 2ull : 1ull) * (W / 2) * (wh / 2) + 1024;  // one request per ray and surface (two only where a footprint straddles two strips)
     uint64_t cap = 0;
     grow((void**)&hit.req_out, &cap, worst, sizeof(vkr_hit_request));
-    grow((void**)&hit.reply_in, &hit.cap_out, worst, sizeof(uint64_t));
+    grow((void**)&hit.reply_in, &hit.cap_out, worst, VKR_HIT_REPLY_BYTES);
     cap = 0;
     grow((void**)&hit.req_in, &cap, worst, sizeof(vkr_hit_request));
-    grow((void**)&hit.reply_out, &hit.cap_in, worst, sizeof(uint64_t));
+    grow((void**)&hit.reply_out, &hit.cap_in, worst, VKR_HIT_REPLY_BYTES);
     grew = false;  // before the first frame: the caller synchronises after set-up (prepare), nothing is in flight
   }
   void hit_release() {
@@ -457,13 +486,19 @@ struct TiledFrame {
     const vkr_img a = albedo_img(), f = frame_albedo_img();
     if (a.pitch_bytes[0] != f.pitch_bytes[0] || a.width != f.width) throw std::runtime_error {"tiled frame: window and whole-frame albedo must share width and row pitch"};
     check(hipMemcpyAsync((uint8_t*)f.base + uint64_t(a.origin_y) * f.pitch_bytes[0], a.base, uint64_t(a.height) * a.pitch_bytes[0], hipMemcpyDeviceToDevice, s), "albedo rows");
+    if (normals_by_request()) {
+      const vkr_img n = dn_img(), fn = frame_normals_img();
+      if (n.pitch_bytes[0] != fn.pitch_bytes[0] || n.width != fn.width) throw std::runtime_error {"tiled frame: window and whole-frame normals must share width and row pitch"};
+      check(hipMemcpyAsync((uint8_t*)fn.base + uint64_t(n.origin_y) * fn.pitch_bytes[0], n.base, uint64_t(n.height) * n.pitch_bytes[0], hipMemcpyDeviceToDevice, s), "normal rows");
+    }
   }
   // pass 1, on the compute stream right after the trace
   void hit_count() {
     const uint32_t w = cfg.world;
     check(hipMemsetAsync(hit.counts, 0, sizeof(uint32_t) * (2 * w + 1), compute), "memset");
-    const vkr_img r = rays_img();
-    if (vkr_hit_requests(&r, W, H, bounds.data(), w, wy0, wy0 + wh, hit.counts, nullptr, nullptr, nullptr, compute) != 0)
+    HitSources h;
+    hit_sources(h);
+    if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, nullptr, nullptr, nullptr, compute) != 0)
       throw std::runtime_error {std::string {"hit_requests: "} + vkr_last_error()};
     hit.counted = true;
   }
@@ -494,14 +529,15 @@ struct TiledFrame {
     if (matrix[me * w + me]) throw std::runtime_error {"tiled frame: a rank requested hit colours from itself"};
     uint64_t cap = hit.cap_out;
     grow((void**)&hit.req_out, &cap, hit.out_seg[w], sizeof(vkr_hit_request));
-    grow((void**)&hit.reply_in, &hit.cap_out, hit.out_seg[w], sizeof(uint64_t));
+    grow((void**)&hit.reply_in, &hit.cap_out, hit.out_seg[w], VKR_HIT_REPLY_BYTES);
     cap = hit.cap_in;
     grow((void**)&hit.req_in, &cap, hit.in_seg[w], sizeof(vkr_hit_request));
-    grow((void**)&hit.reply_out, &hit.cap_in, hit.in_seg[w], sizeof(uint64_t));
+    grow((void**)&hit.reply_out, &hit.cap_in, hit.in_seg[w], VKR_HIT_REPLY_BYTES);
     order_exchange_behind_allocations(s);
     if (hit.out_seg[w]) {
-      const vkr_img r = rays_img();
-      if (vkr_hit_requests(&r, W, H, bounds.data(), w, wy0, wy0 + wh, hit.counts, hit.counts + w, hit.out_seg.data(), hit.req_out, s) != 0)
+      HitSources h;
+      hit_sources(h);
+      if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, hit.counts + w, hit.out_seg.data(), hit.req_out, s) != 0)
         throw std::runtime_error {std::string {"hit_requests: "} + vkr_last_error()};
     }
     uint32_t n = 0;
@@ -510,26 +546,34 @@ struct TiledFrame {
       const uint64_t so = hit.out_seg[p + 1] - hit.out_seg[p], ri = hit.in_seg[p + 1] - hit.in_seg[p];
       if (p == me || (so == 0 && ri == 0)) continue;
       peers[n++] = vkr_halo_peer {int32_t(p), 0u, hit.req_out + hit.out_seg[p], so * sizeof(vkr_hit_request), hit.req_in + hit.in_seg[p], ri * sizeof(vkr_hit_request)};
-      hit.wire_bytes += (ri + so) * 8;  // requests in now, as many replies in later
+      hit.wire_bytes += ri * sizeof(vkr_hit_request) + so * VKR_HIT_REPLY_BYTES;  // requests in now, replies to my requests later
     }
     return n;
   }
   // answers on stream s; returns the peer list of the way back
   uint32_t hit_reply(hipStream_t s, vkr_halo_peer* peers) {
     const uint32_t w = cfg.world, me = cfg.rank;
-    const vkr_img a = albedo_img();
-    if (vkr_hit_reply(&a, hit.req_in, hit.in_seg[w], hit.reply_out, hit.counts + 2 * w, s) != 0) throw std::runtime_error {std::string {"hit_reply: "} + vkr_last_error()};
+    const vkr_img a = albedo_img(), dn = dn_img();
+    if (vkr_hit_reply(&a, normals_by_request() ? &dn : nullptr, hit.req_in, hit.in_seg[w], hit.reply_out, hit.counts + 2 * w, s) != 0)
+      throw std::runtime_error {std::string {"hit_reply: "} + vkr_last_error()};
     uint32_t n = 0;
     for (uint32_t p = 0; p < w; p++) {
       const uint64_t so = hit.in_seg[p + 1] - hit.in_seg[p], ri = hit.out_seg[p + 1] - hit.out_seg[p];
       if (p == me || (so == 0 && ri == 0)) continue;
-      peers[n++] = vkr_halo_peer {int32_t(p), 0u, hit.reply_out + hit.in_seg[p], so * sizeof(uint64_t), hit.reply_in + hit.out_seg[p], ri * sizeof(uint64_t)};
+      peers[n++] = vkr_halo_peer {int32_t(p), 0u, hit.reply_out + uint64_t(hit.in_seg[p]) * VKR_HIT_REPLY_BYTES, so * VKR_HIT_REPLY_BYTES,
+                                  hit.reply_in + uint64_t(hit.out_seg[p]) * VKR_HIT_REPLY_BYTES, ri * VKR_HIT_REPLY_BYTES};
     }
     return n;
   }
   void hit_scatter(hipStream_t s) {
-    const vkr_img f = frame_albedo_img();
-    if (vkr_hit_scatter(&f, hit.req_out, hit.reply_in, hit.out_seg[cfg.world], s) != 0) throw std::runtime_error {std::string {"hit_scatter: "} + vkr_last_error()};
+    const vkr_img f = frame_albedo_img(), fn = frame_normals_img();
+    if (vkr_hit_scatter(&f, normals_by_request() ? &fn : nullptr, hit.req_out, hit.reply_in, hit.out_seg[cfg.world], s) != 0)
+      throw std::runtime_error {std::string {"hit_scatter: "} + vkr_last_error()};
+    if (normals_by_request()) {  // the hit-normal test the windowed trace deferred: the footprints are complete now
+      const vkr_img r = rays_img(), m = pend_mask_img(), d = pend_data_img();
+      const vkr_trace_params tp = frame->trace_params();
+      if (vkr_sssr_validate(&r, &m, &d, &fn, &tp, s) != 0) throw std::runtime_error {std::string {"sssr_validate: "} + vkr_last_error()};
+    }
     hit.counted = false;
   }
   // The native exchange: the counts of every rank cross the host once (the compute stream has GTAO queued meanwhile), the

@@ -119,10 +119,11 @@ int vkrh_set_async(void* frame, uint32_t on);
  * Rank r of `world` owns rows [r * H / world, (r + 1) * H / world) of the full_width x full_height frame and holds
  * them plus `halo` rows above / below (clipped to the frame).  One vkrh_tiled_step() is one frame:
  *
- *   downsample | all-gather(depth mips 1..k + downsampled normals) starts on the exchange stream
+ *   downsample | all-gather(depth mips 1..k) starts on the exchange stream; own albedo / normal rows go into the frame images
  *   TAA (needs neither)            | its halo refresh starts
- *   Hi-Z tail + SSR trace          (after the gather) | hit-colour requests are counted
- *   GTAO main, filter, accumulate  | its halo refresh starts | request / reply for the hit colours on the exchange stream
+ *   Hi-Z tail + SSR trace          (after the gather; rays that end on another rank's rows stay pending) | requests are counted
+ *   GTAO main, filter, accumulate  | its halo refresh starts | request / reply for hit colours + hit normals, then the
+ *                                    deferred hit-normal test (vkr_sssr_validate), on the exchange stream
  *   SSR filter + blur              (after the replies are in place) | its halo refresh starts; history remaps
  *
  * Hit colours: the filter reads the albedo at the hit position of every valid ray, anywhere in the frame.  Each rank asks
@@ -141,7 +142,8 @@ typedef struct vkrh_tiled_config {
   uint32_t halo;            /* full-res pixels, even, a multiple of 2^gathered_mips                          */
   uint32_t gathered_mips;   /* depth image-mips 1..k travel by all-gather (the tile extent must divide by 2^k) */
   uint32_t force_tiled;     /* world == 1: still run the gathers and the staged frame (rehearsal)              */
-  uint32_t albedo_by_gather;/* 0 (default): hit colours by request / reply; 1: all-gather the albedo of the whole frame      */
+  uint32_t albedo_by_gather;/* 0 (default): hit colours AND hit normals by request / reply; 1: all-gather the albedo and the
+                             * downsampled normals of the whole frame (round 2); 2: albedo by request, normals gathered      */
   void*    stream;          /* compute stream                                                                */
   vkr_comm* comm;           /* RCCL communicator of include/vkr_postfx.h, or NULL (no wire: lockstep harness) */
   /* NULL: world strips of full_height / world rows.  Otherwise world + 1 increasing row numbers, [0] = 0 and [world] =

@@ -80,6 +80,15 @@ void Gbuffer::enable_tiling(RenderGraph &graph, uint32_t full_width, uint32_t fu
   frame_albedo = graph.create_frame_image(gpu::ImageInfo {VK_FORMAT_R8G8B8A8_SRGB, COLOR, full_width, full_height});
 }
 
+void Gbuffer::enable_normal_requests(RenderGraph &graph, uint32_t row0, uint32_t row1) {
+  if (!tiled) throw std::runtime_error {"Gbuffer::enable_normal_requests: the G-buffer is not tiled"};
+  normals_by_request = true;
+  normal_row0 = row0; normal_row1 = row1;
+  const auto usage = VK_IMAGE_USAGE_STORAGE_BIT|VK_IMAGE_USAGE_SAMPLED_BIT;
+  pend_mask = graph.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo {VK_FORMAT_R8_UNORM, COLOR, w/2, h/2}, VK_IMAGE_TILING_OPTIMAL, usage);
+  pend_data = graph.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo {VK_FORMAT_R32G32B32A32_SFLOAT, COLOR, 2 * (w/2), h/2}, VK_IMAGE_TILING_OPTIMAL, usage);
+}
+
 // ==== DownsamplePass (downsample_pass.cpp) ================================================================
 #ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 DownsamplePass::DownsamplePass() : sampler {default_sampler()} {
@@ -398,6 +407,16 @@ void AdvancedSSR::run_trace_pass(RenderGraph &graph, const AdvancedSSRParams &pa
   advance_counter();
   const auto hiz = gbuff.tiled? gbuff.frame_hiz : gbuff.depth;
   const uint32_t mips = graph.get_descriptor(hiz).mip_levels;
+  if (gbuff.tiled && gbuff.normals_by_request) {  // multi-GPU: the hit-normal test of rays that end on another rank's rows is deferred
+    if (!trace_windowed_pass.has_program()) trace_windowed_pass = gpu::create_compute_pipeline("sssr_trace_windowed");
+    const vkr_trace_window_push wpc {settings.max_rougness, gbuff.normal_row0, gbuff.normal_row1};
+    rec::compute(graph, "SSSR_trace", trace_windowed_pass,
+      {rec::sampled_mips(0, hiz, sampler, DEPTH, 0, mips), rec::sampled(1, gbuff.frame_normals, sampler), rec::sampled(2, gbuff.material, sampler),
+       rec::uniform(3, config), rec::uniform_buffer(4, halton_buffer), rec::storage(5, rays), rec::storage(6, ssr_occlusion),
+       rec::sampled(7, preintegrated_pdf, sampler), rec::storage(8, gbuff.pend_mask), rec::storage(9, gbuff.pend_data)},
+      rec::push(wpc), rec::Grid {rays, 8, 8, rec::Ceil});
+    return;
+  }
   rec::compute(graph, "SSSR_trace", trace_pass,
     {gbuff.tiled? rec::sampled_mips(0, hiz, sampler, DEPTH, 0, mips) : rec::sampled_mips(0, hiz, sampler, DEPTH, 1, mips - 1),
      rec::sampled(1, gbuff.tiled? gbuff.frame_normals : gbuff.downsampled_normals, sampler), rec::sampled(2, gbuff.material, sampler),

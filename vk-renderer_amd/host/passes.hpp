@@ -140,6 +140,13 @@ struct Gbuffer {
   rendergraph::ImageResourceId frame_normals;  // whole-frame downsampled_normals
   rendergraph::ImageResourceId frame_albedo;   // whole-frame albedo
   void enable_tiling(rendergraph::RenderGraph &graph, uint32_t full_width, uint32_t full_height);
+  // Hit normals by request / reply instead of gathered: frame_normals then only holds half-res frame rows
+  // [normal_row0, normal_row1) when the trace runs; the trace leaves the rays whose hit-normal footprint lies outside
+  // pending (pend_mask / pend_data: include/vkr_postfx.h vkr_sssr_trace_windowed) for vkr_sssr_validate.
+  bool normals_by_request = false;
+  uint32_t normal_row0 = 0, normal_row1 = 0;
+  rendergraph::ImageResourceId pend_mask, pend_data;
+  void enable_normal_requests(rendergraph::RenderGraph &graph, uint32_t row0, uint32_t row1);
 };
 
 struct DrawTAAParams {
@@ -434,6 +441,7 @@ private:
   rendergraph::ImageResourceId tile_planes;    // advanced_ssr.cpp:85-86: output of the regression pass (RGBA32F; never allocated here)
 
   gpu::ComputePipeline trace_pass;
+  gpu::ComputePipeline trace_windowed_pass;  // multi-GPU: hit normals by request (not in the reference)
   gpu::ComputePipeline filter_pass;
   gpu::ComputePipeline blur_pass;
   gpu::ComputePipeline preintegrate_pass;
