@@ -114,3 +114,104 @@ def test_exchange_entries_refuse_missing_arguments(lib):
         fn.restype = C.c_int
         assert fn(None, None, 0, None) == 0
         assert fn(None, None, 1, None) == ERR_NULL and b"NULL" in lib.vkr_last_error()
+
+
+# ---- the multi-GPU entries of round 3: hit colours / hit normals by request / reply, the windowed trace -----------------
+class HitSources(C.Structure):
+    _fields_ = [("rays", C.POINTER(abi.VkrImg)), ("albedo_width", C.c_uint32), ("albedo_height", C.c_uint32), ("window_row0", C.c_uint32),
+                ("window_row1", C.c_uint32), ("pending_mask", C.POINTER(abi.VkrImg)), ("pending_data", C.POINTER(abi.VkrImg)),
+                ("normal_width", C.c_uint32), ("normal_height", C.c_uint32), ("normal_row0", C.c_uint32), ("normal_row1", C.c_uint32)]
+
+
+def _hit_requests(lib, src, bounds, world, counts=FAKE, cursors=None, segments=None, out=None):
+    lib.vkr_hit_requests.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+    b = (C.c_uint32 * len(bounds))(*bounds)
+    seg = (C.c_uint32 * world)() if segments else None
+    rc = lib.vkr_hit_requests(C.byref(src) if src is not None else None, b, world, counts, cursors, seg, out, None)
+    return rc, (lib.vkr_last_error() or b"").decode()
+
+
+def test_hit_requests_refuse_inconsistent_strips(lib):
+    rays = img(abi.FMT_RGBA16_UNORM, 128, 64, full=(128, 256), origin=(0, 32))
+    src = HitSources(C.pointer(rays), 256, 512, 64, 192, None, None, 0, 0, 0, 0)
+    rc, msg = _hit_requests(lib, None, [0, 256, 512], 2)
+    assert rc == ERR_NULL
+    rc, msg = _hit_requests(lib, src, [0, 256, 512], 17)
+    assert rc == ERR_EXTENT and "world 17" in msg
+    rc, msg = _hit_requests(lib, src, [0, 256, 500], 2)          # bounds must end at the frame height
+    assert rc == ERR_EXTENT and "bounds" in msg
+    rc, msg = _hit_requests(lib, src, [0, 255, 512], 2)          # strips are cut at even rows
+    assert rc == ERR_EXTENT and "even" in msg
+    rc, msg = _hit_requests(lib, src, [0, 256, 512], 2, counts=None)  # pass 1 needs the counters
+    assert rc == ERR_NULL
+    rc, msg = _hit_requests(lib, src, [0, 256, 512], 2, out=FAKE)     # pass 2 needs cursors and segments
+    assert rc == ERR_NULL
+    big = HitSources(C.pointer(rays), 32768, 512, 64, 192, None, None, 0, 0, 0, 0)
+    rc, msg = _hit_requests(lib, big, [0, 256, 512], 2)
+    assert rc == ERR_EXTENT and "14 bits" in msg
+    # pending images that do not match the rays
+    mask = img(abi.FMT_R8_UNORM, 64, 64)
+    data = img(abi.FMT_RGBA32_SFLOAT, 256, 64)
+    bad = HitSources(C.pointer(rays), 256, 512, 64, 192, C.pointer(mask), C.pointer(data), 128, 256, 32, 96)
+    rc, msg = _hit_requests(lib, bad, [0, 256, 512], 2)
+    assert rc == ERR_EXTENT and "pending" in msg
+
+
+def test_hit_reply_and_scatter_validate_their_images(lib):
+    lib.vkr_hit_reply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vkr_hit_scatter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    albedo = img(abi.FMT_RGBA8_SRGB, 256, 128, full=(256, 512), origin=(0, 64))
+    assert lib.vkr_hit_reply(C.byref(albedo), None, None, 0, None, None, None) == 0            # nothing to answer
+    assert lib.vkr_hit_reply(C.byref(albedo), None, None, 4, FAKE, FAKE, None) == ERR_NULL     # requests missing
+    wrong = img(abi.FMT_RGBA8_UNORM, 256, 128)
+    assert lib.vkr_hit_reply(C.byref(wrong), None, FAKE, 4, FAKE, FAKE, None) == ERR_FORMAT
+    # the scatter target is the WHOLE-frame image
+    assert lib.vkr_hit_scatter(C.byref(albedo), None, FAKE, FAKE, 4, None) == ERR_EXTENT
+    assert "whole-frame" in (lib.vkr_last_error() or b"").decode()
+
+
+def test_windowed_trace_and_validate_refuse_bad_windows(lib):
+    class WindowPush(C.Structure):
+        _fields_ = [("max_roughness", C.c_float), ("normal_row0", C.c_uint32), ("normal_row1", C.c_uint32)]
+
+    lib.vkr_sssr_trace_windowed.argtypes = [C.c_void_p] * 12
+    lib.vkr_sssr_validate.argtypes = [C.c_void_p] * 6
+    w2, h2, fh = 128, 64, 256
+    depth = img(abi.FMT_D24_UNORM_S8, 128, fh, mips=3)
+    normal = img(abi.FMT_RG16_UNORM, 128, fh)
+    material = img(abi.FMT_RGBA8_SRGB, 256, 128, full=(256, 512), origin=(0, 64))
+    rays = img(abi.FMT_RGBA16_UNORM, w2, h2, full=(128, fh), origin=(0, 32))
+    occ = img(abi.FMT_RGBA16_SFLOAT, w2, h2, full=(128, fh), origin=(0, 32))
+    pdf = img(abi.FMT_R32_SFLOAT, 1024, 1024)
+    mask = img(abi.FMT_R8_UNORM, w2, h2, full=(128, fh), origin=(0, 32))
+    data = img(abi.FMT_RGBA32_SFLOAT, 2 * w2, h2)
+    params = abi.TraceParams()
+    halton = (C.c_float * (4 * 128 + 4))()
+    hp = (C.addressof(halton) + 15) & ~15
+
+    def call(push, n=normal, m=mask, d=data):
+        return lib.vkr_sssr_trace_windowed(C.byref(depth), C.byref(n), C.byref(material), C.byref(params), hp, C.byref(rays), C.byref(occ),
+                                           C.byref(pdf), C.byref(m), C.byref(d), C.byref(push) if push is not None else None, None)
+
+    assert call(None) == ERR_NULL
+    assert call(WindowPush(1.0, 96, 32)) == ERR_EXTENT                      # rows must be a range inside the frame
+    assert call(WindowPush(1.0, 32, fh + 1)) == ERR_EXTENT
+    windowed_normals = img(abi.FMT_RG16_UNORM, 128, 64, full=(128, fh), origin=(0, 32))
+    assert call(WindowPush(1.0, 32, 96), n=windowed_normals) == ERR_EXTENT  # `normal` must be the whole-frame image
+    assert "whole-frame" in (lib.vkr_last_error() or b"").decode()
+    assert call(WindowPush(1.0, 32, 96), d=img(abi.FMT_RGBA32_SFLOAT, w2, h2)) == ERR_EXTENT
+    assert call(WindowPush(1.0, 32, 96), m=img(abi.FMT_RG16_UNORM, w2, h2)) == ERR_FORMAT
+    assert lib.vkr_sssr_validate(C.byref(rays), C.byref(mask), C.byref(data), C.byref(normal), None, None) == ERR_NULL
+    assert lib.vkr_sssr_validate(C.byref(rays), C.byref(mask), C.byref(img(abi.FMT_RGBA32_SFLOAT, w2, h2)), C.byref(normal), C.byref(params), None) == ERR_EXTENT
+
+
+def test_comm_entries_refuse_null(lib):
+    lib.vkr_comm_selfcheck.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vkr_comm_selfcheck_bytes.argtypes = [C.c_int]
+    lib.vkr_comm_selfcheck_bytes.restype = C.c_uint64
+    assert lib.vkr_comm_selfcheck(None, None, None) == ERR_NULL
+    assert lib.vkr_comm_selfcheck_bytes(8) > lib.vkr_comm_selfcheck_bytes(2) > 0
+    before = lib.vkr_get_switches()
+    lib.vkr_set_switches(abi.SWITCH_BLUR_NO_SKIP | abi.SWITCH_TAA_GENERIC)
+    assert lib.vkr_get_switches() == abi.SWITCH_BLUR_NO_SKIP | abi.SWITCH_TAA_GENERIC
+    lib.vkr_set_switches(before)

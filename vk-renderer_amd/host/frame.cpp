@@ -432,7 +432,9 @@ struct TiledFrame {
 
   // ---- hit colours by request / reply (frame.hpp; csrc/hit_exchange.hip) ------------------------------------------------
   struct HitState {
-    uint32_t* counts = nullptr;     // device: [world] counts, [world] cursors, [1] reply errors, [world * world] gathered matrix
+    // device, every part 64-byte aligned (RCCL moves the counts): counts @0, cursors @HIT_CURSORS, reply errors @HIT_ERRORS,
+    // the gathered world x world matrix @HIT_MATRIX
+    uint32_t* counts = nullptr;
     uint32_t* host_counts = nullptr;  // pinned: world * world + 1
     vkr_hit_request* req_out = nullptr; uint8_t* reply_in = nullptr; uint64_t cap_out = 0;   // what I ask / get back
     vkr_hit_request* req_in = nullptr; uint8_t* reply_out = nullptr; uint64_t cap_in = 0;    // what I am asked / answer
@@ -462,7 +464,8 @@ struct TiledFrame {
   vkr_img frame_albedo_img() { return frame->graph.get_image(frame->gbuffer.frame_albedo)->describe(0, 1); }
   void hit_init() {
     const uint32_t w = cfg.world;
-    hit.counts = (uint32_t*)gpu::device_alloc(sizeof(uint32_t) * (2 * w + 1 + w * w));
+    if (w > 16) throw std::runtime_error {"tiled frame: the request / reply exchange is laid out for at most 16 ranks"};
+    hit.counts = (uint32_t*)gpu::device_alloc(sizeof(uint32_t) * HIT_WORDS);
     check(hipHostMalloc((void**)&hit.host_counts, sizeof(uint32_t) * (w * w + 1), hipHostMallocDefault), "pinned counts");
     hit.out_seg.assign(w + 1, 0); hit.in_seg.assign(w + 1, 0);
     // room for what this rank can ask for — every ray of its window ending on another strip — and the same for what it
@@ -495,7 +498,7 @@ struct TiledFrame {
   // pass 1, on the compute stream right after the trace
   void hit_count() {
     const uint32_t w = cfg.world;
-    check(hipMemsetAsync(hit.counts, 0, sizeof(uint32_t) * (2 * w + 1), compute), "memset");
+    check(hipMemsetAsync(hit.counts, 0, sizeof(uint32_t) * HIT_MATRIX, compute), "memset");
     HitSources h;
     hit_sources(h);
     if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, nullptr, nullptr, nullptr, compute) != 0)
@@ -537,7 +540,7 @@ struct TiledFrame {
     if (hit.out_seg[w]) {
       HitSources h;
       hit_sources(h);
-      if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, hit.counts + w, hit.out_seg.data(), hit.req_out, s) != 0)
+      if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, hit.counts + HIT_CURSORS, hit.out_seg.data(), hit.req_out, s) != 0)
         throw std::runtime_error {std::string {"hit_requests: "} + vkr_last_error()};
     }
     uint32_t n = 0;
@@ -554,7 +557,7 @@ struct TiledFrame {
   uint32_t hit_reply(hipStream_t s, vkr_halo_peer* peers) {
     const uint32_t w = cfg.world, me = cfg.rank;
     const vkr_img a = albedo_img(), dn = dn_img();
-    if (vkr_hit_reply(&a, normals_by_request() ? &dn : nullptr, hit.req_in, hit.in_seg[w], hit.reply_out, hit.counts + 2 * w, s) != 0)
+    if (vkr_hit_reply(&a, normals_by_request() ? &dn : nullptr, hit.req_in, hit.in_seg[w], hit.reply_out, hit.counts + HIT_ERRORS, s) != 0)
       throw std::runtime_error {std::string {"hit_reply: "} + vkr_last_error()};
     uint32_t n = 0;
     for (uint32_t p = 0; p < w; p++) {
@@ -582,9 +585,9 @@ struct TiledFrame {
     const uint32_t w = cfg.world;
     check(hipEventRecord(ev_ready[VKRH_GATHER_ALBEDO], compute), "event record");  // NOTE: recorded by the caller's order: after the count pass
     check(hipStreamWaitEvent(xchg, ev_ready[VKRH_GATHER_ALBEDO], 0), "stream wait");
-    const vkr_gather_part part {hit.counts, hit.counts + 2 * w + 1, uint64_t(w) * sizeof(uint32_t)};
+    const vkr_gather_part part {hit.counts, hit.counts + HIT_MATRIX, uint64_t(w) * sizeof(uint32_t)};
     if (vkr_all_gather(cfg.comm, &part, 1, xchg) != 0) throw std::runtime_error {std::string {"exchange: "} + vkr_last_error()};
-    check(hipMemcpyAsync(hit.host_counts, hit.counts + 2 * w + 1, sizeof(uint32_t) * w * w, hipMemcpyDeviceToHost, xchg), "counts to host");
+    check(hipMemcpyAsync(hit.host_counts, hit.counts + HIT_MATRIX, sizeof(uint32_t) * w * w, hipMemcpyDeviceToHost, xchg), "counts to host");
     hit_pending = true;
   }
   bool hit_pending = false;
@@ -602,6 +605,7 @@ struct TiledFrame {
     check(hipEventRecord(ev_done[VKRH_GATHER_ALBEDO], xchg), "event record");
   }
   static constexpr uint32_t HIT_PEERS = 16;
+  static constexpr uint32_t HIT_CURSORS = 16, HIT_ERRORS = 32, HIT_MATRIX = 64, HIT_WORDS = 64 + 256;  // world <= 16
 
   // ---- the frame, in phases (an exchange may only start / must be complete at a phase boundary) ------------------------
   void phase(uint32_t p) {
@@ -987,7 +991,7 @@ int vkrh_tiled_hit_errors(void* tiled, uint32_t* errors) {
     auto* t = (TiledFrame*)tiled;
     if (!t || !errors || !t->by_request()) throw std::runtime_error{"vkrh_tiled_hit_errors: not a tiled frame with hit-colour requests"};
     TiledFrame::check(hipDeviceSynchronize(), "synchronize");
-    TiledFrame::check(hipMemcpy(errors, t->hit.counts + 2 * t->cfg.world, sizeof(uint32_t), hipMemcpyDeviceToHost), "errors");
+    TiledFrame::check(hipMemcpy(errors, t->hit.counts + TiledFrame::HIT_ERRORS, sizeof(uint32_t), hipMemcpyDeviceToHost), "errors");
   });
 }
 int vkrh_tiled_hit_bytes(void* tiled, uint64_t* bytes) {
