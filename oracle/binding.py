@@ -63,6 +63,31 @@ class OracleBackend:
     def set_gather_mips(self, n):
         self.gather_mips = n
 
+    # hit colours / hit normals by request / reply (tiling.TiledFrame gather_mode 0 / 2): the flat chain's twins of the C-ABI
+    windowed = False  # set by the tiling driver: the trace leaves rays that end on another rank's rows pending
+
+    def local_rows(self, normals):
+        """own window rows into the whole-frame images (what the all-gather would have put there)"""
+        c = self.chain
+        for src, dst in ((c.albedo, c.frame_albedo),) + (((c.dn, c.frame_normals),) if normals else ()):
+            assert src.pitch[0] == dst.pitch[0]
+            o = src.origin[1] * dst.pitch[0]
+            dst.host[o: o + src.height * src.pitch[0]] = src.host[: src.height * src.pitch[0]]
+
+    def hit_count(self, bounds, normals):
+        return self.chain.hit_count(bounds, normals)
+
+    def hit_write(self, bounds, counts, normals):
+        return self.chain.hit_write(bounds, counts, normals)
+
+    def hit_reply(self, requests, count, normals):
+        return self.chain.hit_reply(requests, count, normals)
+
+    def hit_scatter(self, requests, replies, count, normals):
+        self.chain.hit_scatter(requests, replies, count, normals)
+        if normals:
+            self.chain.ssr_validate()
+
     def rows(self, name, mip=0):
         img = getattr(self.chain, name)
         h, w = mip_extent(img.height, mip), mip_extent(img.width, mip)
@@ -85,7 +110,10 @@ class OracleBackend:
         elif stage == "trace":
             if c.tiled:
                 c.hiz_tail(self.gather_mips)
-            c.ssr_trace(frame_random=c.frame_index % 16)
+            if self.windowed:
+                c.ssr_trace_windowed(frame_random=c.frame_index % 16)
+            else:
+                c.ssr_trace(frame_random=c.frame_index % 16)
         elif stage == "gtao":
             c.gtao_main()
             c.gtao_filter()

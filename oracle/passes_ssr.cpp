@@ -126,11 +126,14 @@ vec3 hierarchical_raymarch_find_hor(const TraceCtx& c, vec3 origin, vec3 directi
 
 extern "C" void vkr_ref_set_step_sink(uint8_t* sink, int pitch_bytes) { g_step_sink = sink; g_step_sink_pitch = pitch_bytes; }
 
-// trace.comp:41-141
-extern "C" int vkr_ref_sssr_trace(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
-                                  const vkr_trace_params* params, const float* halton_vec4,
-                                  const vkr_img* out_ray, const vkr_img* out_occlusion, const vkr_img* pdf_tex,
-                                  const vkr_trace_push* push) {
+// trace.comp:41-141.  window != NULL: the multi-GPU variant (include/vkr_postfx.h vkr_sssr_trace_windowed) — the same
+// conjunction of validity tests, with the hit-normal test of a ray whose footprint rows are not all inside
+// [normal_row0, normal_row1) deferred to vkr_ref_sssr_validate.
+static int trace_impl(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                      const vkr_trace_params* params, const float* halton_vec4,
+                      const vkr_img* out_ray, const vkr_img* out_occlusion, const vkr_img* pdf_tex,
+                      const vkr_trace_push* push, const vkr_trace_window_push* window, const vkr_img* pending_mask,
+                      const vkr_img* pending_data) {
   Image DEPTH(*depth), NORMAL(*normal), MATERIAL(*material), OUT_RAY(*out_ray), OUT_OCC(*out_occlusion), PDF_TEX(*pdf_tex);
   const vkr_trace_params& p = *params;
   mat4 normal_mat;
@@ -188,16 +191,38 @@ extern "C" int vkr_ref_sssr_trace(const vkr_img* depth, const vkr_img* normal, c
         vec2 ray_step = abs(out_r.xy() - ray_start.xy()) * tex_size;
         if (max(ray_step.x, ray_step.y) < 2.0f) valid_hit = false;
       }
-      if (valid_hit) {
-        vec3 hit_normal_world = sample_gbuffer_normal(NORMAL, out_r.xy());
-        vec3 hit_normal = (normal_mat * vec4(hit_normal_world, 0.0f)).xyz();
-        if (dot(hit_normal, R) > 0.0f || dot(pixel_normal, R) < 0.0f) valid_hit = false;
-      }
-      if (valid_hit) {
+      auto depth_test = [&]() {
         float hit_depth = DEPTH.sample(out_r.xy(), 0).x;
         float hit_z = linearize_depth2(hit_depth, p.znear, p.zfar);
         float ray_z = linearize_depth2(out_r.z, p.znear, p.zfar);
-        if (ray_z > hit_z + 0.3f || ray_z < hit_z - 0.1f) valid_hit = false;
+        return !(ray_z > hit_z + 0.3f || ray_z < hit_z - 0.1f);
+      };
+      auto hit_normal_faces_ray = [&]() {
+        vec3 hit_normal_world = sample_gbuffer_normal(NORMAL, out_r.xy());
+        vec3 hit_normal = (normal_mat * vec4(hit_normal_world, 0.0f)).xyz();
+        return !(dot(hit_normal, R) > 0.0f);
+      };
+      if (!window) {
+        if (valid_hit && (!hit_normal_faces_ray() || dot(pixel_normal, R) < 0.0f)) valid_hit = false;
+        if (valid_hit && !depth_test()) valid_hit = false;
+      } else {
+        if (valid_hit && dot(pixel_normal, R) < 0.0f) valid_hit = false;
+        if (valid_hit && !depth_test()) valid_hit = false;
+        bool pending = false;
+        if (valid_hit) {
+          const int nfh = NORMAL.fh();
+          const int y0 = f2i(floorf(cfma(out_r.y, (float)nfh, -0.5f)));
+          const int r0 = clamp(y0, 0, nfh - 1), r1 = clamp(y0 + 1, 0, nfh - 1);
+          pending = r0 < (int)window->normal_row0 || r1 >= (int)window->normal_row1;
+          if (!pending) {
+            if (!hit_normal_faces_ray()) valid_hit = false;
+          } else {
+            float* pd = (float*)Image(*pending_data).texel_ptr(2 * lx, ly, 0);
+            pd[0] = R.x; pd[1] = R.y; pd[2] = R.z; pd[3] = 0.0f;
+            pd[4] = out_r.x; pd[5] = out_r.y; pd[6] = 0.0f; pd[7] = 0.0f;
+          }
+        }
+        *Image(*pending_mask).texel_ptr(lx, ly, 0) = pending ? 1 : 0;
       }
       OUT_RAY.store(gx, gy, vec4(out_r, valid_hit ? pixel_depth : 1.0f));
 
@@ -217,6 +242,41 @@ extern "C" int vkr_ref_sssr_trace(const vkr_img* depth, const vkr_img* normal, c
       }
     }
   }
+  return 0;
+}
+
+extern "C" int vkr_ref_sssr_trace(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                                  const vkr_trace_params* params, const float* halton_vec4,
+                                  const vkr_img* out_ray, const vkr_img* out_occlusion, const vkr_img* pdf_tex,
+                                  const vkr_trace_push* push) {
+  return trace_impl(depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, push, nullptr, nullptr, nullptr);
+}
+
+extern "C" int vkr_ref_sssr_trace_windowed(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                                           const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                                           const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_img* pending_mask,
+                                           const vkr_img* pending_data, const vkr_trace_window_push* push) {
+  const vkr_trace_push base {push->max_roughness};
+  return trace_impl(depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, &base, push, pending_mask, pending_data);
+}
+
+// the deferred hit-normal test (trace.comp:103-109) of the pending rays
+extern "C" int vkr_ref_sssr_validate(const vkr_img* rays, const vkr_img* pending_mask, const vkr_img* pending_data, const vkr_img* frame_normals,
+                                     const vkr_trace_params* params) {
+  Image RAYS(*rays), MASK(*pending_mask), DATA(*pending_data), NORMAL(*frame_normals);
+  mat4 normal_mat;
+  std::memcpy(normal_mat.m, params->normal_mat.m, 64);
+  for (int ly = 0; ly < RAYS.h(); ly++)
+    for (int lx = 0; lx < RAYS.w(); lx++) {
+      if (*MASK.texel_ptr(lx, ly, 0) == 0) continue;
+      const float* pd = (const float*)DATA.texel_ptr(2 * lx, ly, 0);
+      vec3 hit_normal_world = sample_gbuffer_normal(NORMAL, vec2(pd[4], pd[5]));
+      vec3 hit_normal = (normal_mat * vec4(hit_normal_world, 0.0f)).xyz();
+      if (dot(hit_normal, vec3(pd[0], pd[1], pd[2])) > 0.0f) {
+        uint16_t one = 0xFFFFu;
+        std::memcpy(RAYS.texel_ptr(lx, ly, 0) + 6, &one, 2);
+      }
+    }
   return 0;
 }
 

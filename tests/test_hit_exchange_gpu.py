@@ -1,0 +1,114 @@
+"""The multi-GPU entries of round 3, kernel by kernel against their oracle twins on one GPU: vkr_sssr_trace_windowed,
+vkr_hit_requests (both passes), vkr_hit_reply, vkr_hit_scatter, vkr_sssr_validate (csrc/hit_exchange.hip, csrc/ssr.hip vs
+oracle/passes_hit.cpp, oracle/passes_ssr.cpp).  One frame cut into two strips; the lower strip's window is traced with only
+its own rows of the downsampled normals in memory, asks the upper strip for what it lacks, and must end with the rays the
+plain trace stores.  Requests are an unordered set per owner on the GPU (block-aggregated atomics): compared sorted."""
+import numpy as np
+import pytest
+
+from vk_renderer_amd import abi
+from vk_renderer_amd.camera import FrameSetup
+from vk_renderer_amd.chain import PostFxChain
+
+from parity import mismatches
+
+pytestmark = pytest.mark.gpu
+
+W, H, HALO = 256, 320, 48
+BOUNDS = [0, 160, 320]
+
+
+def _window(rank):
+    y0, y1 = BOUNDS[rank], BOUNDS[rank + 1]
+    wy0, wy1 = max(0, y0 - HALO), min(H, y1 + HALO)
+    return (0, wy0, W, wy1 - wy0)
+
+
+def _chains(backend, device):
+    setup = FrameSetup(W, H)
+    plain = PostFxChain(W, H, backend=backend, device=device, setup=setup)
+    ranks = [PostFxChain(W, H, backend=backend, device=device, setup=setup, window=_window(r), force_tiled=True) for r in range(2)]
+    for c in [plain] + ranks:
+        c.synth(); c.build_prev_hiz(); c.init_histories(); c.preintegrate_pdf(); c.downsample()
+    plain.ssr_trace(frame_random=0)
+    for c in ranks:  # the gathered pyramid: whole-frame image mips 1..L-1
+        for m in range(c.frame_hiz.mips):
+            src = plain.depth
+            h = max(1, (H // 2) >> m)
+            a = src.to_host()[src.offset[m + 1]: src.offset[m + 1] + src.pitch[m + 1] * h]
+            dst = c.frame_hiz
+            assert src.pitch[m + 1] == dst.pitch[m]
+            host = dst.to_host().copy()
+            host[dst.offset[m]: dst.offset[m] + dst.pitch[m] * h] = a
+            dst.upload(host)
+        c.hiz_tail(4)
+        for src, dst in ((c.albedo, c.frame_albedo), (c.dn, c.frame_normals)):  # own rows only
+            host = np.full(dst.nbytes, 0xA5, dtype=np.uint8)  # poison: a texel nobody delivers shows
+            o = src.origin[1] * dst.pitch[0]
+            host[o: o + src.height * src.pitch[0]] = src.to_host()[: src.height * src.pitch[0]]
+            dst.upload(host)
+    return plain, ranks
+
+
+def test_windowed_trace_requests_replies_scatter_validate(oracle_lib):
+    import torch
+
+    assert torch.cuda.is_available()
+    rp, rr = _chains("oracle", None)
+    gp, gr = _chains("product", "cuda")
+    lower_r, lower_g, upper_r, upper_g = rr[1], gr[1], rr[0], gr[0]
+    # 1. windowed trace: rays (provisional), mask, pending data
+    for c in (lower_r, lower_g):
+        c.ssr_trace_windowed(frame_random=0)
+    lower_g.sync()
+    assert np.array_equal(lower_g.rays.raw(0), lower_r.rays.raw(0)), "windowed trace: rays differ"
+    bad = int(mismatches(lower_r.raw.format, lower_g.raw.decode(0), lower_r.raw.decode(0)).sum())  # smooth terms: the usual tolerance
+    assert bad <= 8, f"windowed trace: (occlusion, pdf): {bad} texels outside tolerance"
+    mask_g, mask_r = lower_g.pend_mask.raw(0)[..., 0].astype(bool), lower_r.pend_mask.raw(0)[..., 0].astype(bool)
+    assert np.array_equal(mask_g, mask_r) and mask_r.sum() > 0, f"pending masks differ / empty ({mask_r.sum()})"
+
+    def pend(c):
+        d = c.pend_data
+        rows = d.to_host()[: d.pitch[0] * d.height].reshape(d.height, d.pitch[0])[:, : d.width * 16]
+        return np.ascontiguousarray(rows).view(np.float32).reshape(d.height, d.width // 2, 8)
+
+    pg, pr = pend(lower_g), pend(lower_r)
+    assert np.array_equal(pg[mask_r][:, [0, 1, 2, 4, 5]], pr[mask_r][:, [0, 1, 2, 4, 5]]), "pending R / hit uv differ"
+    # 2. requests: counts, then the set per owner
+    cg, cr = lower_g.hit_count(BOUNDS), lower_r.hit_count(BOUNDS)
+    assert cg == cr and cr[0] > 0 and cr[1] == 0, (cg, cr)
+    qg, seg_g = lower_g.hit_write(BOUNDS, cg)
+    qr, seg_r = lower_r.hit_write(BOUNDS, cr)
+    qg_h, qr_h = lower_g.buffer_to_host(qg).view(np.uint32)[: seg_g[-1]], np.asarray(qr, dtype=np.uint32)[: seg_r[-1]]
+    assert seg_g == seg_r and np.array_equal(np.sort(qg_h), np.sort(qr_h)), "request sets differ"
+    assert (qr_h & abi.HIT_NORMAL).any() and (~qr_h & abi.HIT_NORMAL).any(), "both surfaces are asked for"
+    assert (qr_h & abi.HIT_BOTH_ROWS).any()
+    # 3. replies from the upper strip's window, on the same (sorted) request list
+    order = np.sort(qr_h)
+    n = int(order.size)
+    rep_r, err_r = upper_r.hit_reply(order.copy(), n)
+    q_dev = torch.from_numpy(order.view(np.int32).copy()).cuda()
+    rep_g, err_g = upper_g.hit_reply(q_dev, n)
+    assert err_r == 0 and err_g == 0
+    rep_g_h, rep_r_h = upper_g.buffer_to_host(rep_g).view(np.uint32)[: 4 * n], np.asarray(rep_r, dtype=np.uint32)[: 4 * n]
+    assert np.array_equal(rep_g_h, rep_r_h), "replies differ"
+    # 4. scatter + deferred hit-normal test: the rays of the plain trace, and the requested texels in the frame images
+    lower_r.hit_scatter(order.copy(), rep_r_h.copy(), n)
+    lower_r.ssr_validate()
+    lower_g.hit_scatter(q_dev, torch.from_numpy(rep_g_h.view(np.int32).copy()).cuda(), n)
+    lower_g.ssr_validate()
+    lower_g.sync()
+    oy = lower_r.rays.origin[1]
+    want = rp.rays.raw(0)[oy: oy + lower_r.rays.height]
+    assert np.array_equal(lower_r.rays.raw(0), want), "oracle: validated rays differ from the plain trace"
+    assert np.array_equal(lower_g.rays.raw(0), want), "product: validated rays differ from the plain trace"
+    for name in ("frame_albedo", "frame_normals"):
+        assert np.array_equal(getattr(lower_g, name).raw(0), getattr(lower_r, name).raw(0)), f"{name} differs after the scatter"
+    # every texel the filter then reads was delivered: reflections equal the plain frame's on the strip's interior
+    for c in (lower_r, lower_g, rp):
+        c.ssr_filter()
+    lower_g.sync()
+    y0 = BOUNDS[1] // 2
+    a = lower_g.reflections.raw(0)[y0 - oy:], lower_r.reflections.raw(0)[y0 - oy:]
+    b = rp.reflections.raw(0)[y0:]
+    assert np.array_equal(a[1], b) and np.array_equal(a[0], b), "reflections of the strip differ from the plain frame"

@@ -26,7 +26,9 @@ WORKER = textwrap.dedent("""
     cols, rows = (int(v) for v in os.environ['VKR_GRID'].split('x'))
     W, H = 128 * cols, int(os.environ.get('VKR_TILE_H', '144')) * rows
     setup = FrameSetup(W, H)
-    t = TiledFrame(setup, rank, world, cols, rows, None, backend=binding.OracleBackend, halo=48)
+    mode = int(os.environ.get('VKR_GATHER_MODE', '1'))
+    t = TiledFrame(setup, rank, world, cols, rows, None, backend=binding.OracleBackend, halo=48, gather_mode=mode)
+    assert t.gather_mode == mode
     assert t.gather_mips == int(os.environ.get('VKR_EXPECT_GATHER', '4')), t.gather_mips
     t.prepare()
     for _ in range(3):  # the third frame reuses the exchange plans cached for the first (ping-pong parity)
@@ -48,6 +50,11 @@ WORKER = textwrap.dedent("""
         if n:
             print(f'rank {rank} {name}: {n} differing bytes')
         bad += n
+    if mode != 1:  # hit colours (and, mode 0, hit normals) by request / reply: the exchange did carry something
+        m = t.hit_matrix
+        assert sum(sum(row) for row in m) > 0 and all(m[r][r] == 0 for r in range(world)), m
+        if mode == 0:
+            assert int(c.pend_mask.raw(0).astype(bool).sum()) >= 0
     # the gathered whole-frame pyramid equals the single-process pyramid (image mips 1..L-1)
     for m in range(c.frame_hiz.mips):
         n = int((c.frame_hiz.raw(m) != (ref.depth.raw(m + 1) & 0xFFFFFF)).sum())
@@ -75,6 +82,21 @@ def test_tiled_frame_matches_single_process(grid, tile_h, gather, tmp_path, orac
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, OMP_NUM_THREADS="2", VKR_GRID=grid, VKR_TILE_H=str(tile_h), VKR_EXPECT_GATHER=str(gather))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("world,mode", [(2, 0), (4, 0), (2, 2)])
+def test_request_reply_exchange_matches_single_process(world, mode, tmp_path, oracle_lib):
+    """Hit colours and hit normals by request / reply (include/vkr_postfx.h vkr_hit_*, vkr_sssr_trace_windowed, vkr_sssr_validate)
+    between real processes over gloo, on the oracle's twins of those entries: the albedo (mode 2) or the albedo and the
+    downsampled normals (mode 0) are NOT gathered — every rank asks the owners for the footprint rows it lacks — and the tile
+    interiors must still equal the single-process frame bit for bit after three frames."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, OMP_NUM_THREADS="2", VKR_GRID=f"1x{world}", VKR_TILE_H="144", VKR_EXPECT_GATHER="4", VKR_GATHER_MODE=str(mode))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

@@ -188,6 +188,19 @@ class SynthParams(C.Structure):
 P = C.POINTER
 _IMG = P(VkrImg)
 
+
+class TraceWindowPush(C.Structure):  # vkr_trace_window_push
+    _fields_ = [("max_roughness", C.c_float), ("normal_row0", C.c_uint32), ("normal_row1", C.c_uint32)]
+
+
+class HitSources(C.Structure):  # vkr_hit_sources
+    _fields_ = [("rays", _IMG), ("albedo_width", C.c_uint32), ("albedo_height", C.c_uint32), ("window_row0", C.c_uint32),
+                ("window_row1", C.c_uint32), ("pending_mask", _IMG), ("pending_data", _IMG),
+                ("normal_width", C.c_uint32), ("normal_height", C.c_uint32), ("normal_row0", C.c_uint32), ("normal_row1", C.c_uint32)]
+
+
+HIT_BOTH_ROWS, HIT_NORMAL, HIT_REPLY_BYTES = 0x10000000, 0x20000000, 16
+
 # name -> argument types *without* the trailing stream
 ENTRY_ARGS = {
     "downsample_gbuffer": [_IMG, _IMG, _IMG, _IMG, _IMG],
@@ -219,6 +232,12 @@ ENTRY_ARGS = {
     "screen_trace_main": [_IMG, _IMG, _IMG, _IMG, _IMG, P(ScreenTraceParams)],
     "screen_trace_filter": [_IMG, _IMG, _IMG, P(ScreenTraceFilterPush)],
     "screen_trace_accumulate": [_IMG, _IMG, _IMG, _IMG, P(ScreenTraceAccumPush)],
+    # multi-GPU: hit colours / hit normals by request / reply (no reference counterpart)
+    "sssr_trace_windowed": [_IMG, _IMG, _IMG, P(TraceParams), C.c_void_p, _IMG, _IMG, _IMG, _IMG, _IMG, P(TraceWindowPush)],
+    "sssr_validate": [_IMG, _IMG, _IMG, _IMG, P(TraceParams)],
+    "hit_requests": [P(HitSources), P(C.c_uint32), C.c_uint32, C.c_void_p, C.c_void_p, P(C.c_uint32), C.c_void_p],
+    "hit_reply": [_IMG, _IMG, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p],
+    "hit_scatter": [_IMG, _IMG, C.c_void_p, C.c_void_p, C.c_uint32],
 }
 
 

@@ -196,10 +196,12 @@ class PostFxChain:
 
     def build_prev_hiz(self):
         """prev_depth's mips: what last frame's DownsamplePass left in the image that is now prev_depth (main.cpp:416)."""
-        scratch_n = ImageBuf(abi.FMT_RG16_UNORM, self.dn.width, self.dn.height, device=self.device)
-        scratch_v = ImageBuf(abi.FMT_RG16_SFLOAT, self.dn.width, self.dn.height, device=self.device)
-        n0 = ImageBuf(abi.FMT_RG16_UNORM, self.normal.width, self.normal.height, device=self.device)
-        v0 = ImageBuf(abi.FMT_RG16_SFLOAT, self.normal.width, self.normal.height, device=self.device)
+        half = dict(device=self.device, full=self.dn.full, origin=self.dn.origin)       # the window's geometry (tiled chains)
+        full = dict(device=self.device, full=self.normal.full, origin=self.normal.origin)
+        scratch_n = ImageBuf(abi.FMT_RG16_UNORM, self.dn.width, self.dn.height, **half)
+        scratch_v = ImageBuf(abi.FMT_RG16_SFLOAT, self.dn.width, self.dn.height, **half)
+        n0 = ImageBuf(abi.FMT_RG16_UNORM, self.normal.width, self.normal.height, **full)
+        v0 = ImageBuf(abi.FMT_RG16_SFLOAT, self.normal.width, self.normal.height, **full)
         self.call("downsample_gbuffer", C.byref(self.prev_depth.desc()), C.byref(n0.desc()), C.byref(v0.desc()),
                   C.byref(scratch_n.desc()), C.byref(scratch_v.desc()))
         self.call("depth_mips", C.byref(self.prev_depth.desc()), 1)
@@ -242,6 +244,85 @@ class PostFxChain:
         self.call("sssr_trace", C.byref(hiz), C.byref(dn),
                   C.byref(self.material.desc()), C.byref(tp), self._halton_ptr(), C.byref(self.rays.desc()),
                   C.byref(self.raw.desc()), C.byref(self.pdf.desc()), C.byref(push))
+
+    # ---- multi-GPU: hit colours / hit normals by request / reply (include/vkr_postfx.h; no reference counterpart) ----
+    def _pending_images(self):
+        if not hasattr(self, "pend_mask"):
+            r = self.rays
+            self.pend_mask = ImageBuf(abi.FMT_R8_UNORM, r.width, r.height, device=self.device, full=r.full, origin=r.origin)
+            self.pend_data = ImageBuf(abi.FMT_RGBA32_SFLOAT, 2 * r.width, r.height, device=self.device)
+        return self.pend_mask, self.pend_data
+
+    def ssr_trace_windowed(self, frame_random=None, max_roughness=1.0):
+        """vkr_sssr_trace_windowed: frame_normals holds only this window's rows; rays whose hit-normal footprint leaves them
+        stay pending (pend_mask / pend_data) for ssr_validate()."""
+        assert self.tiled
+        mask, data = self._pending_images()
+        tp = self.setup.trace_params(frame_random)
+        oy, h2 = self.dn.origin[1], self.dn.height
+        push = abi.TraceWindowPush(max_roughness, oy, oy + h2)
+        self.call("sssr_trace_windowed", C.byref(self.frame_hiz.desc()), C.byref(self.frame_normals.desc()), C.byref(self.material.desc()),
+                  C.byref(tp), self._halton_ptr(), C.byref(self.rays.desc()), C.byref(self.raw.desc()), C.byref(self.pdf.desc()),
+                  C.byref(mask.desc()), C.byref(data.desc()), C.byref(push))
+
+    def ssr_validate(self):
+        mask, data = self._pending_images()
+        tp = self.setup.trace_params()
+        self.call("sssr_validate", C.byref(self.rays.desc()), C.byref(mask.desc()), C.byref(data.desc()), C.byref(self.frame_normals.desc()), C.byref(tp))
+
+    def _u32_buffer(self, n):
+        if self.device is None:
+            return np.zeros(max(n, 1), dtype=np.uint32)
+        import torch
+
+        return torch.zeros(max(n, 1), dtype=torch.int32, device=self.device)
+
+    def _hit_sources(self, normals):
+        self._hit_descs = [self.rays.desc()]  # keep the descriptors alive while the struct points at them
+        src = abi.HitSources()
+        src.rays = C.pointer(self._hit_descs[0])
+        src.albedo_width, src.albedo_height = self.W, self.H
+        src.window_row0, src.window_row1 = self.window[1], self.window[1] + self.window[3]
+        if normals:
+            mask, data = self._pending_images()
+            self._hit_descs += [mask.desc(), data.desc()]
+            src.pending_mask, src.pending_data = C.pointer(self._hit_descs[1]), C.pointer(self._hit_descs[2])
+            src.normal_width, src.normal_height = self.W // 2, self.H // 2
+            src.normal_row0, src.normal_row1 = self.dn.origin[1], self.dn.origin[1] + self.dn.height
+        return src
+
+    def hit_count(self, row_bounds, normals=True):
+        """[requests this window has for owner o] (vkr_hit_requests pass 1)"""
+        world = len(row_bounds) - 1
+        counts = self._u32_buffer(world)
+        b = (C.c_uint32 * (world + 1))(*row_bounds)
+        self.call("hit_requests", C.byref(self._hit_sources(normals)), b, world, self._buf_ptr(counts), None, None, None)
+        return [int(v) for v in self.buffer_to_host(counts)[:world]]
+
+    def hit_write(self, row_bounds, counts, normals=True):
+        """The requests, owner o's at [segments[o], segments[o + 1]) (vkr_hit_requests pass 2) -> (uint32 buffer, segments)"""
+        world = len(row_bounds) - 1
+        segments = [0]
+        for c in counts:
+            segments.append(segments[-1] + c)
+        out, cursors = self._u32_buffer(segments[-1]), self._u32_buffer(world)
+        b = (C.c_uint32 * (world + 1))(*row_bounds)
+        seg = (C.c_uint32 * world)(*segments[:world])
+        self.call("hit_requests", C.byref(self._hit_sources(normals)), b, world, None, self._buf_ptr(cursors), seg, self._buf_ptr(out))
+        return out, segments
+
+    def hit_reply(self, requests, count, normals=True):
+        """16 bytes per request from this window's albedo / downsampled normals -> (uint32 buffer [4 * count], errors)"""
+        replies, errors = self._u32_buffer(4 * count), self._u32_buffer(1)
+        dn = self.dn.desc()
+        self.call("hit_reply", C.byref(self.albedo.desc()), C.byref(dn) if normals else None, self._buf_ptr(requests), count,
+                  self._buf_ptr(replies), self._buf_ptr(errors))
+        return replies, int(self.buffer_to_host(errors)[0])
+
+    def hit_scatter(self, requests, replies, count, normals=True):
+        fn = self.frame_normals.desc()
+        self.call("hit_scatter", C.byref(self.frame_albedo.desc()), C.byref(fn) if normals else None, self._buf_ptr(requests),
+                  self._buf_ptr(replies), count)
 
     def ssr_filter(self, render_flags=7):
         tp = self.setup.trace_params()

@@ -123,12 +123,15 @@ class HostBackend:
 
 class TiledFrame:
     def __init__(self, setup, rank, world, cols, rows, device, backend="host", halo=HALO, force_tiled=False, native=False, comm=None,
-                 row_bounds=None):
+                 row_bounds=None, gather_mode=1):
         """native (strips on the host backend only): the frame order, the pack / unpack launches and the exchanges run in
         C++ (host/frame.cpp TiledFrame: grouped RCCL launches on its own stream, ordered with events) — step() is one
         call.  comm: abi.Comm, or None to drive the C++ phases from a harness (tests) / to rehearse on one rank.
         row_bounds (native strips only): world + 1 row numbers; strip r is rows [row_bounds[r], row_bounds[r + 1]) —
-        strips of different heights balance ranks whose rows differ in cost (host.balance_rows)."""
+        strips of different heights balance ranks whose rows differ in cost (host.balance_rows).
+        gather_mode (this Python driver; the C++ frame has its own, host.HostFrame): 1 = albedo and downsampled normals
+        all-gathered (the default here); 0 = hit colours and hit normals by request / reply, 2 = only the hit colours —
+        strips only, on a backend that exposes the hit_* steps (the oracle's: that is how the CPU tests run them)."""
         assert cols * rows == world
         self.setup, self.rank, self.world, self.cols, self.rows_n = setup, rank, world, cols, rows
         W, H = setup.width, setup.height
@@ -166,6 +169,10 @@ class TiledFrame:
             cls = HostBackend if backend == "host" else backend
             self.backend = cls(setup, self.window, self.tiled, device)
         self.backend.set_gather_mips(self.gather_mips)
+        self.gather_mode = 1 if (self.native or not self.tiled or world == 1) else int(gather_mode)
+        if self.gather_mode != 1:
+            assert cols == 1 and hasattr(self.backend, "hit_count"), "request / reply needs strips and a backend with the hit_* steps"
+            self.backend.windowed = self.gather_mode == 0
         self.frame = self.backend.frame
         self.device = self.backend.device
         self._xchg_s = 0.0
@@ -218,8 +225,12 @@ class TiledFrame:
         b.run_stage("downsample")
         hiz = self.gather_pack("hiz")
         yield "gather_start", hiz
-        albedo = self.gather_pack("albedo")
-        yield "gather_start", albedo
+        by_request = self.gather_mode != 1
+        if not by_request:
+            albedo = self.gather_pack("albedo")
+            yield "gather_start", albedo
+        else:
+            b.local_rows(normals=self.gather_mode == 0)
         yield "halo_wait", "taa"
         self.halo_unpack("taa")
         b.run_stage("taa")
@@ -233,8 +244,11 @@ class TiledFrame:
         b.run_stage("gtao")
         self.halo_pack("ao")
         yield "halo_start", "ao"
-        yield "gather_wait", albedo
-        albedo.unpack.run()
+        if by_request:
+            yield "hit_exchange", None  # counts -> requests -> replies -> scatter (-> deferred hit-normal test)
+        else:
+            yield "gather_wait", albedo
+            albedo.unpack.run()
         yield "halo_wait", "ssr"
         self.halo_unpack("ssr")
         b.run_stage("ssr_resolve")
@@ -272,6 +286,8 @@ class TiledFrame:
                     work.wait()
             elif op == "halo_start":
                 self._halo_works[arg] = self._halo_issue(arg)
+            elif op == "hit_exchange":
+                self._hit_exchange()
             else:  # halo_wait
                 self._halo_complete(arg)
             self._xchg_s += time.perf_counter() - t0
@@ -310,10 +326,55 @@ class TiledFrame:
         return self._xchg_s / max(steps, 1) * 1e3
 
     # ---- exchange A: all-gather of the unbounded-reach surfaces -------------------------------------
+    def _hit_exchange(self):
+        """The request / reply round over torch.distributed (host tensors: this driver runs on the oracle in the CPU tests):
+        every rank's counts are gathered, 4-byte requests and 16-byte replies travel point to point, the replies are
+        scattered into the whole-frame images."""
+        import numpy as np
+
+        b, world, me = self.backend, self.world, self.rank
+        normals = self.gather_mode == 0
+        bounds = [r * self.th for r in range(world + 1)]
+        counts = b.hit_count(bounds, normals)
+        matrix = [None] * world
+        dist.all_gather_object(matrix, counts)
+        requests, seg = b.hit_write(bounds, counts, normals)
+        req_np = np.asarray(requests, dtype=np.uint32)
+        incoming = [matrix[r][me] for r in range(world)]
+        in_seg = [0]
+        for n in incoming:
+            in_seg.append(in_seg[-1] + n)
+        req_in = np.zeros(max(in_seg[-1], 1), dtype=np.uint32)
+
+        def exchange(out_np, out_seg, in_np, in_seg_, words):
+            ops, keep = [], []
+            for p in range(world):
+                if p == me:
+                    continue
+                so, ri = out_seg[p + 1] - out_seg[p], in_seg_[p + 1] - in_seg_[p]
+                if so:
+                    keep.append(torch.from_numpy(np.ascontiguousarray(out_np[words * out_seg[p]: words * out_seg[p + 1]]).view(np.int32)))
+                    ops.append(dist.P2POp(dist.isend, keep[-1], p))
+                if ri:
+                    keep.append(torch.from_numpy(in_np[words * in_seg_[p]: words * in_seg_[p + 1]].view(np.int32)))
+                    ops.append(dist.P2POp(dist.irecv, keep[-1], p))
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+
+        exchange(req_np, seg, req_in, in_seg, 1)
+        replies, errors = b.hit_reply(req_in, in_seg[-1], normals)
+        assert errors == 0, "a rank was asked for texels outside its window"
+        rep_np = np.asarray(replies, dtype=np.uint32)
+        rep_in = np.zeros(max(4 * seg[-1], 4), dtype=np.uint32)
+        exchange(rep_np, in_seg, rep_in, seg, 4)
+        b.hit_scatter(req_np, rep_in, seg[-1], normals)
+        self.hit_matrix = matrix
+
     def _gather_plan(self, group):
         """[(src image, src mip, dst image, dst mip, divisor)]: tile interior at full-res >> divisor"""
         if group == "hiz":
-            return [("depth", m, "frame_hiz", m - 1, m) for m in range(1, self.gather_mips + 1)] + [("dn", 0, "frame_normals", 0, 1)]
+            depth = [("depth", m, "frame_hiz", m - 1, m) for m in range(1, self.gather_mips + 1)]
+            return depth + ([] if getattr(self, "gather_mode", 1) == 0 else [("dn", 0, "frame_normals", 0, 1)])
         return [("albedo", 0, "frame_albedo", 0, 0)]
 
     def gather_pack(self, group):
