@@ -491,7 +491,7 @@ int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_img* frame_normals, c
                     uint32_t count, void* stream);
 
 /* Measurement switches — the library's only process-wide state.  The environment (VKR_BLUR_NO_SKIP, VKR_FILTER_NO_SKIP,
- * VKR_TAA_GENERIC, VKR_SHADING_GENERIC) is read once, at the first launch that asks; afterwards only vkr_set_switches
+ * VKR_TAA_GENERIC, VKR_SHADING_GENERIC, VKR_BLUR_GENERIC) is read once, at the first launch that asks; afterwards only vkr_set_switches
  * changes them.  NO_SKIP: evaluate every tap of the blur / filter even in tiles without a reflection / hit (a
  * content-independent time; the stored texels are the same wherever every weight is finite).  GENERIC: the TAA /
  * shading instantiations that do not assume equal window layouts.                                                  */
@@ -499,6 +499,7 @@ int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_img* frame_normals, c
 #define VKR_SWITCH_FILTER_NO_SKIP  2u
 #define VKR_SWITCH_TAA_GENERIC     4u
 #define VKR_SWITCH_SHADING_GENERIC 8u
+#define VKR_SWITCH_BLUR_GENERIC    16u /* every wave of the blur on the per-lane Gaussian loop (no wave-uniform-sigma path) */
 uint32_t vkr_get_switches(void);
 void vkr_set_switches(uint32_t mask);
 

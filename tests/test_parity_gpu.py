@@ -161,6 +161,43 @@ def test_taa_generic_footprints(size, oracle_lib, monkeypatch):
     lib.vkr_set_switches(before)
 
 
+@pytest.mark.parametrize("size", [(640, 360), (1282, 722), (3840, 2160)])
+def test_blur_uniform_sigma_and_general_paths(size, oracle_lib):
+    """ssr.hip resolves a wave whose pixels share one sigma (constant roughness over a surface) on blur_uniform_sigma — Gaussian
+    factors evaluated once, rows unrolled, column sums — and every other wave on the per-lane loop; VKR_SWITCH_BLUR_GENERIC
+    sends all waves through the latter.  Both must give the oracle's image (zero texels outside tolerance), and the frame
+    must exercise both: the two runs differ in the last bit of some texels (different summation order), never by more than
+    one UNORM8 code."""
+    import numpy as np
+
+    lib = abi.product()
+    before = lib.vkr_get_switches()
+    ref, gpu = _pair(*size, oracle_lib)
+    ref.synth()
+    ref.build_prev_hiz()
+    ref.init_histories()
+    ref.preintegrate_pdf()
+    ref.downsample(); ref.ssr_trace(); ref.ssr_filter()
+    _sync_inputs(ref, gpu)
+    ref.ssr_blur()
+    images = {}
+    try:
+        for general in (False, True):
+            lib.vkr_set_switches((before | abi.SWITCH_BLUR_GENERIC) if general else (before & ~abi.SWITCH_BLUR_GENERIC))
+            gpu.ssr_blur()
+            gpu.sync()
+            _compare(ref, gpu, ("blurred",), budget=0)
+            images[general] = gpu.blurred.raw(0).astype(np.int32)
+    finally:
+        lib.vkr_set_switches(before)
+    d = np.abs(images[False] - images[True])
+    differing = int((d != 0).any(axis=-1).sum())
+    print(f"[parity] blur paths at {size}: {differing} texels differ between the uniform-sigma and the general path, max {int(d.max())} code")
+    assert int(d.max()) <= 1
+    if size[0] >= 3840:  # (a few flipped roundings per 1e5 texels: a small frame can have none)
+        assert differing > 0, "no wave took the uniform-sigma path (or the switch is dead): the test frame does not exercise it"
+
+
 @pytest.mark.parametrize("size", [(640, 360), (1920, 1080)])
 def test_gtao_only_config1(size, oracle_lib):
     """BASELINE config 1: GTAO main pass only, non-MIS (use_mis = 0), single and two directions — also at the

@@ -25,6 +25,7 @@ uint32_t switches() {
     if (getenv("VKR_FILTER_NO_SKIP")) v |= VKR_SWITCH_FILTER_NO_SKIP;
     if (getenv("VKR_TAA_GENERIC")) v |= VKR_SWITCH_TAA_GENERIC;
     if (getenv("VKR_SHADING_GENERIC")) v |= VKR_SWITCH_SHADING_GENERIC;
+    if (getenv("VKR_BLUR_GENERIC")) v |= VKR_SWITCH_BLUR_GENERIC;
     uint32_t expected = 0x80000000u;
     if (!g_switches.compare_exchange_strong(expected, v)) v = expected;
   }

@@ -449,6 +449,7 @@ struct BlurArgs {
   float max_roughness;
   uint32_t accumulate, disable_blur;
   uint32_t skip_empty_tiles;  // 1: a tile whose staged reflections are all black skips its taps (the sums are exactly 0)
+  uint32_t uniform_sigma_path;  // 1: waves whose pixels share one sigma take blur_uniform_sigma
 };
 
 // Tile geometry of the blur: a block resolves BLUR_BX x BLUR_BY pixels and stages the pixels within
@@ -472,6 +473,12 @@ struct BlurArgs {
 #define BLUR_TW (BLUR_BX + 2 * BLUR_R)
 #define BLUR_TH (BLUR_BY + 2 * BLUR_R)
 #define BLUR_THREADS (BLUR_BX * BLUR_BY / 2)
+#ifndef BLUR_AHEAD
+#define BLUR_AHEAD 3
+#endif
+#ifndef BLUR_WAVES
+#define BLUR_WAVES 4  // waves per SIMD the register budget is sized for
+#endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 VKR_DEV v2f splat2(float a) { return (v2f){a, a}; }
@@ -494,21 +501,30 @@ __device__ unsigned long long g_blur_stamps[65536 * 8];
 #define VKR_STAMP_VALUE(slot, v) do {} while (0)
 #endif
 
+// A staged pixel is ONE 16-byte record, so a tap is one ds_read_b128: {normal.x, normal.y, normal.z, depth} as floats, with the low
+// mantissa byte of the three normal components replaced by the R, G, B codes of the reflection texel.  v_cvt_f32_ubyte0 reads a
+// code straight out of the word; the normal keeps 15 mantissa bits (relative error < 2^-15), and it only enters the smooth normal
+// weight.  The depth word is exact: the bilateral weight is a cliff.
+VKR_DEV uint4 blur_pack(f3 n, float depth, uint32_t rgba) {
+  return make_uint4((__float_as_uint(n.x) & ~0xFFu) | (rgba & 0xFFu), (__float_as_uint(n.y) & ~0xFFu) | ((rgba >> 8) & 0xFFu),
+                    (__float_as_uint(n.z) & ~0xFFu) | ((rgba >> 16) & 0xFFu), __float_as_uint(depth));
+}
+
 // accumulators: xyz = sum w * colour (UNORM8 code units), w = sum w
-VKR_DEV void blur_tap(const float4* s_nd, const uint32_t* s_refl, const BlurCentre& c, int t, float wg, f4& acc) {
-  const float4 nd = s_nd[t];
-  const uint32_t col = s_refl[t];
-  const float bil = vmax(__builtin_fmaf(-fabsf(c.depth - nd.w), c.k_bilateral, 1.0f), 0.0f);
-  const float nw = vmax(__builtin_fmaf(c.normal.z, nd.z, __builtin_fmaf(c.normal.y, nd.y, c.normal.x * nd.x)), 0.0f);
+VKR_DEV void blur_tap(const uint4* s_px, const BlurCentre& c, int t, float wg, f4& acc) {
+  const uint4 p = lds_load4(&s_px[t]);
+  const float nx = __uint_as_float(p.x), ny = __uint_as_float(p.y), nz = __uint_as_float(p.z), d = __uint_as_float(p.w);
+  const float bil = vmax(__builtin_fmaf(-fabsf(c.depth - d), c.k_bilateral, 1.0f), 0.0f);
+  const float nw = vmax(__builtin_fmaf(c.normal.z, nz, __builtin_fmaf(c.normal.y, ny, c.normal.x * nx)), 0.0f);
   const float w = (wg * bil) * nw;
-  acc.x = __builtin_fmaf(w, (float)(col & 0xFFu), acc.x);
-  acc.y = __builtin_fmaf(w, (float)((col >> 8) & 0xFFu), acc.y);
-  acc.z = __builtin_fmaf(w, (float)((col >> 16) & 0xFFu), acc.z);
+  acc.x = __builtin_fmaf(w, (float)(p.x & 0xFFu), acc.x);
+  acc.y = __builtin_fmaf(w, (float)(p.y & 0xFFu), acc.y);
+  acc.z = __builtin_fmaf(w, (float)(p.z & 0xFFu), acc.z);
   acc.w += w;
 }
 
 // one pixel on its own (rows of the pair with different radii, or a missing partner row)
-VKR_DEV f4 blur_single(const float4* s_nd, const uint32_t* s_refl, const BlurCentre& c) {
+VKR_DEV f4 blur_single(const uint4* s_px, const BlurCentre& c) {
   f4 acc = mk4(0, 0, 0, 0);
   const float kappa = __builtin_amdgcn_exp2f(2.0f * c.neg_inv_e_log2);  // exp(-2/e)
   const int r = c.r;
@@ -522,7 +538,7 @@ VKR_DEV f4 blur_single(const float4* s_nd, const uint32_t* s_refl, const BlurCen
     float ej = e_start, rho_j = rho_start;
 #pragma unroll 1
     for (int j = -r; j <= r; j++) {
-      blur_tap(s_nd, s_refl, c, c.tc + i + j * BLUR_TW, gi * ej, acc);
+      blur_tap(s_px, c, c.tc + i + j * BLUR_TW, gi * ej, acc);
       ej *= rho_j; rho_j *= kappa;
     }
     ei *= rho_i; rho_i *= kappa;
@@ -530,9 +546,73 @@ VKR_DEV f4 blur_single(const float4* s_nd, const uint32_t* s_refl, const BlurCen
   return acc;
 }
 
-// one BLUR_BX x BLUR_BY tile of the output; s_nd / s_refl: the staged tile, one float4 {normal.xyz, depth} + one packed
-// RGBA8 reflection texel per pixel; s_lut: the sRGB decode table (staged by the caller, visible after the barrier below)
-VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* s_refl, const float* s_lut, const int tid) {
+// Wave-uniform sigma (a material's roughness is constant over most of a surface, so the 32 x 4 pixels of a wave usually share
+// it): the Gaussian factors E(k) = exp(-k^2 / e) are then the same numbers in every lane.  They are evaluated once, held as the
+// R + 1 register pairs P[k] = {E(k), E(k+1)} (E(R+1) := 0), and a staged row s — row s of pixel A, row s - 1 of pixel B — takes
+// its pair of row factors {E(|s|), E(|s-1|)} from one of them, swapped for s >= 1 by the operand selectors of the packed
+// multiply.  Against the general loop below: no running Gaussian products (two packed multiplies per tap), the rows of a column
+// fully unrolled (LDS offsets are immediates, no loop counter), the column factor E(i) applied once per column to the column's
+// sums, the unpaired end rows served by the zero in P[R].  Per pixel the taps and their weights are the shader's; the sums are
+// formed column by column (rounding noise against a 1e-3 / one-code tolerance).
+template <bool SWAP> VKR_DEV v2f pk_mul_rows(v2f a, v2f p) {
+  if (!SWAP) return a * p;
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(p));
+  return r;
+}
+
+template <int R> VKR_DEV void blur_uniform_sigma(const uint4* s_px, const BlurCentre* c, f4& accA, f4& accB) {
+  const float nie = c[0].neg_inv_e_log2, g = c[0].g;  // the same in every lane and for both pixels
+  v2f P[R + 1];
+#pragma unroll
+  for (int k = 0; k <= R; k++)
+    P[k] = (v2f){__builtin_amdgcn_exp2f((float)(k * k) * nie), k < R ? __builtin_amdgcn_exp2f((float)((k + 1) * (k + 1)) * nie) : 0.0f};
+  const v2f cnx = {c[0].normal.x, c[1].normal.x}, cny = {c[0].normal.y, c[1].normal.y}, cnz = {c[0].normal.z, c[1].normal.z};
+  const v2f kb = {c[0].k_bilateral, c[1].k_bilateral};
+  const v2f kcd = kb * (v2f){c[0].depth, c[1].depth};
+  const float kappa = __builtin_amdgcn_exp2f(2.0f * nie);
+  float ei = P[R].x, rho_i = __builtin_amdgcn_exp2f((float)(1 - 2 * R) * nie);  // E(-R), rho(-R)
+  v2f acc_r = {0.0f, 0.0f}, acc_g = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f}, acc_w = {0.0f, 0.0f};
+  const uint4* col = s_px + (c[0].tc - R - R * BLUR_TW);  // row -R of pixel A, column -R
+#pragma unroll 1
+  for (int i = -R; i <= R; i++, col++) {
+    v2f col_r = {0.0f, 0.0f}, col_g = {0.0f, 0.0f}, col_b = {0.0f, 0.0f}, col_w = {0.0f, 0.0f};
+    uint4 ahead[BLUR_AHEAD];  // the reads run BLUR_AHEAD rows ahead of the arithmetic
+#pragma unroll
+    for (int k = 0; k < BLUR_AHEAD; k++) ahead[k] = lds_load4(col + k * BLUR_TW);
+#pragma unroll
+    for (int s = -R; s <= R + 1; s++) {
+      const uint4 p = ahead[(s + R) % BLUR_AHEAD];
+      if (s + R + BLUR_AHEAD <= 2 * R + 1) ahead[(s + R) % BLUR_AHEAD] = lds_load4(col + (s + R + BLUR_AHEAD) * BLUR_TW);
+      const v2f nzw = {__uint_as_float(p.z), __uint_as_float(p.w)};
+      const v2f nxy = __builtin_elementwise_fma(cny, splat2(__uint_as_float(p.y)), cnx * splat2(__uint_as_float(p.x)));
+      v2f nw, kdz;
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] clamp" : "=v"(nw) : "v"(cnz), "v"(nzw), "v"(nxy));
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+          : "=v"(kdz) : "v"(kb), "v"(nzw), "v"(kcd));
+      const v2f tw = s >= 1 ? pk_mul_rows<true>(nw, P[s >= 1 ? s - 1 : 0]) : pk_mul_rows<false>(nw, P[s >= 1 ? 0 : -s]);
+      v2f w;
+      w.x = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(kdz.x), tw.x, tw.x), 0.0f), 1.0f);
+      w.y = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(kdz.y), tw.y, tw.y), 0.0f), 1.0f);
+      col_r = __builtin_elementwise_fma(w, splat2((float)(p.x & 0xFFu)), col_r);
+      col_g = __builtin_elementwise_fma(w, splat2((float)(p.y & 0xFFu)), col_g);
+      col_b = __builtin_elementwise_fma(w, splat2((float)(p.z & 0xFFu)), col_b);
+      col_w += w;
+    }
+    const v2f e2 = splat2(ei);
+    acc_r = __builtin_elementwise_fma(e2, col_r, acc_r);
+    acc_g = __builtin_elementwise_fma(e2, col_g, acc_g);
+    acc_b = __builtin_elementwise_fma(e2, col_b, acc_b);
+    acc_w = __builtin_elementwise_fma(e2, col_w, acc_w);
+    ei *= rho_i; rho_i *= kappa;
+  }
+  accA = mk4(acc_r.x * g, acc_g.x * g, acc_b.x * g, acc_w.x * g);
+  accB = mk4(acc_r.y * g, acc_g.y * g, acc_b.y * g, acc_w.y * g);
+}
+
+// one BLUR_BX x BLUR_BY tile of the output; s_px: the staged tile, one 16-byte record per pixel (blur_pack); s_lut: the sRGB
+// decode table (staged by the caller, visible after the barrier below)
+VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, uint4* s_px, const float* s_lut, const int tid) {
   const int bx0 = a.out.ox + blk.x * BLUR_BX - BLUR_R;  // frame coordinates of the tile origin
   const int by0 = a.out.oy + blk.y * BLUR_BY - BLUR_R;
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
@@ -590,8 +670,7 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
     for (int k = 0; k < STAGE_ITERS; k++) {
       const int t = min(tid + k * BLUR_THREADS, BLUR_TW * BLUR_TH - 1);
       const f3 n = decode_normal_fast(taps_resolve<FmtRG16U>(stage_normal[k]));  // only enters the normal weight
-      s_nd[t] = make_float4(n.x, n.y, n.z, FmtD24::decode(stage_depth[k]));
-      s_refl[t] = stage_refl[k];
+      lds_store4(&s_px[t], blur_pack(n, FmtD24::decode(stage_depth[k]), stage_refl[k]));
     }
   }
 
@@ -625,7 +704,7 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
       float roughness = taps_srgb_channel(rough_taps[k], 1, s_lut);
       roughness = mixf(0.0f, a.max_roughness, roughness);
       c[k].tc = (2 * threadIdx.y + k + BLUR_R) * BLUR_TW + (threadIdx.x + BLUR_R);
-      c[k].depth = s_nd[c[k].tc].w;
+      c[k].depth = __uint_as_float(s_px[c[k].tc].w);
       c[k].normal = decode_normal_fast(taps_resolve<FmtRG16U>(normal_taps[k]));
       float sigma = mixf(0.4f, 4.0f, roughness);
       if (a.disable_blur != 0) sigma = 0.35f;
@@ -656,11 +735,34 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
   VKR_STAMP(2);  // per-pixel set-up done
   VKR_STAMP_VALUE(5, empty_tile ? 0 : c[0].r);
   f4 accA = mk4(0, 0, 0, 0), accB = mk4(0, 0, 0, 0);
-  if (empty_tile) {
-    // nothing to add up: both sums stay 0 and the epilogue turns them into colour 0 (then the history mix)
+  bool uniform_sigma = false;
+  if (!empty_tile && a.uniform_sigma_path != 0) {
+    const uint32_t key = __float_as_uint(c[0].neg_inv_e_log2);
+    const uint32_t key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+    const bool same = has_b && key == key0 && __float_as_uint(c[1].neg_inv_e_log2) == key0;
+    if (__ballot(same) == ~0ull) {  // a full wave, every pixel with the same sigma (hence the same radius and normalisation)
+      uniform_sigma = true;
+      switch (__builtin_amdgcn_readfirstlane(c[0].r)) {
+        case 1: blur_uniform_sigma<1>(s_px, c, accA, accB); break;
+        case 2: blur_uniform_sigma<2>(s_px, c, accA, accB); break;
+        case 3: blur_uniform_sigma<3>(s_px, c, accA, accB); break;
+        case 4: blur_uniform_sigma<4>(s_px, c, accA, accB); break;
+        case 5: blur_uniform_sigma<5>(s_px, c, accA, accB); break;
+        case 6: blur_uniform_sigma<6>(s_px, c, accA, accB); break;
+        case 7: blur_uniform_sigma<7>(s_px, c, accA, accB); break;
+        case 8: blur_uniform_sigma<8>(s_px, c, accA, accB); break;
+        case 9: blur_uniform_sigma<9>(s_px, c, accA, accB); break;
+        case 10: blur_uniform_sigma<10>(s_px, c, accA, accB); break;
+        case 11: blur_uniform_sigma<11>(s_px, c, accA, accB); break;
+        default: uniform_sigma = false; break;
+      }
+    }
+  }
+  if (empty_tile || uniform_sigma) {
+    // empty: nothing to add up, both sums stay 0 and the epilogue turns them into colour 0 (then the history mix)
   } else if (!has_b || c[0].r != c[1].r) {
-    accA = blur_single(s_nd, s_refl, c[0]);
-    if (has_b) accB = blur_single(s_nd, s_refl, c[1]);
+    accA = blur_single(s_px, c[0]);
+    if (has_b) accB = blur_single(s_px, c[1]);
   } else {
     // paired path: lane x = pixel A, lane y = pixel B, same radius r.  A's rows are jA = -r..r,
     // B's rows jB = jA - 1; the staged row tcA + jA*TW serves both for jA = -r+1..r.
@@ -685,16 +787,15 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
     for (int i = -r; i <= r; i++) {
       const int col = tcA + i;
       // unpaired ends of the column: A's row -r and B's row +r (tcB + r*TW = tcA + (r+1)*TW)
-      blur_tap(s_nd, s_refl, c[0], col - r * BLUR_TW, ei.x * e_edge.x, edgeA);
-      blur_tap(s_nd, s_refl, c[1], col + (r + 1) * BLUR_TW, ei.y * e_edge.y, edgeB);
+      blur_tap(s_px, c[0], col - r * BLUR_TW, ei.x * e_edge.x, edgeA);
+      blur_tap(s_px, c[1], col + (r + 1) * BLUR_TW, ei.y * e_edge.y, edgeB);
       v2f wj = ei * ej_first, rho_j = rhoj_first;  // running E(i) * E(j)
       int t = col - (r - 1) * BLUR_TW;
 #pragma unroll 2
       for (int j = -r + 1; j <= r; j++, t += BLUR_TW) {
-        const float4 nd = s_nd[t];
-        const uint32_t colr = s_refl[t];
-        const v2f nzw = {nd.z, nd.w};
-        const v2f nxy = __builtin_elementwise_fma(cny, splat2(nd.y), cnx * splat2(nd.x));
+        const uint4 p = lds_load4(&s_px[t]);
+        const v2f nzw = {__uint_as_float(p.z), __uint_as_float(p.w)};
+        const v2f nxy = __builtin_elementwise_fma(cny, splat2(__uint_as_float(p.y)), cnx * splat2(__uint_as_float(p.x)));
         v2f nw, kdz;
         // nw = clamp(cnz * n.z + nxy): v_pk_* has no max, the clamp modifier does it for free
         asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] clamp" : "=v"(nw) : "v"(cnz), "v"(nzw), "v"(nxy));
@@ -706,9 +807,9 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
         v2f w;
         w.x = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(kdz.x), tw.x, tw.x), 0.0f), 1.0f);
         w.y = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(kdz.y), tw.y, tw.y), 0.0f), 1.0f);
-        acc_r = __builtin_elementwise_fma(w, splat2((float)(colr & 0xFFu)), acc_r);
-        acc_g = __builtin_elementwise_fma(w, splat2((float)((colr >> 8) & 0xFFu)), acc_g);
-        acc_b = __builtin_elementwise_fma(w, splat2((float)((colr >> 16) & 0xFFu)), acc_b);
+        acc_r = __builtin_elementwise_fma(w, splat2((float)(p.x & 0xFFu)), acc_r);
+        acc_g = __builtin_elementwise_fma(w, splat2((float)(p.y & 0xFFu)), acc_g);
+        acc_b = __builtin_elementwise_fma(w, splat2((float)(p.z & 0xFFu)), acc_b);
         acc_w += w;
         wj *= rho_j; rho_j *= kappa;
       }
@@ -733,9 +834,8 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, float4* s_nd, uint32_t* 
   }
 }
 
-__global__ __launch_bounds__(BLUR_THREADS, 4) void k_sssr_blur(BlurArgs a) {
-  __shared__ float4 s_nd[BLUR_TH * BLUR_TW];
-  __shared__ uint32_t s_refl[BLUR_TH * BLUR_TW];
+__global__ __launch_bounds__(BLUR_THREADS, BLUR_WAVES) void k_sssr_blur(BlurArgs a) {
+  __shared__ uint4 s_px[BLUR_TH * BLUR_TW];
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   const int tid = threadIdx.y * BLUR_BX + threadIdx.x;
   VKR_STAMP(0);
@@ -748,7 +848,7 @@ __global__ __launch_bounds__(BLUR_THREADS, 4) void k_sssr_blur(BlurArgs a) {
   }
 #endif
   srgb_lut_stage(s_lut, tid, BLUR_THREADS);
-  blur_tile(a, xcd_block<4, 2>(), s_nd, s_refl, s_lut, tid);  // chunks of 128 x 64 output pixels
+  blur_tile(a, xcd_block<4, 2>(), s_px, s_lut, tid);  // chunks of 128 x 64 output pixels
   VKR_STAMP(4);
 }
 
@@ -905,6 +1005,7 @@ static int make_blur_args(BlurArgs& a, const vkr_img* depth, const vkr_img* norm
   a.accumulate = push->accumulate;
   a.disable_blur = push->disable_blur;
   a.skip_empty_tiles = (switches() & VKR_SWITCH_BLUR_NO_SKIP) ? 0u : 1u;  // measurement switch: identical output for finite weights
+  a.uniform_sigma_path = (switches() & VKR_SWITCH_BLUR_GENERIC) ? 0u : 1u;
   if (a.max_roughness > 1.0f || a.max_roughness < 0.0f) {  // sigma <= 4 bounds the staged radius (blur.comp:45)
     set_error("sssr_blur: max_roughness must be in [0,1] (reference slider range, advanced_ssr.cpp:558)");
     return VKR_ERR_EXTENT;
