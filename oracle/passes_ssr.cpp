@@ -84,6 +84,9 @@ struct TraceCtx {
 uint8_t* g_step_sink = nullptr;
 int g_step_sink_pitch = 0;
 thread_local uint32_t t_last_steps = 0;
+// instrumentation for kernel design (tools/trace_steps.py --gate): how often the horizon update of a step is evaluated, passes its
+// |v| < 0.3 gate, and could have been refused by |v.z| alone; [0..3] pinned steps, [4..7] later steps: {steps, mip <= 1, passed, |v.z| >= 0.3}
+uint64_t* g_gate_counters = nullptr;
 
 // trace.comp:206-268
 vec3 hierarchical_raymarch_find_hor(const TraceCtx& c, vec3 origin, vec3 direction, int most_detailed_mip,
@@ -116,6 +119,15 @@ vec3 hierarchical_raymarch_find_hor(const TraceCtx& c, vec3 origin, vec3 directi
       float h2 = dot(w0, normalize(v));
       if (length(v) < 0.3f) h = max(h, h2);
     }
+    if (g_gate_counters) {
+      uint64_t* k = g_gate_counters + (i <= 15 ? 0 : 4);
+      __atomic_fetch_add(&k[0], 1, __ATOMIC_RELAXED);
+      if (current_mip <= 1) {
+        __atomic_fetch_add(&k[1], 1, __ATOMIC_RELAXED);
+        if (length(v) < 0.3f) __atomic_fetch_add(&k[2], 1, __ATOMIC_RELAXED);
+        if (std::fabs(v.z) >= 0.3001f) __atomic_fetch_add(&k[3], 1, __ATOMIC_RELAXED);
+      }
+    }
   }
   valid_hit = (i <= max_traversal_intersections);
   t_last_steps = i;
@@ -125,6 +137,7 @@ vec3 hierarchical_raymarch_find_hor(const TraceCtx& c, vec3 origin, vec3 directi
 }  // namespace
 
 extern "C" void vkr_ref_set_step_sink(uint8_t* sink, int pitch_bytes) { g_step_sink = sink; g_step_sink_pitch = pitch_bytes; }
+extern "C" void vkr_ref_set_gate_counters(uint64_t* counters8) { g_gate_counters = counters8; }
 
 // trace.comp:41-141.  window != NULL: the multi-GPU variant (include/vkr_postfx.h vkr_sssr_trace_windowed) — the same
 // conjunction of validity tests, with the hit-normal test of a ray whose footprint rows are not all inside

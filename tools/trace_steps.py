@@ -33,8 +33,14 @@ def main():
     steps = np.zeros((H // 2, W // 2), dtype=np.uint8)
     lib.vkr_ref_set_step_sink.argtypes = [C.c_void_p, C.c_int]
     lib.vkr_ref_set_step_sink(steps.ctypes.data, steps.strides[0])
+    gate = np.zeros(8, dtype=np.uint64)
+    lib.vkr_ref_set_gate_counters.argtypes = [C.c_void_p]
+    lib.vkr_ref_set_gate_counters(gate.ctypes.data)
     c.ssr_trace(frame_random=0)
     lib.vkr_ref_set_step_sink(None, 0)
+    lib.vkr_ref_set_gate_counters(None)
+    for name, k in (("pinned steps", gate[:4]), ("later steps", gate[4:])):
+        print(f"{name}: {int(k[0])} steps, horizon update evaluated (mip <= 1) {int(k[1])}, gate passed {int(k[2])}, |v.z| >= 0.3 alone refuses {int(k[3])}")
     np.save(a.out, steps)
     h = np.bincount(steps.ravel(), minlength=81)
     print("mean", steps.mean(), "hist16", h[16] / steps.size, "hist80", h[80] / steps.size, "min", steps.min())
