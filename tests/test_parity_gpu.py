@@ -198,6 +198,62 @@ def test_blur_uniform_sigma_and_general_paths(size, oracle_lib):
         assert differing > 0, "no wave took the uniform-sigma path (or the switch is dead): the test frame does not exercise it"
 
 
+@pytest.mark.parametrize("pathological", [False, True])
+def test_empty_tile_skip_against_no_skip(pathological, oracle_lib):
+    """The filter and the blur return zeros for a tile without a hit / a reflection instead of evaluating its taps
+    (ssr.hip).  The sums they skip are w * 0, so the stored texels are the same wherever every weight is finite — the
+    precondition the comments state.  Checked here on the benchmark scene (bit-identical images), and on the
+    same scene with the inputs that make a weight infinite or NaN planted into it: material roughness 0 under grazing
+    normals (alpha2 * rcp(0) in the filter) and stored depth 0 (k_bilateral = 1000 / 0 in the blur).  There the two runs
+    may only differ where such a texel is a centre or lies inside an otherwise empty tile's taps; the count is printed
+    and bounded by the pixels within a blur radius of a planted texel."""
+    W, H = 640, 360
+    lib = abi.product()
+    before = lib.vkr_get_switches()
+    ref, gpu = _pair(W, H, oracle_lib)
+    ref.synth()
+    ref.build_prev_hiz()
+    ref.init_histories()
+    ref.preintegrate_pdf()
+    planted = np.zeros((H // 2, W // 2), dtype=bool)
+    if pathological:
+        rng = np.random.default_rng(7)
+        mat = ref.material.raw(0).copy()
+        dep = ref.depth.raw(0).copy()
+        nrm = ref.normal.raw(0).copy()
+        for _ in range(40):
+            x, y = int(rng.integers(8, W - 8)), int(rng.integers(8, H - 8))
+            mat[y:y + 2, x:x + 2, 1] = 0                      # roughness 0 (sRGB code 0)
+            nrm[y:y + 2, x:x + 2] = (65535, 32768)            # octahedral (+1, 0): a normal along +x, grazing for most views
+            if _ % 2:
+                dep[y:y + 2, x:x + 2] = dep[y:y + 2, x:x + 2] & 0xFF000000  # D24 = 0
+            planted[y // 2, x // 2] = True
+        ref.material.set_raw(mat); ref.depth.set_raw(dep); ref.normal.set_raw(nrm)
+    ref.downsample(); ref.ssr_trace(); 
+    _sync_inputs(ref, gpu)
+    images = {}
+    try:
+        for no_skip in (False, True):
+            mask = abi.SWITCH_BLUR_NO_SKIP | abi.SWITCH_FILTER_NO_SKIP
+            lib.vkr_set_switches((before | mask) if no_skip else (before & ~mask))
+            gpu.ssr_filter(); gpu.ssr_blur(); gpu.sync()
+            images[no_skip] = (gpu.reflections.raw(0).copy(), gpu.blurred.raw(0).copy())
+    finally:
+        lib.vkr_set_switches(before)
+    for k, name in enumerate(("reflections", "blurred")):
+        differ = (images[False][k][..., :3] != images[True][k][..., :3]).any(axis=-1)
+        print(f"[parity] skip vs no-skip, pathological={pathological}: {name} {int(differ.sum())} texels differ")
+        if not pathological:
+            assert int(differ.sum()) == 0, f"{name}: the empty-tile skip changed {int(differ.sum())} texels of a frame whose weights are all finite"
+        else:
+            # a planted texel reaches at most 11 + 1 half-res pixels (blur radius + the filter's cross)
+            ys, xs = np.nonzero(planted)
+            near = np.zeros_like(planted)
+            for y, x in zip(ys, xs):
+                near[max(0, y - 13):y + 14, max(0, x - 13):x + 14] = True
+            assert not (differ & ~near).any(), f"{name}: skip and no-skip differ away from every planted non-finite weight"
+
+
 @pytest.mark.parametrize("size", [(640, 360), (1920, 1080)])
 def test_gtao_only_config1(size, oracle_lib):
     """BASELINE config 1: GTAO main pass only, non-MIS (use_mis = 0), single and two directions — also at the
