@@ -33,15 +33,19 @@ struct GtaoArgs {
 struct DepthTile {
   const float* d;
   int x0, y0;  // frame coordinates of tile texel (0,0)
+  float x0f, y0f;  // the same as floats (|.| < 2^16: exact)
   float fw, fh;
 };
-// texture(depth, uv): same arithmetic as sample<FmtD24>, texels served from the tile
+// texture(depth, uv): same arithmetic as sample<FmtD24>, texels served from the tile.  The texel index is taken relative to
+// the tile and clamped while still a float (floor values and the tile origin are integers far below 2^24, so the
+// difference is exact; a NaN clamps to the low bound), then converted: one v_med3_f32 per axis instead of two integer ones.
 VKR_DEV float tile_sample(const DepthTile& t, f2 uv) {
   float x = cfma(uv.x, t.fw, -0.5f), y = cfma(uv.y, t.fh, -0.5f);
   float x0f = floorf(x), y0f = floorf(y);
   float fx = x - x0f, fy = y - y0f;
-  int tx = iclamp(f2i(x0f) - t.x0, 0, GT_TW - 2), ty = iclamp(f2i(y0f) - t.y0, 0, GT_TH - 2);
-  const float* p = t.d + ty * GT_TW + tx;
+  const int tx = (int)__builtin_amdgcn_fmed3f(x0f - t.x0f, 0.0f, (float)(GT_TW - 2));
+  const int ty = (int)__builtin_amdgcn_fmed3f(y0f - t.y0f, 0.0f, (float)(GT_TH - 2));
+  const float* p = t.d + (__umul24((uint32_t)ty, (uint32_t)GT_TW) + (uint32_t)tx);
   return mixf(mixf(p[0], p[1], fx), mixf(p[GT_TW], p[GT_TW + 1], fx), fy);
 }
 
@@ -59,9 +63,11 @@ template <bool TILED>
 VKR_DEV float find_horizon(const DepthTile& depth, const Tex& depth_tex, const Proj& pr, f2 start, f3 camera_start, f2 dir, f3 v) {
   float h_cos = -1.0f;
   float previous_z = camera_start.z;
+  float s = 0.0f;  // i / 16: multiples of 2^-4 add exactly
 #pragma unroll 1
   for (int i = 1; i <= 16; i++) {
-    f2 tc = madd(start, (float)i / 16.0f, dir);
+    s += 0.0625f;
+    f2 tc = madd(start, s, dir);
     float sample_depth = depth_sample<TILED>(depth, depth_tex, tc);
     f3 sample_pos = reconstruct_view_vec(tc, sample_depth, pr);
     if (sample_pos.z > previous_z + 0.1f) break;  // MAX_THIKNESS, main.comp:82
@@ -69,7 +75,7 @@ VKR_DEV float find_horizon(const DepthTile& depth, const Tex& depth_tex, const P
     f3 sample_offset = sample_pos - camera_start;
     // max()-reduced cosine: the hardware rsq is accurate enough (the break test above stays exact)
     float sample_cos = dot(v, sample_offset) * fast_rsq(dot(sample_offset, sample_offset));
-    h_cos = vmax(h_cos, sample_cos);
+    asm("v_max_f32 %0, %1, %2" : "=v"(h_cos) : "v"(h_cos), "v"(sample_cos));  // fmaxf without the canonicalising self-max (a NaN cosine is dropped either way)
   }
   return h_cos;
 }
@@ -78,7 +84,8 @@ VKR_DEV float find_horizon(const DepthTile& depth, const Tex& depth_tex, const P
 // (main.comp:276-278), so its 16 (cos,sin) pairs are kernel arguments evaluated once on the host
 // instead of per pixel.
 template <bool TILED>
-__global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
+// (a block is 16 waves: with more than 64 VGPRs only one block fits a CU — 4 waves per SIMD — and the pass is 11 % slower)
+__global__ __launch_bounds__(GT_BX * GT_BY, 8) void k_gtao_main(GtaoArgs a) {
   const i2 blk = xcd_block<2, 4>();  // chunks of 128 x 64 output pixels
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   __shared__ float s_depth[GT_TW * GT_TH];
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(GT_BX * GT_BY) void k_gtao_main(GtaoArgs a) {
   tile.d = s_depth;
   tile.x0 = a.out.ox + blk.x * GT_BX - GT_R;
   tile.y0 = a.out.oy + blk.y * GT_BY - GT_R;
+  tile.x0f = (float)tile.x0; tile.y0f = (float)tile.y0;
   tile.fw = (float)a.depth.fw; tile.fh = (float)a.depth.fh;
   if (TILED)
     for (int t = tid; t < GT_TW * GT_TH; t += GT_BX * GT_BY)
