@@ -31,7 +31,10 @@ struct MarchEnv {
 VKR_DEV void horizon_gate(const MarchEnv& env, const RayConst& rc, RayState& st, f2 uv, float surface_z) {
   const f3 v = reconstruct_view_vec(uv, surface_z, env.pr) - rc.view_vec;
   const float d2 = dot(v, v);
-  if (d2 < env.horizon_d2) st.h = vmax(st.h, dot(rc.normal, v) * __builtin_amdgcn_rsqf(d2));  // length(v) < 0.3, decided exactly on the squared length
+  if (d2 < env.horizon_d2) {  // length(v) < 0.3, decided exactly on the squared length
+    const float c = dot(rc.normal, v) * __builtin_amdgcn_rsqf(d2);
+    asm("v_max_f32 %0, %1, %2" : "=v"(st.h) : "v"(st.h), "v"(c));  // fmaxf without the canonicalising self-max (a NaN cosine is dropped either way)
+  }
 }
 
 // One step of the march; returns false when the ray is finished.  HORIZON / PIN_STEPS = 15 / max 80 is
@@ -48,8 +51,8 @@ VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, i
   float surface_z = 0.0f;
   if ((unsigned)st.mip < (unsigned)env.mip_count) {
     const uint4 m = env.mip_table[st.mip];
-    const int tx = f2i(mip_pos.x), ty = f2i(mip_pos.y);
-    if (tx >= 0 && ty >= 0 && tx < (int)(m.w & 0xFFFFu) && ty < (int)(m.w >> 16)) {
+    const int tx = f2i_index(mip_pos.x), ty = f2i_index(mip_pos.y);
+    if ((uint32_t)tx < (m.w & 0xFFFFu) && (uint32_t)ty < (m.w >> 16)) {  // 0 <= t < extent as one unsigned compare per axis
       typedef const __attribute__((address_space(1))) uint32_t* gptr_t;  // a global, not flat, address
       const uint64_t addr = (((uint64_t)m.y << 32) | m.x) + (uint64_t)(__umul24((uint32_t)ty, m.z) + (uint32_t)tx * 4u);  // 32-bit offset, see toff()
       surface_z = d24_to_float(*(gptr_t)addr);
@@ -84,7 +87,7 @@ template <class Fetch0>
 VKR_DEV void march_step_pinned0(const MarchEnv& env, const RayConst& rc, RayState& st, const Fetch0& fetch0) {
   const f3 position = madd(rc.origin, st.t, rc.direction);
   const f2 mip_pos = env.screen_size * xy(position);
-  const float surface_z = fetch0(f2i(mip_pos.x), f2i(mip_pos.y));
+  const float surface_z = fetch0(f2i_index(mip_pos.x), f2i_index(mip_pos.y));
   const f2 uv_offset = mk2(rc.direction.x < 0.0f ? -env.uv_offset_abs.x : env.uv_offset_abs.x,
                            rc.direction.y < 0.0f ? -env.uv_offset_abs.y : env.uv_offset_abs.y);
   const f2 floor_offset = mk2(rc.direction.x < 0.0f ? 0.0f : 1.0f, rc.direction.y < 0.0f ? 0.0f : 1.0f);

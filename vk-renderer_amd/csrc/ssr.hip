@@ -190,7 +190,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
     // round 0: the first 15 steps never leave mip 0 (specialised step), step 16 (i = 15) is the first that may
     {
       const auto fetch0 = [&](int x, int y) -> float {
-        return (x >= 0 && y >= 0 && x < depth0.w && y < depth0.h) ? d24_to_float(*(const uint32_t*)(depth0.p + toff(depth0, x, y, 4))) : 0.0f;
+        return ((uint32_t)x < (uint32_t)depth0.w && (uint32_t)y < (uint32_t)depth0.h) ? d24_to_float(*(const uint32_t*)(depth0.p + toff(depth0, x, y, 4))) : 0.0f;
       };
 #pragma unroll 1
       for (int k = 0; k < 15; k++) march_step_pinned0(env, rc, st, fetch0);

@@ -136,6 +136,13 @@ VKR_DEV int f2i(float f) {
   asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
   return min(max(r, -1073741824), 1073741824);
 }
+// float -> int for an index that is only range-checked: v_cvt_i32_f32 as it is (truncate, NaN -> 0, saturate at INT_MIN /
+// INT_MAX, both of which fail an unsigned `< extent` test)
+VKR_DEV int f2i_index(float f) {
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
+}
 VKR_DEV uint32_t f2u(float f) {
   uint32_t r;
   asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
