@@ -468,7 +468,9 @@ struct BlurArgs {
 // rho(k)*exp(-2/e)), the bilateral term uses a reciprocal-multiply, colour is accumulated in
 // UNORM8 code units and scaled by 1/255 once.
 #define BLUR_BX 32
+#ifndef BLUR_BY
 #define BLUR_BY 32
+#endif
 #define BLUR_R 11
 #define BLUR_TW (BLUR_BX + 2 * BLUR_R)
 #define BLUR_TH (BLUR_BY + 2 * BLUR_R)
@@ -848,7 +850,7 @@ __global__ __launch_bounds__(BLUR_THREADS, BLUR_WAVES) void k_sssr_blur(BlurArgs
   }
 #endif
   srgb_lut_stage(s_lut, tid, BLUR_THREADS);
-  blur_tile(a, xcd_block<4, 2>(), s_px, s_lut, tid);  // chunks of 128 x 64 output pixels
+  blur_tile(a, xcd_block<4, 64 / BLUR_BY>(), s_px, s_lut, tid);  // chunks of 128 x 64 output pixels
   VKR_STAMP(4);
 }
 
