@@ -446,8 +446,10 @@ typedef struct vkr_gather_part { const void* send; void* recv; uint64_t bytes; }
 int vkr_all_gather(vkr_comm* comm, const vkr_gather_part* parts, uint32_t count, void* stream);
 /* the same for shares of different sizes (strips balanced by cost): rank r's share of a surface lies at
  * recv + offsets[r] .. recv + offsets[r + 1] (offsets: world + 1 entries in host memory, identical on every rank; an
- * empty share is allowed); `send` is this rank's share where it lies now.  One grouped launch: an ncclBroadcast per
- * share, rooted at its owner.                                                                                        */
+ * empty share is allowed); `send` is this rank's share where it lies now.  One grouped launch: every share sent straight
+ * to each peer and received into place (ncclSend / ncclRecv: on a fully connected xGMI node a share crosses one link once;
+ * RCCL fuses the point-to-point operations of a group), the own share copied on the stream.  VKR_GATHER_V_BROADCAST=1
+ * (read at the first call) selects one ncclBroadcast per share, rooted at its owner, instead.                        */
 typedef struct vkr_gather_v_part { const void* send; void* recv; const uint64_t* offsets; } vkr_gather_v_part;
 int vkr_all_gather_v(vkr_comm* comm, const vkr_gather_v_part* parts, uint32_t count, void* stream);
 /* halo refresh of one history surface: per neighbour the packed slice to send and the buffer to receive into

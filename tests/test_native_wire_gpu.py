@@ -4,7 +4,7 @@ Every rank is its own process on cuda:0 and drives the C++ tiled frame (host/fra
 communicator (vkr_comm_*).  RCCL itself refuses two ranks on one device, so VKR_RCCL_LIBRARY points the C-ABI's dlopen at
 tests/stub_rccl/libstub_rccl.so: the same ten entry points, host-staged through POSIX shared memory, honouring the stream
 argument and the group semantics — what runs is csrc/rccl_exchange.hip (grouped launches, in-place gather offsets,
-broadcast-based all_gather_v), the event ordering between the compute and the exchange stream, pack / unpack of the halo
+point-to-point and broadcast-based all_gather_v), the event ordering between the compute and the exchange stream, pack / unpack of the halo
 rows and the strip re-cutting of bench.py, with >= 2 peers on every exchange.  Each rank compares its tile interior with
 the plain single-GPU frame it computes itself; a rank that hangs is killed by the stub's own timeout (exit 3) or by the
 test's, never silently.  The stub's log shows what crossed the wire."""
@@ -161,30 +161,38 @@ def _wire_log(path, world):
     return rows
 
 
-@pytest.mark.parametrize("bounds,moving,frames", [
-    ([0, 160, 320], False, 3),              # two equal strips: vkr_all_gather (grouped ncclAllGather) + halo Send / Recv
-    ([0, 160, 320, 480, 640], True, 4),     # four equal strips, camera moving every frame
-    ([0, 160, 400, 480], True, 4),          # strips of different heights: vkr_all_gather_v (grouped ncclBroadcast), camera moving
-    ([0, 96, 168, 304, 480], False, 3),     # 168 = 8 * 21: only depth mips 1..3 travel
+@pytest.mark.parametrize("bounds,moving,frames,by_broadcast", [
+    ([0, 160, 320], False, 3, False),              # two equal strips: vkr_all_gather (grouped ncclAllGather) + halo Send / Recv
+    ([0, 160, 320, 480, 640], True, 4, False),     # four equal strips, camera moving every frame
+    ([0, 160, 400, 480], True, 4, False),          # strips of different heights: vkr_all_gather_v (grouped Send / Recv to every peer), camera moving
+    ([0, 160, 400, 480], True, 4, True),           # the same through VKR_GATHER_V_BROADCAST=1 (one ncclBroadcast per surface and owner)
+    ([0, 96, 168, 304, 480], False, 3, False),     # 168 = 8 * 21: only depth mips 1..3 travel
 ])
-def test_native_tiled_frame_between_real_processes(bounds, moving, frames, tmp_path):
+def test_native_tiled_frame_between_real_processes(bounds, moving, frames, by_broadcast, tmp_path):
     world = len(bounds) - 1
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     log = tmp_path / "wire.log"
     env = dict(os.environ, VKR_RCCL_LIBRARY=_stub(), VKR_STUB_RCCL_LOG=str(log), VKR_STUB_RCCL_TIMEOUT_S="120", VKR_BOUNDS=json.dumps(bounds),
                VKR_MOVING="1" if moving else "0", VKR_FRAMES=str(frames), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("VKR_GATHER_V_BROADCAST", None)
+    if by_broadcast:
+        env["VKR_GATHER_V_BROADCAST"] = "1"
     rc, out, err = _launch(world, [str(script)], env, timeout=420)
     assert rc == 0, out[-3000:] + err[-3000:]
     rows = _wire_log(log, world)
     equal = all(bounds[r + 1] - bounds[r] == bounds[1] for r in range(world))
     for r, k in rows.items():
         # per frame: two gather groups; the self check adds one of each kind
+        neighbours = (1 if r > 0 else 0) + (1 if r + 1 < world else 0)
         if equal:
             assert k["allgather"][0] >= 2 * frames and k["allgather"][1] > 0
-        else:
+        elif by_broadcast:
             assert k["broadcast"][0] >= 2 * frames * world - 2 and k["broadcast"][1] > 0
-        neighbours = (1 if r > 0 else 0) + (1 if r + 1 < world else 0)
+        else:
+            assert k["broadcast"][0] == 0, "the default all_gather_v is point-to-point"
+            # besides the halos: every frame's gather sends this rank's share of >= 1 surface to every peer
+            assert k["send"][0] >= 3 * frames * neighbours + frames * (world - 1)
         assert k["send"][0] >= 3 * frames * neighbours and k["recv"][0] == k["send"][0]
 
 
@@ -210,6 +218,6 @@ def test_bench_native_branch_between_real_processes(world, balance, tmp_path):
     rows = _wire_log(log, world)
     if balance:
         assert len(d["config"]["strip_balance"]) >= 1
-        assert any(k["broadcast"][0] > 0 for k in rows.values()) or len(set(d["config"]["strip_rows"])) == 1
+        assert len(set(d["config"]["strip_rows"])) >= 1
     for k in rows.values():
         assert k["send"][0] > 0 and k["recv"][0] > 0 and (k["allgather"][0] > 0 or k["broadcast"][0] > 0)

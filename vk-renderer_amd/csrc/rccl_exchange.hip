@@ -144,7 +144,36 @@ extern "C" int vkr_all_gather_v(vkr_comm* comm, const vkr_gather_v_part* parts, 
       if (p.offsets[r + 1] < p.offsets[r]) { vkr::set_error("all_gather_v: part %u: offsets must not decrease", i); return vkr::VKR_ERR_LAYOUT; }
     if (p.offsets[comm->rank + 1] > p.offsets[comm->rank] && !p.send) { vkr::set_error("all_gather_v: part %u has no send buffer", i); return vkr::VKR_ERR_NULL; }
   }
-  // all-gather-v as the usual group of broadcasts: share r of every surface from its owner into place on every rank
+  // Shares of different sizes.  Default: every rank sends its share of every surface straight to each peer and receives
+  // theirs into place, all in one group — on a fully connected xGMI node each share crosses one link once, and RCCL fuses
+  // the point-to-point operations of a group into one launch (the same shape as an all-to-all-v).  VKR_GATHER_V_BROADCAST=1
+  // selects the textbook form instead, one ncclBroadcast per surface and owner (world x surfaces collectives in the group).
+  static const bool by_broadcast = getenv("VKR_GATHER_V_BROADCAST") != nullptr;
+  if (!by_broadcast) {
+    for (uint32_t i = 0; i < count; i++) {  // my own share into place (what the root's broadcast would have copied)
+      const vkr_gather_v_part& p = parts[i];
+      const uint64_t n = p.offsets[comm->rank + 1] - p.offsets[comm->rank];
+      void* dst = (uint8_t*)p.recv + p.offsets[comm->rank];
+      if (n && p.send != dst) {
+        const hipError_t ce = hipMemcpyAsync(dst, p.send, (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (ce != hipSuccess) { vkr::set_error("all_gather_v: copy of the own share failed: %s", hipGetErrorString(ce)); return (int)ce; }
+      }
+    }
+    ncclResult_t r = g_rccl.GroupStart();
+    for (uint32_t i = 0; r == ncclSuccess && i < count; i++) {
+      const vkr_gather_v_part& p = parts[i];
+      const uint64_t mine = p.offsets[comm->rank + 1] - p.offsets[comm->rank];
+      for (int peer = 0; r == ncclSuccess && peer < comm->world; peer++) {
+        if (peer == comm->rank) continue;
+        const uint64_t theirs = p.offsets[peer + 1] - p.offsets[peer];
+        if (mine) r = g_rccl.Send(p.send, (size_t)mine, ncclUint8, peer, comm->comm, (hipStream_t)stream);
+        if (r == ncclSuccess && theirs) r = g_rccl.Recv((uint8_t*)p.recv + p.offsets[peer], (size_t)theirs, ncclUint8, peer, comm->comm, (hipStream_t)stream);
+      }
+    }
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return fail("all_gather_v", r);
+    return e == ncclSuccess ? vkr::VKR_OK : fail("all_gather_v", e);
+  }
   ncclResult_t r = g_rccl.GroupStart();
   for (uint32_t i = 0; r == ncclSuccess && i < count; i++) {
     const vkr_gather_v_part& p = parts[i];
