@@ -478,10 +478,12 @@ typedef struct vkr_hit_sources {
   const vkr_img* pending_data;    /* every pending ray, outside half-res rows [normal_row0, normal_row1)                       */
   uint32_t normal_width, normal_height, normal_row0, normal_row1;
 } vkr_hit_sources;
-/* out == NULL: counts[o] += number of requests this rank has for owner o (counts: device, world entries, zeroed by the
- * caller).  out != NULL: writes them, owner o's from out[segments[o]] on (segments: host, world entries; cursors: device,
- * world entries, zeroed by the caller).                                                                                */
-int vkr_hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* cursors,
+/* Two passes over the same `src` and bounds.  Pass 1 (out == NULL): counts[o] += number of requests this rank has for
+ * owner o (counts: device, world entries, zeroed by the caller); with a workspace (device, VKR_HIT_WORKSPACE_WORDS uint32,
+ * no initialisation needed) it also leaves there what pass 2 needs.  Pass 2 (out != NULL; workspace as pass 1 filled it):
+ * writes the requests, owner o's from out[segments[o]] on (segments: host, world entries, the prefix sums of counts).    */
+#define VKR_HIT_WORKSPACE_WORDS 4096u
+int vkr_hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* workspace,
                      const uint32_t* segments, vkr_hit_request* out, void* stream);
 /* replies (device, 16 bytes each, 16-byte aligned): the texel pair(s) of requests[i] from this rank's albedo / downsampled-
  * normal window (normals may be NULL when no normal request can arrive); a request for texels the window does not hold

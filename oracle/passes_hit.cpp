@@ -29,8 +29,10 @@ void footprint(std::vector<Req>& out, float u, float v, int w, int h, uint32_t l
 }
 }  // namespace
 
-extern "C" int vkr_ref_hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* cursors,
+// (the product's fifth argument is a workspace its pass 1 leaves for its pass 2: no use here)
+extern "C" int vkr_ref_hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* /*workspace*/,
                                     const uint32_t* segments, vkr_hit_request* out) {
+  std::vector<uint32_t> cursors(world, 0u);
   Image RAYS(*src->rays);
   std::vector<Req> reqs;
   for (int ly = 0; ly < RAYS.h(); ly++)

@@ -144,7 +144,7 @@ def test_hit_requests_refuse_inconsistent_strips(lib):
     assert rc == ERR_EXTENT and "even" in msg
     rc, msg = _hit_requests(lib, src, [0, 256, 512], 2, counts=None)  # pass 1 needs the counters
     assert rc == ERR_NULL
-    rc, msg = _hit_requests(lib, src, [0, 256, 512], 2, out=FAKE)     # pass 2 needs cursors and segments
+    rc, msg = _hit_requests(lib, src, [0, 256, 512], 2, out=FAKE)     # pass 2 needs the workspace of pass 1 and the segments
     assert rc == ERR_NULL
     big = HitSources(C.pointer(rays), 32768, 512, 64, 192, None, None, 0, 0, 0, 0)
     rc, msg = _hit_requests(lib, big, [0, 256, 512], 2)

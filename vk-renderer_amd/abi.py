@@ -200,6 +200,7 @@ class HitSources(C.Structure):  # vkr_hit_sources
 
 
 HIT_BOTH_ROWS, HIT_NORMAL, HIT_REPLY_BYTES = 0x10000000, 0x20000000, 16
+HIT_WORKSPACE_WORDS = 4096  # include/vkr_postfx.h VKR_HIT_WORKSPACE_WORDS
 
 # name -> argument types *without* the trailing stream
 ENTRY_ARGS = {

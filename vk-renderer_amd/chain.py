@@ -295,8 +295,9 @@ class PostFxChain:
         """[requests this window has for owner o] (vkr_hit_requests pass 1)"""
         world = len(row_bounds) - 1
         counts = self._u32_buffer(world)
+        self._hit_workspace = self._u32_buffer(abi.HIT_WORKSPACE_WORDS)  # pass 1 leaves its per-block counts here for pass 2
         b = (C.c_uint32 * (world + 1))(*row_bounds)
-        self.call("hit_requests", C.byref(self._hit_sources(normals)), b, world, self._buf_ptr(counts), None, None, None)
+        self.call("hit_requests", C.byref(self._hit_sources(normals)), b, world, self._buf_ptr(counts), self._buf_ptr(self._hit_workspace), None, None)
         return [int(v) for v in self.buffer_to_host(counts)[:world]]
 
     def hit_write(self, row_bounds, counts, normals=True):
@@ -305,10 +306,10 @@ class PostFxChain:
         segments = [0]
         for c in counts:
             segments.append(segments[-1] + c)
-        out, cursors = self._u32_buffer(segments[-1]), self._u32_buffer(world)
+        out = self._u32_buffer(segments[-1])
         b = (C.c_uint32 * (world + 1))(*row_bounds)
         seg = (C.c_uint32 * world)(*segments[:world])
-        self.call("hit_requests", C.byref(self._hit_sources(normals)), b, world, None, self._buf_ptr(cursors), seg, self._buf_ptr(out))
+        self.call("hit_requests", C.byref(self._hit_sources(normals)), b, world, None, self._buf_ptr(self._hit_workspace), seg, self._buf_ptr(out))
         return out, segments
 
     def hit_reply(self, requests, count, normals=True):

@@ -32,38 +32,58 @@ struct HitReqArgs {
   int nw, nh;               // downsampled-normal frame extent (half-res)
   uint32_t nrow0, nrow1;    // the half-res rows held
   uint32_t* counts;         // pass 1: per owner
-  uint32_t* cursors;        // pass 2: per owner, zeroed by the caller
+  uint32_t* workspace;      // [block][HIT_MAX_WORLD]: what each block of pass 1 counted per owner; pass 2 turns it into the blocks' bases
   uint32_t seg[HIT_MAX_WORLD];  // pass 2: first request of owner o's segment
   vkr_hit_request* out;     // NULL: pass 1
 };
 
-// One thread per ray texel of the window.  Requests of a block are reserved per owner with one global atomic.
-__global__ __launch_bounds__(256) void k_hit_requests(HitReqArgs a) {
-  __shared__ uint32_t s_n[HIT_MAX_WORLD], s_base[HIT_MAX_WORLD];
-  const int tid = threadIdx.y * 64 + threadIdx.x;
-  if (tid < HIT_MAX_WORLD) s_n[tid] = 0u;
-  __syncthreads();
-  const int lx = blockIdx.x * 64 + threadIdx.x, ly = blockIdx.y * 4 + threadIdx.y;
-  // per ray and surface one request (both footprint rows from one owner) or two (the rows belong to different strips)
-  uint32_t code[4], owner[4], slot[4];
-  int n = 0;
-  bool have = false, pending = false;
-  f2 uv = mk2(0.0f, 0.0f);
-  const bool inside = lx < a.rays.w && ly < a.rays.h && blockIdx.y != gridDim.y - 1;
-  if (inside) {
-    const uint2 v = *(const uint2*)(a.rays.p + toff(a.rays, lx, ly, 8));
-    if ((v.y >> 16) != 0xFFFFu) { have = true; uv = mk2(unorm16_to_float(v.x & 0xFFFFu), unorm16_to_float(v.x >> 16)); }  // filter.comp:93-95: w != 1
-    if (a.has_normals) pending = *texel_ptr<uint8_t>(a.pend_mask, lx, ly) != 0u;
-  }
-  // the grid has one block row more than the window: its first thread stands for the ray texels OUTSIDE the frame that the
+// One thread per ray texel of a 64 x 16 tile.  A launch has at most HIT_BLOCKS blocks of 1024 threads; a block walks tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... of the window, HIT_BATCH of them at a time with all their ray loads in flight
+// together (one dependent load per tile and wave would leave the kernel waiting on memory latency).  Pass 1 adds the block's
+// requests per owner to the rank's counters with one atomic per owner and block — all counters of a rank share a cache
+// line, a device-scope atomic on one line costs ~11 ns whoever issues it, and one reservation per 64 x 4 tile (16 k tiles of
+// a 7680 x 540 strip) made this byte-moving kernel take 0.16 ms — and leaves what it counted in the workspace.  Pass 2 has
+// the same blocks walk the same tiles: a block's requests for owner o start at segment[o] + what the blocks before it
+// counted, so it needs neither a second count nor a global atomic (within a block's range the order is that of its LDS atomics).
+#define HIT_BLOCKS 256
+static_assert(HIT_BLOCKS * HIT_MAX_WORLD == VKR_HIT_WORKSPACE_WORDS, "the workspace holds one count per block and owner");
+#define HIT_BATCH 4
+#define HIT_TILE_H 16
+struct HitTile { int tiles_x, tiles_y; };  // tiles of the window plus one apron row of tiles (see hit_emit)
+struct HitRay { uint2 v; uint32_t pending; int lx, ly; bool inside, apron; };
+
+VKR_DEV HitRay hit_load(const HitReqArgs& a, const HitTile& g, int tile, int tid) {
+  HitRay r;
+  const int bx = tile % g.tiles_x, by = tile / g.tiles_x;
+  r.lx = bx * 64 + (tid & 63); r.ly = by * HIT_TILE_H + (tid >> 6);
+  const bool apron_row = by == g.tiles_y - 1;
+  r.inside = tile < g.tiles_x * g.tiles_y && r.lx < a.rays.w && r.ly < a.rays.h && !apron_row;
+  // the last row of tiles lies below the window: its first thread stands for the ray texels OUTSIDE the frame that the
   // filter's apron reads at the frame's left / right edge — they read 0, i.e. uv (0, 0) with w = 0 != 1: a hit
-  if (blockIdx.y == gridDim.y - 1 && blockIdx.x == 0 && tid == 0) { have = true; uv = mk2(0.0f, 0.0f); }
+  r.apron = tile < g.tiles_x * g.tiles_y && apron_row && bx == 0 && tid == 0;
+  r.v = make_uint2(0u, 0xFFFF0000u); r.pending = 0u;
+  if (r.inside) {
+    r.v = *(const uint2*)(a.rays.p + toff(a.rays, r.lx, r.ly, 8));
+    if (a.has_normals) r.pending = *texel_ptr<uint8_t>(a.pend_mask, r.lx, r.ly);
+  }
+  return r;
+}
+
+// per ray and surface one request (both footprint rows from one owner) or two (the rows belong to different strips)
+VKR_DEV int hit_emit(const HitReqArgs& a, const HitRay& r, uint32_t* code, uint32_t* owner) {
+  int n = 0;
+  bool have = false;
+  f2 uv = mk2(0.0f, 0.0f);
+  if (r.inside && (r.v.y >> 16) != 0xFFFFu) { have = true; uv = mk2(unorm16_to_float(r.v.x & 0xFFFFu), unorm16_to_float(r.v.x >> 16)); }  // filter.comp:93-95: w != 1
+  if (r.apron) have = true;
   // rows r0 <= r1 <= r0 + 1 of a footprint, [lo, hi) the rows held, shift: strips are cut at even full-res rows
   auto emit = [&](uint32_t r0, uint32_t r1, uint32_t x, uint32_t lo, uint32_t hi, uint32_t tag, uint32_t shift) {
     const bool want0 = r0 < lo || r0 >= hi, want1 = r1 != r0 && (r1 < lo || r1 >= hi);
+    if (!want0 && !want1) return;
+    // the owner of a row = how many strip boundaries lie at or below it: a loop over the (wave-uniform) boundaries, so that
+    // the table is read with a scalar index (a per-lane index into the kernel arguments is a waterfall loop)
     uint32_t o0 = 0, o1 = 0;
-    while (o0 + 1 < a.world && (r0 << shift) >= a.bounds[o0 + 1]) ++o0;
-    while (o1 + 1 < a.world && (r1 << shift) >= a.bounds[o1 + 1]) ++o1;
+    for (uint32_t k = 1; k < a.world; k++) { o0 += (r0 << shift) >= a.bounds[k] ? 1u : 0u; o1 += (r1 << shift) >= a.bounds[k] ? 1u : 0u; }
     if (want0 && want1 && o0 == o1) { code[n] = r0 | (x << 14) | VKR_HIT_BOTH_ROWS | tag; owner[n++] = o0; return; }
     if (want0) { code[n] = r0 | (x << 14) | tag; owner[n++] = o0; }
     if (want1) { code[n] = r1 | (x << 14) | tag; owner[n++] = o1; }
@@ -74,22 +94,49 @@ __global__ __launch_bounds__(256) void k_hit_requests(HitReqArgs a) {
     const int x0 = f2i(floorf(fx)), y0 = f2i(floorf(fy));
     emit((uint32_t)iclamp(y0, 0, a.ah - 1), (uint32_t)iclamp(y0 + 1, 0, a.ah - 1), (uint32_t)iclamp(x0, 0, a.aw - 2), a.win0, a.win1, 0u, 0u);
   }
-  if (pending) {
+  if (r.pending != 0u) {
     // texture(normal, hit uv) of the deferred test: sample<FmtRG16U>() on the half-res frame, the uv as the trace had it
-    const float4 hv = texel_ptr<float4>(a.pend_data, 2 * lx, ly)[1];
+    const float4 hv = texel_ptr<float4>(a.pend_data, 2 * r.lx, r.ly)[1];
     const float fx = cfma(hv.x, (float)a.nw, -0.5f), fy = cfma(hv.y, (float)a.nh, -0.5f);
     const int x0 = f2i(floorf(fx)), y0 = f2i(floorf(fy));
     emit((uint32_t)iclamp(y0, 0, a.nh - 1), (uint32_t)iclamp(y0 + 1, 0, a.nh - 1), (uint32_t)iclamp(x0, 0, a.nw - 2), a.nrow0, a.nrow1, VKR_HIT_NORMAL, 1u);
   }
-  for (int k = 0; k < n; k++) slot[k] = atomicAdd(&s_n[owner[k]], 1u);
+  return n;
+}
+
+__global__ __launch_bounds__(1024) void k_hit_requests(HitReqArgs a, HitTile g) {
+  __shared__ uint32_t s_n[HIT_MAX_WORLD], s_base[HIT_MAX_WORLD];
+  const int tid = threadIdx.x;
+  const int tiles = g.tiles_x * g.tiles_y;
+  if (tid < HIT_MAX_WORLD) { s_n[tid] = 0u; s_base[tid] = a.seg[tid]; }
   __syncthreads();
-  if (tid < (int)a.world && s_n[tid]) {
-    if (a.out) s_base[tid] = a.seg[tid] + atomicAdd(&a.cursors[tid], s_n[tid]);
-    else atomicAdd(&a.counts[tid], s_n[tid]);
+  if (a.out) {  // pass 2: my base per owner = the segment's start + everything the blocks before me counted in pass 1
+    const uint32_t o = (uint32_t)tid & (HIT_MAX_WORLD - 1);
+    uint32_t before = 0u;
+    for (uint32_t b = (uint32_t)tid / HIT_MAX_WORLD; b < blockIdx.x; b += 1024u / HIT_MAX_WORLD) before += a.workspace[b * HIT_MAX_WORLD + o];
+    if (before) atomicAdd(&s_base[o], before);
+    __syncthreads();
   }
-  if (!a.out) return;
+  uint32_t code[4], owner[4];
+  for (int first = blockIdx.x; first < tiles; first += gridDim.x * HIT_BATCH) {
+    HitRay r[HIT_BATCH];
+#pragma unroll
+    for (int j = 0; j < HIT_BATCH; j++) r[j] = hit_load(a, g, first + j * gridDim.x, tid);
+#pragma unroll
+    for (int j = 0; j < HIT_BATCH; j++) {
+      const int n = hit_emit(a, r[j], code, owner);
+      for (int k = 0; k < n; k++) {
+        const uint32_t slot = atomicAdd(&s_n[owner[k]], 1u);
+        if (a.out) a.out[s_base[owner[k]] + slot] = code[k];
+      }
+    }
+  }
+  if (a.out) return;
   __syncthreads();
-  for (int k = 0; k < n; k++) a.out[s_base[owner[k]] + slot[k]] = code[k];
+  if (tid < HIT_MAX_WORLD) {
+    if (a.workspace) a.workspace[blockIdx.x * HIT_MAX_WORLD + tid] = s_n[tid];
+    if (tid < (int)a.world && s_n[tid]) atomicAdd(&a.counts[tid], s_n[tid]);
+  }
 }
 
 // the texel pair of the requested row — and of the row below it for a two-row request — from the owner's window image of
@@ -131,9 +178,9 @@ __global__ __launch_bounds__(256) void k_hit_scatter(Tex frame_albedo, Tex frame
 
 using namespace vkr;
 
-extern "C" int vkr_hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* cursors,
+extern "C" int vkr_hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* workspace,
                                 const uint32_t* segments, vkr_hit_request* out, void* stream) {
-  if (!src || !row_bounds || (!out && !counts) || (out && (!cursors || !segments))) { set_error("hit_requests: NULL argument"); return VKR_ERR_NULL; }
+  if (!src || !row_bounds || (!out && !counts) || (out && (!workspace || !segments))) { set_error("hit_requests: NULL argument"); return VKR_ERR_NULL; }
   if (world < 1 || world > HIT_MAX_WORLD) { set_error("hit_requests: world %u (1..%d)", world, HIT_MAX_WORLD); return VKR_ERR_EXTENT; }
   if (src->albedo_width > 16384 || src->albedo_height > 16384) { set_error("hit_requests: a request packs row and column into 14 bits each (frame <= 16384)"); return VKR_ERR_EXTENT; }
   if (src->albedo_width < 2 || src->albedo_height < 1 || row_bounds[0] != 0 || row_bounds[world] != src->albedo_height ||
@@ -164,12 +211,13 @@ extern "C" int vkr_hit_requests(const vkr_hit_sources* src, const uint32_t* row_
     }
     a.nw = (int)src->normal_width; a.nh = (int)src->normal_height; a.nrow0 = src->normal_row0; a.nrow1 = src->normal_row1;
   }
-  a.counts = counts; a.cursors = cursors; a.out = out;
+  a.counts = counts; a.workspace = workspace; a.out = out;
   for (uint32_t r = 0; r < HIT_MAX_WORLD; r++) a.seg[r] = (out && r < world) ? segments[r] : 0u;
-  const dim3 block(64, 4);
-  dim3 grid = grid2d(a.rays.w, a.rays.h, block);
-  grid.y += 1;  // the extra row: see the kernel
-  hipLaunchKernelGGL(k_hit_requests, grid, block, 0, (hipStream_t)stream, a);
+  HitTile g;
+  g.tiles_x = (a.rays.w + 63) / 64;
+  g.tiles_y = (a.rays.h + HIT_TILE_H - 1) / HIT_TILE_H + 1;  // one more row of tiles: see hit_load
+  const int tiles = g.tiles_x * g.tiles_y;
+  hipLaunchKernelGGL(k_hit_requests, dim3((uint32_t)(tiles < HIT_BLOCKS ? tiles : HIT_BLOCKS)), dim3(1024), 0, (hipStream_t)stream, a, g);
   return launch_status("hit_requests");
 }
 

@@ -432,9 +432,10 @@ struct TiledFrame {
 
   // ---- hit colours by request / reply (frame.hpp; csrc/hit_exchange.hip) ------------------------------------------------
   struct HitState {
-    // device, every part 64-byte aligned (RCCL moves the counts): counts @0, cursors @HIT_CURSORS, reply errors @HIT_ERRORS,
+    // device, every part 64-byte aligned (RCCL moves the counts): counts @0, reply errors @HIT_ERRORS,
     // the gathered world x world matrix @HIT_MATRIX
     uint32_t* counts = nullptr;
+    uint32_t* workspace = nullptr;  // VKR_HIT_WORKSPACE_WORDS: what pass 1 of vkr_hit_requests leaves for pass 2
     uint32_t* host_counts = nullptr;  // pinned: world * world + 1
     vkr_hit_request* req_out = nullptr; uint8_t* reply_in = nullptr; uint64_t cap_out = 0;   // what I ask / get back
     vkr_hit_request* req_in = nullptr; uint8_t* reply_out = nullptr; uint64_t cap_in = 0;    // what I am asked / answer
@@ -466,6 +467,7 @@ struct TiledFrame {
     const uint32_t w = cfg.world;
     if (w > 16) throw std::runtime_error {"tiled frame: the request / reply exchange is laid out for at most 16 ranks"};
     hit.counts = (uint32_t*)gpu::device_alloc(sizeof(uint32_t) * HIT_WORDS);
+    hit.workspace = (uint32_t*)gpu::device_alloc(sizeof(uint32_t) * VKR_HIT_WORKSPACE_WORDS);
     check(hipHostMalloc((void**)&hit.host_counts, sizeof(uint32_t) * (w * w + 1), hipHostMallocDefault), "pinned counts");
     hit.out_seg.assign(w + 1, 0); hit.in_seg.assign(w + 1, 0);
     // room for what this rank can ask for — every ray of its window ending on another strip — and the same for what it
@@ -481,6 +483,7 @@ struct TiledFrame {
   }
   void hit_release() {
     gpu::device_free(hit.counts);
+    gpu::device_free(hit.workspace);
     if (hit.host_counts) (void)hipHostFree(hit.host_counts);
     gpu::device_free(hit.req_out); gpu::device_free(hit.reply_in); gpu::device_free(hit.req_in); gpu::device_free(hit.reply_out);
   }
@@ -501,7 +504,7 @@ struct TiledFrame {
     check(hipMemsetAsync(hit.counts, 0, sizeof(uint32_t) * HIT_MATRIX, compute), "memset");
     HitSources h;
     hit_sources(h);
-    if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, nullptr, nullptr, nullptr, compute) != 0)
+    if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, hit.workspace, nullptr, nullptr, compute) != 0)
       throw std::runtime_error {std::string {"hit_requests: "} + vkr_last_error()};
     hit.counted = true;
   }
@@ -540,7 +543,7 @@ struct TiledFrame {
     if (hit.out_seg[w]) {
       HitSources h;
       hit_sources(h);
-      if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, hit.counts + HIT_CURSORS, hit.out_seg.data(), hit.req_out, s) != 0)
+      if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, hit.workspace, hit.out_seg.data(), hit.req_out, s) != 0)
         throw std::runtime_error {std::string {"hit_requests: "} + vkr_last_error()};
     }
     uint32_t n = 0;
