@@ -608,7 +608,7 @@ struct TiledFrame {
     check(hipEventRecord(ev_done[VKRH_GATHER_ALBEDO], xchg), "event record");
   }
   static constexpr uint32_t HIT_PEERS = 16;
-  static constexpr uint32_t HIT_CURSORS = 16, HIT_ERRORS = 32, HIT_MATRIX = 64, HIT_WORDS = 64 + 256;  // world <= 16
+  static constexpr uint32_t HIT_ERRORS = 32, HIT_MATRIX = 64, HIT_WORDS = 64 + 256;  // world <= 16
 
   // ---- the frame, in phases (an exchange may only start / must be complete at a phase boundary) ------------------------
   void phase(uint32_t p) {
