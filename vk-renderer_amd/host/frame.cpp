@@ -498,13 +498,14 @@ struct TiledFrame {
       check(hipMemcpyAsync((uint8_t*)fn.base + uint64_t(n.origin_y) * fn.pitch_bytes[0], n.base, uint64_t(n.height) * n.pitch_bytes[0], hipMemcpyDeviceToDevice, s), "normal rows");
     }
   }
-  // pass 1, on the compute stream right after the trace
-  void hit_count() {
+  // pass 1, behind the trace on stream s (the harness: the compute stream; with a communicator: the exchange stream, so that
+  // GTAO starts right after the trace and the count runs beside it)
+  void hit_count(hipStream_t s) {
     const uint32_t w = cfg.world;
-    check(hipMemsetAsync(hit.counts, 0, sizeof(uint32_t) * HIT_MATRIX, compute), "memset");
+    check(hipMemsetAsync(hit.counts, 0, sizeof(uint32_t) * HIT_MATRIX, s), "memset");
     HitSources h;
     hit_sources(h);
-    if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, hit.workspace, nullptr, nullptr, compute) != 0)
+    if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, hit.workspace, nullptr, nullptr, s) != 0)
       throw std::runtime_error {std::string {"hit_requests: "} + vkr_last_error()};
     hit.counted = true;
   }
@@ -586,8 +587,9 @@ struct TiledFrame {
   // rest is enqueued on the exchange stream and ends in ev_done[VKRH_GATHER_ALBEDO], which the filter waits for.
   void hit_exchange_native() {
     const uint32_t w = cfg.world;
-    check(hipEventRecord(ev_ready[VKRH_GATHER_ALBEDO], compute), "event record");  // NOTE: recorded by the caller's order: after the count pass
+    check(hipEventRecord(ev_ready[VKRH_GATHER_ALBEDO], compute), "event record");  // the trace (and its pending images) are complete
     check(hipStreamWaitEvent(xchg, ev_ready[VKRH_GATHER_ALBEDO], 0), "stream wait");
+    hit_count(xchg);
     const vkr_gather_part part {hit.counts, hit.counts + HIT_MATRIX, uint64_t(w) * sizeof(uint32_t)};
     if (vkr_all_gather(cfg.comm, &part, 1, xchg) != 0) throw std::runtime_error {std::string {"exchange: "} + vkr_last_error()};
     check(hipMemcpyAsync(hit.host_counts, hit.counts + HIT_MATRIX, sizeof(uint32_t) * w * w, hipMemcpyDeviceToHost, xchg), "counts to host");
@@ -633,8 +635,8 @@ struct TiledFrame {
         wait(VKRH_GATHER_HIZ);
         f.run(VKRH_STAGE_HIZ_TAIL | VKRH_STAGE_SSR_TRACE);
         if (by_request()) {
-          hit_count();
-          if (cfg.comm) hit_exchange_native();
+          if (cfg.comm) hit_exchange_native();  // count -> all-gather of the counts -> host copy, all on the exchange stream
+          else hit_count(compute);
         }
         break;
       case 3:  // GTAO needs the trace's (occlusion, pdf) but not the albedo: it runs ahead of the reference's order to hide the second gather
