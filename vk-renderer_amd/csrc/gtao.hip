@@ -90,16 +90,30 @@ __global__ __launch_bounds__(GT_BX * GT_BY, 8) void k_gtao_main(GtaoArgs a) {
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   __shared__ float s_depth[GT_TW * GT_TH];
   const int tid = threadIdx.y * GT_BX + threadIdx.x;
-  srgb_lut_stage(s_lut, tid, GT_BX * GT_BY);
   DepthTile tile;
   tile.d = s_depth;
   tile.x0 = a.out.ox + blk.x * GT_BX - GT_R;
   tile.y0 = a.out.oy + blk.y * GT_BY - GT_R;
   tile.x0f = (float)tile.x0; tile.y0f = (float)tile.y0;
   tile.fw = (float)a.depth.fw; tile.fh = (float)a.depth.fh;
-  if (TILED)
-    for (int t = tid; t < GT_TW * GT_TH; t += GT_BX * GT_BY)
-      s_depth[t] = fetch_clamped<FmtD24>(a.depth, tile.x0 + t % GT_TW, tile.y0 + t / GT_TW);
+  // every load of the staging phase is issued before the first is waited for: the table entry and the <= 5 tile texels of a
+  // thread (one wait instead of six in a row: a block is 16 of the CU's 32 waves, and they all stand at this barrier)
+  constexpr int STAGE = (GT_TW * GT_TH + GT_BX * GT_BY - 1) / (GT_BX * GT_BY);
+  uint32_t raw[STAGE];
+  const uint32_t lut_bits = k_srgb_decode_bits[tid & (VKR_SRGB_LUT_SIZE - 1)];
+  if (TILED) {
+#pragma unroll
+    for (int k = 0; k < STAGE; k++) {
+      const int t = min(tid + k * GT_BX * GT_BY, GT_TW * GT_TH - 1);  // the last batch re-stages the last texel
+      const int lx = iclamp(tile.x0 + t % GT_TW - a.depth.ox, 0, a.depth.w - 1), ly = iclamp(tile.y0 + t / GT_TW - a.depth.oy, 0, a.depth.h - 1);
+      raw[k] = *(const uint32_t*)(a.depth.p + toff(a.depth, lx, ly, 4));
+    }
+  }
+  if (tid < VKR_SRGB_LUT_SIZE) s_lut[tid] = __uint_as_float(lut_bits);
+  if (TILED) {
+#pragma unroll
+    for (int k = 0; k < STAGE; k++) s_depth[min(tid + k * GT_BX * GT_BY, GT_TW * GT_TH - 1)] = FmtD24::decode(raw[k]);
+  }
   __syncthreads();
   const int lx = blk.x * GT_BX + threadIdx.x;
   const int ly = blk.y * GT_BY + threadIdx.y;
