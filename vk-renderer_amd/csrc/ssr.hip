@@ -117,10 +117,6 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   __shared__ uint16_t s_list[2][TRACE_THREADS];
   __shared__ int s_count[2];
   const int tid = threadIdx.x;
-  srgb_lut_stage(s_lut, tid, TRACE_THREADS);
-  if (tid < 16) s_mip[tid] = mip_descriptor(a.depth.mip[tid < a.depth.count ? tid : 0]);
-  if (tid < 2) s_count[tid] = 0;
-  __syncthreads();
   // wave w owns the 8x8 tile (blk.x*4 + w % 4, blk.y*TRACE_WY + w / 4)
   const int wave = tid >> 6, lane = tid & 63;
   const int lx = (blk.x * 4 + (wave & 3)) * 8 + (lane & 7);
@@ -131,6 +127,16 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   const f2 screen_uv = mk2(pixel_centre_uv(gx, tex_size.x), pixel_centre_uv(gy, tex_size.y));
   const Proj pr = a.pr;
   const Tex& depth0 = a.depth.mip[0];
+  // the pixel's three samples (trace.comp:49-58) are in flight before the block waits for its tables
+  // (every lane: the texel indices are clamped into the images, and a conditional load would have to be waited for at once)
+  const BilinearTaps taps_material = bilinear_taps_u32(a.material, screen_uv);
+  const BilinearTaps taps_depth = bilinear_taps_u32(depth0, screen_uv);
+  const BilinearTaps taps_normal = bilinear_taps_u32(a.normal, screen_uv);
+  const uint4 my_mip = mip_descriptor(a.depth.mip[(tid & 15) < a.depth.count ? (tid & 15) : 0]);  // (a load from the kernel arguments: every lane, with the others)
+  srgb_lut_stage(s_lut, tid, TRACE_THREADS);
+  if (tid < 16) s_mip[tid] = my_mip;
+  if (tid < 2) s_count[tid] = 0;
+  __syncthreads();
 
   MarchEnv env;
   env.mip_table = s_mip;
@@ -148,11 +154,11 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   bool running = false;
   if (active) {
     // trace.comp:49-58
-    roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
+    roughness = taps_srgb_channel(taps_material, 1, s_lut);
     const float mg = mixf(0.0f, a.max_roughness, roughness);
     roughness = mg * mg;
-    pixel_depth = sample<FmtD24>(depth0, screen_uv);
-    const f3 pixel_normal_world = decode_normal(sample<FmtRG16U>(a.normal, screen_uv));
+    pixel_depth = taps_resolve<FmtD24>(taps_depth);
+    const f3 pixel_normal_world = decode_normal(taps_resolve<FmtRG16U>(taps_normal));
     rc.normal = normalize(xyz(mul(a.normal_mat, mk4(pixel_normal_world.x, pixel_normal_world.y, pixel_normal_world.z, 0.0f))));
     rc.view_vec = reconstruct_view_vec(screen_uv, pixel_depth, pr);
 
@@ -356,22 +362,25 @@ __global__ __launch_bounds__(FILT_BX * FILT_BY) void k_sssr_filter(FilterArgs a)
   __shared__ float4 s_geo[FILT_TW * FILT_TH];  // {fresnel power term, NdotL, NdotV, depth}
   __shared__ float4 s_rad[FILT_TW * FILT_TH];  // radiance rgb
   const int tid = threadIdx.y * FILT_BX + threadIdx.x;
-  srgb_lut_stage(s_lut, tid, FILT_BX * FILT_BY);
-  __syncthreads();
 
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
   const int bx0 = a.out.ox + blk.x * FILT_BX - 1, by0 = a.out.oy + blk.y * FILT_BY - 1;
   // A tile none of whose rays (apron included) found a hit has radiance 0 at every tap: each pixel's colour sums stay
   // exactly 0 and the stored texel is 0 whatever the weights are (52 % of the tiles of the benchmark frame).  A ray
   // texel outside the frame reads 0, i.e. w != 1: it counts as a hit, as in the shader.
+  // (the sRGB table is staged behind the rays' loads of the check and shares their wait and barrier)
   if (a.skip_empty_tiles) {
     bool hit = false;
     for (int t = tid; t < FILT_TW * FILT_TH; t += FILT_BX * FILT_BY) hit = hit || fetch<FmtRGBA16U>(a.rays, bx0 + t % FILT_TW, by0 + t / FILT_TW).w != 1.0f;
+    srgb_lut_stage(s_lut, tid, FILT_BX * FILT_BY);
     if (__syncthreads_or(hit) == 0) {
       const int lx = blk.x * FILT_BX + threadIdx.x, ly = blk.y * FILT_BY + threadIdx.y;
       if (lx < a.out.w && ly < a.out.h) *texel_ptr<uint32_t>(a.out, lx, ly) = 0u;
       return;
     }
+  } else {
+    srgb_lut_stage(s_lut, tid, FILT_BX * FILT_BY);
+    __syncthreads();
   }
   for (int t = tid; t < FILT_TW * FILT_TH; t += FILT_BX * FILT_BY) {
     const int px = bx0 + t % FILT_TW, py = by0 + t / FILT_TW;
@@ -613,8 +622,8 @@ template <int R> VKR_DEV void blur_uniform_sigma(const uint4* s_px, const BlurCe
 }
 
 // one BLUR_BX x BLUR_BY tile of the output; s_px: the staged tile, one 16-byte record per pixel (blur_pack); s_lut: the sRGB
-// decode table (staged by the caller, visible after the barrier below)
-VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, uint4* s_px, const float* s_lut, const int tid) {
+// decode table (storage; staged inside, visible after the first barrier)
+VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, uint4* s_px, float* s_lut, const int tid) {
   const int bx0 = a.out.ox + blk.x * BLUR_BX - BLUR_R;  // frame coordinates of the tile origin
   const int by0 = a.out.oy + blk.y * BLUR_BY - BLUR_R;
   const f2 tex_size = mk2((float)a.out.fw, (float)a.out.fh);
@@ -653,6 +662,9 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, uint4* s_px, const float
     stage_refl[k] = in_refl ? c : 0u;
     lit |= stage_refl[k] & 0x00FFFFFFu;  // alpha is not read by the taps
   }
+  // the sRGB table is staged here, behind the loads above, so that its own load is waited for together with them (its
+  // readers come after the barriers below)
+  srgb_lut_stage(s_lut, tid, BLUR_THREADS);
   const bool empty_tile = a.skip_empty_tiles != 0 && __syncthreads_or(lit != 0u) == 0;
   if (!empty_tile) {
     BilinearTaps stage_normal[STAGE_ITERS];
@@ -849,8 +861,7 @@ __global__ __launch_bounds__(BLUR_THREADS, BLUR_WAVES) void k_sssr_blur(BlurArgs
     VKR_STAMP_VALUE(6, ((unsigned long long)xcc << 32) | hw);
   }
 #endif
-  srgb_lut_stage(s_lut, tid, BLUR_THREADS);
-  blur_tile(a, xcd_block<4, 64 / BLUR_BY>(), s_px, s_lut, tid);  // chunks of 128 x 64 output pixels
+  blur_tile(a, xcd_block<4, 64 / BLUR_BY>(), s_px, s_lut, tid);  // chunks of 128 x 64 output pixels; stages s_lut
   VKR_STAMP(4);
 }
 
