@@ -49,11 +49,38 @@ VKR_DEV BilinearTaps taps_at(const Tex& t, const Footprint& f) {
 
 // SHARED: colour, velocity and current depth have one window geometry and pitch (the launcher checks), so the three
 // samples at screen_uv share one footprint.
-template <bool SHARED>
+// TILED (implies SHARED): the three images also have the output's full extent, so texture(., screen_uv) of pixel g lands on
+// the texels {g - 1, g} x {g - 1, g} or {g, g + 1} x {g, g + 1} (pixel-centre uv: uv * size - 0.5 is g up to 3e-4).  The
+// 66 x 6 texels a 64 x 4 block can touch are then staged once per block in LDS — each loaded by one thread instead of by
+// up to four, 1.5 instead of 4 loads per pixel and image — with the clamp-to-edge of the sampler applied while staging,
+// and the taps read them there.  The pass is bound by the number of loads it issues (DESIGN_EXPERIMENTS.md A.8).
+#define TAA_TW 66
+#define TAA_TH 6
+template <bool SHARED, bool TILED>
 __global__ __launch_bounds__(256) void k_taa_resolve(TaaArgs a) {
   const i2 blk = xcd_block<2, 16>();  // chunks of 128 x 64 output pixels
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
-  srgb_lut_stage(s_lut, threadIdx.y * blockDim.x + threadIdx.x, 256);
+  __shared__ uint32_t s_col[TILED ? TAA_TW * TAA_TH : 1], s_vel[TILED ? TAA_TW * TAA_TH : 1], s_dep[TILED ? TAA_TW * TAA_TH : 1];
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  const int tile_x0 = a.out.ox + blk.x * 64 - 1, tile_y0 = a.out.oy + blk.y * 4 - 1;  // frame coordinates of tile texel (0, 0)
+  if (TILED) {
+    // both staging passes' loads (and the table's) are in flight together; texels past the tile's end re-stage its last one
+    uint32_t off[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int t = min(tid + k * 256, TAA_TW * TAA_TH - 1);
+      const int cx = iclamp(tile_x0 + t % TAA_TW - a.color.ox, 0, a.color.w - 1), cy = iclamp(tile_y0 + t / TAA_TW - a.color.oy, 0, a.color.h - 1);
+      off[k] = __umul24((uint32_t)cy, (uint32_t)a.color.pitch) + (uint32_t)cx * 4u;
+    }
+    const uint32_t c0 = *(const uint32_t*)(a.color.p + off[0]), v0 = *(const uint32_t*)(a.velocity.p + off[0]), d0 = *(const uint32_t*)(a.cur_depth.p + off[0]);
+    const uint32_t c1 = *(const uint32_t*)(a.color.p + off[1]), v1 = *(const uint32_t*)(a.velocity.p + off[1]), d1 = *(const uint32_t*)(a.cur_depth.p + off[1]);
+    srgb_lut_stage(s_lut, tid, 256);
+    s_col[tid] = c0; s_vel[tid] = v0; s_dep[tid] = d0;
+    const int t1 = min(tid + 256, TAA_TW * TAA_TH - 1);
+    s_col[t1] = c1; s_vel[t1] = v1; s_dep[t1] = d1;
+  } else {
+    srgb_lut_stage(s_lut, tid, 256);
+  }
   __syncthreads();
   const int lx = blk.x * blockDim.x + threadIdx.x;
   const int ly = blk.y * blockDim.y + threadIdx.y;
@@ -61,9 +88,26 @@ __global__ __launch_bounds__(256) void k_taa_resolve(TaaArgs a) {
   const int gx = a.out.ox + lx, gy = a.out.oy + ly;
   // (g + 0.5) / size: both operands and the quotient are far inside the normal range
   const f2 screen_uv = mk2(pixel_centre_uv(gx, (float)a.out.fw), pixel_centre_uv(gy, (float)a.out.fh));
-  const Footprint fc = footprint4(a.color, screen_uv);
-  const Footprint fv = SHARED ? fc : footprint4(a.velocity, screen_uv);
-  const BilinearTaps tc = taps_at(a.color, fc), tv = taps_at(a.velocity, fv);
+  Footprint fc, fv;
+  BilinearTaps tc, tv, td_tile;
+  if (TILED) {
+    // the sampler's arithmetic (footprint4) up to the texel indices, which are taken relative to the tile; they cannot leave
+    // it (see above) and are clamped into it all the same
+    const float x = cfma(screen_uv.x, (float)a.color.fw, -0.5f), y = cfma(screen_uv.y, (float)a.color.fh, -0.5f);
+    const float x0f = floorf(x), y0f = floorf(y);
+    const int ix = iclamp(f2i(x0f) - tile_x0, 0, TAA_TW - 2), iy = iclamp(f2i(y0f) - tile_y0, 0, TAA_TH - 2);
+    const int i00 = iy * TAA_TW + ix;
+    tc.fx = tv.fx = td_tile.fx = x - x0f; tc.fy = tv.fy = td_tile.fy = y - y0f;
+    tc.t00 = s_col[i00]; tc.t10 = s_col[i00 + 1]; tc.t01 = s_col[i00 + TAA_TW]; tc.t11 = s_col[i00 + TAA_TW + 1];
+    tv.t00 = s_vel[i00]; tv.t10 = s_vel[i00 + 1]; tv.t01 = s_vel[i00 + TAA_TW]; tv.t11 = s_vel[i00 + TAA_TW + 1];
+    td_tile.t00 = s_dep[i00]; td_tile.t10 = s_dep[i00 + 1]; td_tile.t01 = s_dep[i00 + TAA_TW]; td_tile.t11 = s_dep[i00 + TAA_TW + 1];
+    fc = Footprint {}; fv = fc;
+  } else {
+    fc = footprint4(a.color, screen_uv);
+    fv = SHARED ? fc : footprint4(a.velocity, screen_uv);
+    tc = taps_at(a.color, fc); tv = taps_at(a.velocity, fv);
+    td_tile = tc;  // (unused)
+  }
   const f2 velocity = taps_resolve<FmtRG16F>(tv);
   const f2 prev_uv = screen_uv + velocity;
   const bool inside = prev_uv.x >= 0.0f && prev_uv.y >= 0.0f && prev_uv.x <= 1.0f && prev_uv.y <= 1.0f;
@@ -113,8 +157,13 @@ __global__ __launch_bounds__(256) void k_taa_resolve(TaaArgs a) {
     bool reprojected = d2 < a.still_d2;
     if (!reprojected) {
       const float delta_len = sqrtf(d2);
-      const Footprint fd = SHARED ? fc : footprint4(a.cur_depth, screen_uv);
-      const f3 vc = reconstruct_view_vec(screen_uv, taps_resolve<FmtD24>(taps_at(a.cur_depth, fd)), a.pr);
+      float cur_depth;
+      if (TILED) cur_depth = taps_resolve<FmtD24>(td_tile);
+      else {
+        const Footprint fd = SHARED ? fc : footprint4(a.cur_depth, screen_uv);
+        cur_depth = taps_resolve<FmtD24>(taps_at(a.cur_depth, fd));
+      }
+      const f3 vc = reconstruct_view_vec(screen_uv, cur_depth, a.pr);
       const f3 v_world_cur = xyz(mul(a.inverse_camera, mk4(vc.x, vc.y, vc.z, 1.0f)));
       const f3 vp = reconstruct_view_vec(prev_uv, sample<FmtD24>(a.hist_depth, prev_uv), a.pr);
       const f3 v_world_prev = xyz(mul(a.prev_inverse_camera, mk4(vp.x, vp.y, vp.z, 1.0f)));
@@ -171,8 +220,11 @@ extern "C" int vkr_taa_resolve(const vkr_img* history_color, const vkr_img* hist
   a.pr.zfar = params->fovy_aspect_znear_zfar[3];
   a.still_d2 = sqrt_threshold(0.005f);
   const bool shared = same_layout(a.color, a.velocity) && same_layout(a.color, a.cur_depth) && !(switches() & VKR_SWITCH_TAA_GENERIC);
+  // the block's footprint tile needs texture(., screen_uv) to land next to the pixel: the images' full extent is the output's
+  const bool tiled = shared && a.color.fw == a.out.fw && a.color.fh == a.out.fh && a.color.w >= 2 && a.color.h >= 2;
   dim3 block(64, 4);
-  if (shared) hipLaunchKernelGGL(k_taa_resolve<true>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_taa_resolve<false>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  if (tiled) hipLaunchKernelGGL((k_taa_resolve<true, true>), grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  else if (shared) hipLaunchKernelGGL((k_taa_resolve<true, false>), grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_taa_resolve<false, false>), grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   return launch_status("taa_resolve");
 }
