@@ -54,30 +54,39 @@ VKR_DEV BilinearTaps taps_at(const Tex& t, const Footprint& f) {
 // 66 x 6 texels a 64 x 4 block can touch are then staged once per block in LDS — each loaded by one thread instead of by
 // up to four, 1.5 instead of 4 loads per pixel and image — with the clamp-to-edge of the sampler applied while staging,
 // and the taps read them there.  The pass is bound by the number of loads it issues (DESIGN_EXPERIMENTS.md A.8).
-#define TAA_TW 66
-#define TAA_TH 6
+#ifndef TAA_BX
+#define TAA_BX 64
+#endif
+#define TAA_BY (256 / TAA_BX)
+#define TAA_TW (TAA_BX + 2)
+#define TAA_TH (TAA_BY + 2)
+#define TAA_STAGE ((TAA_TW * TAA_TH + 255) / 256)
 template <bool SHARED, bool TILED>
 __global__ __launch_bounds__(256) void k_taa_resolve(TaaArgs a) {
-  const i2 blk = xcd_block<2, 16>();  // chunks of 128 x 64 output pixels
+  const i2 blk = xcd_block<128 / TAA_BX, 64 / TAA_BY>();  // chunks of 128 x 64 output pixels
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   __shared__ uint32_t s_col[TILED ? TAA_TW * TAA_TH : 1], s_vel[TILED ? TAA_TW * TAA_TH : 1], s_dep[TILED ? TAA_TW * TAA_TH : 1];
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
-  const int tile_x0 = a.out.ox + blk.x * 64 - 1, tile_y0 = a.out.oy + blk.y * 4 - 1;  // frame coordinates of tile texel (0, 0)
+  const int tile_x0 = a.out.ox + blk.x * TAA_BX - 1, tile_y0 = a.out.oy + blk.y * TAA_BY - 1;  // frame coordinates of tile texel (0, 0)
   if (TILED) {
     // both staging passes' loads (and the table's) are in flight together; texels past the tile's end re-stage its last one
-    uint32_t off[2];
+    uint32_t off[TAA_STAGE], c[TAA_STAGE], v[TAA_STAGE], d[TAA_STAGE];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < TAA_STAGE; k++) {
       const int t = min(tid + k * 256, TAA_TW * TAA_TH - 1);
       const int cx = iclamp(tile_x0 + t % TAA_TW - a.color.ox, 0, a.color.w - 1), cy = iclamp(tile_y0 + t / TAA_TW - a.color.oy, 0, a.color.h - 1);
       off[k] = __umul24((uint32_t)cy, (uint32_t)a.color.pitch) + (uint32_t)cx * 4u;
     }
-    const uint32_t c0 = *(const uint32_t*)(a.color.p + off[0]), v0 = *(const uint32_t*)(a.velocity.p + off[0]), d0 = *(const uint32_t*)(a.cur_depth.p + off[0]);
-    const uint32_t c1 = *(const uint32_t*)(a.color.p + off[1]), v1 = *(const uint32_t*)(a.velocity.p + off[1]), d1 = *(const uint32_t*)(a.cur_depth.p + off[1]);
+#pragma unroll
+    for (int k = 0; k < TAA_STAGE; k++) {
+      c[k] = *(const uint32_t*)(a.color.p + off[k]); v[k] = *(const uint32_t*)(a.velocity.p + off[k]); d[k] = *(const uint32_t*)(a.cur_depth.p + off[k]);
+    }
     srgb_lut_stage(s_lut, tid, 256);
-    s_col[tid] = c0; s_vel[tid] = v0; s_dep[tid] = d0;
-    const int t1 = min(tid + 256, TAA_TW * TAA_TH - 1);
-    s_col[t1] = c1; s_vel[t1] = v1; s_dep[t1] = d1;
+#pragma unroll
+    for (int k = 0; k < TAA_STAGE; k++) {
+      const int t = min(tid + k * 256, TAA_TW * TAA_TH - 1);
+      s_col[t] = c[k]; s_vel[t] = v[k]; s_dep[t] = d[k];
+    }
   } else {
     srgb_lut_stage(s_lut, tid, 256);
   }
@@ -222,7 +231,7 @@ extern "C" int vkr_taa_resolve(const vkr_img* history_color, const vkr_img* hist
   const bool shared = same_layout(a.color, a.velocity) && same_layout(a.color, a.cur_depth) && !(switches() & VKR_SWITCH_TAA_GENERIC);
   // the block's footprint tile needs texture(., screen_uv) to land next to the pixel: the images' full extent is the output's
   const bool tiled = shared && a.color.fw == a.out.fw && a.color.fh == a.out.fh && a.color.w >= 2 && a.color.h >= 2;
-  dim3 block(64, 4);
+  dim3 block(TAA_BX, TAA_BY);
   if (tiled) hipLaunchKernelGGL((k_taa_resolve<true, true>), grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   else if (shared) hipLaunchKernelGGL((k_taa_resolve<true, false>), grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_taa_resolve<false, false>), grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
