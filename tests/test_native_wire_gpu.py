@@ -167,6 +167,7 @@ def _wire_log(path, world):
     ([0, 160, 400, 480], True, 4, False),          # strips of different heights: vkr_all_gather_v (grouped Send / Recv to every peer), camera moving
     ([0, 160, 400, 480], True, 4, True),           # the same through VKR_GATHER_V_BROADCAST=1 (one ncclBroadcast per surface and owner)
     ([0, 96, 168, 304, 480], False, 3, False),     # 168 = 8 * 21: only depth mips 1..3 travel
+    ([0, 128, 224, 352, 480, 640], True, 3, False),  # five ranks (one below the box's limit of processes on the card), uneven strips
 ])
 def test_native_tiled_frame_between_real_processes(bounds, moving, frames, by_broadcast, tmp_path):
     world = len(bounds) - 1
