@@ -31,6 +31,58 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _gpus_requested(argv):
+    """--gpus N from the command line, before argparse (and before anything that could touch the GPU) runs"""
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks as CHILD processes through
+    torch.distributed.run — before this process has imported torch or loaded a HIP library, and never by exec — relay the
+    one JSON line rank 0 prints, and leave with the children's status.  A run that does not finish within
+    VKR_BENCH_LAUNCH_TIMEOUT seconds (default 1500) is killed with its whole process group and the exit status is 124."""
+    import signal
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, VKR_BENCH_SELF_LAUNCHED="1")
+    limit = float(os.environ.get("VKR_BENCH_LAUNCH_TIMEOUT", "1500"))
+    print(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks ({' '.join(cmd[1:9])} ...)", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        out, _ = child.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"[bench] the {n}-rank run did not finish within {limit:.0f} s: killing it", file=sys.stderr, flush=True)
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.wait()
+        return 124
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.strip()]
+    if child.returncode == 0 and len(lines) != 1:
+        print(f"[bench] expected ONE line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    for ln in lines:
+        print(ln, flush=True)
+    return child.returncode
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _gpus_requested(sys.argv[1:]) > 1:
+    sys.exit(self_launch(_gpus_requested(sys.argv[1:])))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -126,6 +178,9 @@ def main():
                     help="BASELINE.json configs: c1 1920x1080 GTAO main only (non-MIS); c2 3840x2160 composite (default at N = 1, the "
                          "metric's config); c3 7680x4320 composite (analytic scene: Sponza.bin is absent from the reference mount); "
                          "c4 15360x8640 composite tiled over the ranks (default at N > 1); c5 3840x2160 with 8 x (trace, filter, blur) + TAA")
+    ap.add_argument("--material", default="flat", choices=["flat", "textured"],
+                    help="synthetic scene: 'flat' = one roughness per object (the frozen scene the metric is quoted on); 'textured' = "
+                         "roughness perturbed per texel (VKR_SYNTH_TEXTURED_ROUGHNESS): the blur's sigma varies inside every wavefront")
     ap.add_argument("--shading", action="store_true", help="add the deferred-shading composite (SURVEY 8(f) #1) between GTAO and TAA")
     args = ap.parse_args()
     if args.config is None:
@@ -216,7 +271,7 @@ def main():
     if W % cols or H % rows:
         raise SystemExit(f"frame {W}x{H} does not divide into a {cols}x{rows} grid")
     tw, th = W // cols, H // rows
-    setup = FrameSetup(W, H, use_mis=0 if args.config == "c1" else 1)
+    setup = FrameSetup(W, H, use_mis=0 if args.config == "c1" else 1, material=args.material)
     tiled = TiledFrame(setup, rank, world, cols, rows, device, force_tiled=args.rehearse_tiled, native=comm is not None, comm=comm)
     frame = tiled.frame
     frame.set_async(args.overlap)
@@ -364,22 +419,29 @@ def main():
 
     # The headline depends on the frame's content: tiles of the blur / filter without a reflection / hit skip their taps
     # (bit-identical output).  A second, short timed loop with the skips switched off gives the content-independent number.
-    noskip_ms = None
+    noskip_ms = generic_ms = None
     if world == 1 and args.config in ("c2", "c3", "c4", "c5") and not args.no_noskip:
         lib = abi.product()
         before = lib.vkr_get_switches()
-        lib.vkr_set_switches(before | abi.SWITCH_BLUR_NO_SKIP | abi.SWITCH_FILTER_NO_SKIP)
         NOSKIP_STEPS = max(10, min(args.steps, 20))
-        for _ in range(3):
-            tiled.step()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(NOSKIP_STEPS):
-            tiled.step()
-        tiled.flush()
-        barrier()
-        noskip_ms = (time.perf_counter() - t1) / NOSKIP_STEPS * 1e3
-        lib.vkr_set_switches(before)
+
+        def timed_with(switches):
+            lib.vkr_set_switches(before | switches)
+            for _ in range(3):
+                tiled.step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(NOSKIP_STEPS):
+                tiled.step()
+            tiled.flush()
+            barrier()
+            dt = (time.perf_counter() - t1) / NOSKIP_STEPS * 1e3
+            lib.vkr_set_switches(before)
+            return dt
+
+        noskip_ms = timed_with(abi.SWITCH_BLUR_NO_SKIP | abi.SWITCH_FILTER_NO_SKIP)
+        # ... and with the blur's wave-uniform-sigma path off as well: nothing left that depends on what the frame shows
+        generic_ms = timed_with(abi.SWITCH_BLUR_NO_SKIP | abi.SWITCH_FILTER_NO_SKIP | abi.SWITCH_BLUR_GENERIC)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
@@ -439,7 +501,9 @@ def main():
                 "strip_rows": [row_bounds[r + 1] - row_bounds[r] for r in range(world)],
                 "strip_balance": balance_log,  # per balancing pass: the strips and every rank's compute time with them
                 "exchange": exchange,
+                "launcher": "self (bench.py started its ranks)" if os.environ.get("VKR_BENCH_SELF_LAUNCHED") == "1" else ("torch.distributed.run" if world > 1 else "none"),
                 "gbuffer": "rasterised procedural mesh scene (GbufferPass timed)" if args.raster else "analytic generator (not timed)",
+                "material": args.material + (" (one roughness per object)" if args.material == "flat" else " (roughness per texel, VKR_SYNTH_TEXTURED_ROUGHNESS)"),
             },
             "roofline": {
                 "bound": "hbm",
@@ -475,6 +539,11 @@ def main():
             out["ms_per_step_noskip"] = noskip_ms
             out["value_noskip"] = px / (noskip_ms * 1e-3) / 1e6
             out["noskip_note"] = "second timed loop with VKR_SWITCH_BLUR_NO_SKIP | VKR_SWITCH_FILTER_NO_SKIP: every tap evaluated, same output"
+        if generic_ms is not None:
+            out["ms_per_step_generic"] = generic_ms
+            out["value_generic"] = px / (generic_ms * 1e-3) / 1e6
+            out["generic_note"] = ("third timed loop: the skips off AND VKR_SWITCH_BLUR_GENERIC (every blur wave on the per-lane-sigma loop): "
+                                   "the time of a frame whose content helps nowhere")
         if world > 1 and (W, H) == (C4_W, C4_H):
             # the denominator of the scaling curve: the SAME 15360x8640 frame on one GPU (python bench.py --config c4 --gpus 1)
             ref_path = os.path.join(ROOT, "profiles", "r03_bench_c4_n1.json")

@@ -217,9 +217,13 @@ typedef struct vkr_synth_params {
   vkr_mat4 mvp;               /* projection * current view                           */
   float    fovy, aspect, znear, zfar;
   uint32_t seed;              /* PCG32 stream for the checker / per-object material  */
-  uint32_t flags;             /* bit0: depth only (used for prev_depth)              */
+  uint32_t flags;             /* VKR_SYNTH_*                                          */
 } vkr_synth_params;
-#define VKR_SYNTH_DEPTH_ONLY 1u
+#define VKR_SYNTH_DEPTH_ONLY 1u          /* depth attachment only (used for prev_depth)                                        */
+/* Second material mode: the roughness of an object is perturbed PER TEXEL (+-0.15, PCG hash of the pixel), like a roughness
+ * texture: the blur's sigma (blur.comp:44-75) and the trace's lobe then vary inside every wavefront.  The default scene has
+ * one roughness per object, which the SSR blur's wave-uniform-sigma path and empty-tile skips exploit.                    */
+#define VKR_SYNTH_TEXTURED_ROUGHNESS 2u
 
 /* ---- entry points ------------------------------------------------------------------- */
 

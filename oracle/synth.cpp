@@ -131,7 +131,13 @@ extern "C" int vkr_ref_synth_gbuffer(const vkr_img* depth, const vkr_img* normal
       vec2 en = encode_normal(nrm);
       N.store(gx, gy, vec4(en.x, en.y, 0, 0));
       A.store(gx, gy, vec4(om.base * checker, 1.0f));
-      M.store(gx, gy, vec4(0.5f, om.roughness, om.metallic, 0.5f));
+      float roughness = om.roughness;
+      if (params->flags & VKR_SYNTH_TEXTURED_ROUGHNESS) {  // per-texel roughness (include/vkr_postfx.h)
+        const float n = u01(hash3((uint32_t)gx, (uint32_t)gy, seed ^ 0x7E57u)) - 0.5f;
+        roughness = roughness + 0.3f * n;
+        roughness = roughness < 0.02f ? 0.02f : (roughness > 1.0f ? 1.0f : roughness);
+      }
+      M.store(gx, gy, vec4(0.5f, roughness, om.metallic, 0.5f));
       vec4 cp = prev_mvp * vec4(P, 1.0f), cc = mvp * vec4(P, 1.0f);
       vec2 vel(0.5f * (cp.x / cp.w - cc.x / cc.w), 0.5f * (cp.y / cp.w - cc.y / cc.w));
       V.store(gx, gy, vec4(vel.x, vel.y, 0, 0));

@@ -47,9 +47,11 @@ def _ensure_backend(backend):
         binding.install(build_if_missing=True)
 
 
-def run_chain(backend="oracle", device=None):
+def run_chain(backend="oracle", device=None, material="flat"):
     _ensure_backend(backend)
-    c = PostFxChain(W, H, backend=backend, device=device)
+    from vk_renderer_amd.camera import FrameSetup
+
+    c = PostFxChain(W, H, backend=backend, device=device, setup=FrameSetup(W, H, material=material))
     c.synth()
     c.build_prev_hiz()
     c.init_histories()
@@ -135,6 +137,17 @@ def main():
         data[name + "__crop"] = crop(img)
     data["pdf__spot"] = c.pdf.decode()[[100, 512, 900], :, 0][:, [100, 512, 900]]
     out = fixture("chain_256x144")
+    np.savez_compressed(out, **data)
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+    # the second material mode (VKR_SYNTH_TEXTURED_ROUGHNESS): roughness per texel
+    c = run_chain(material="textured")
+    data = {}
+    for name in IMAGES:
+        img = getattr(c, name)
+        data[name + "__sha256"] = np.array(digest(img))
+        data[name + "__crop"] = crop(img)
+    out = fixture("textured_256x144")
     np.savez_compressed(out, **data)
     print("wrote", out, os.path.getsize(out), "bytes")
 

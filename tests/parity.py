@@ -22,9 +22,25 @@ def record(name, texels, bit_equal, outside_tol, max_abs_diff, rule):
                  "max_abs_diff": float(max_abs_diff), "rule": rule})
 
 
+def _srgb_table():
+    c = np.arange(256, dtype=np.float64) / 255.0
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+
 def storage_step(fmt, ref):
-    if fmt in (abi.FMT_RGBA8_UNORM, abi.FMT_RGBA8_SRGB, abi.FMT_R8_UNORM):
+    if fmt in (abi.FMT_RGBA8_UNORM, abi.FMT_R8_UNORM):
         return np.full_like(ref, 1.0 / 255.0)
+    if fmt == abi.FMT_RGBA8_SRGB:
+        # one stored CODE: in linear light the gap between neighbouring codes grows from 3e-4 (dark) to 8.6e-3 (code 254 -> 255),
+        # so "1 / 255" is less than one code for every texel brighter than code 124.  The step at a
+        # decoded value is the larger of the gaps to its two neighbours; alpha is stored linearly.
+        t = _srgb_table()
+        code = np.clip(np.searchsorted(t, ref.astype(np.float64) - 1e-9), 0, 255)
+        gap = np.maximum(t[np.minimum(code + 1, 255)] - t[code], t[code] - t[np.maximum(code - 1, 0)])
+        step = gap.astype(np.float32)
+        if ref.ndim == 3 and ref.shape[-1] == 4:
+            step[..., 3] = 1.0 / 255.0
+        return step
     if fmt in (abi.FMT_RG16_UNORM, abi.FMT_RGBA16_UNORM):
         return np.full_like(ref, 1.0 / 65535.0)
     if fmt in (abi.FMT_RG16_SFLOAT, abi.FMT_RGBA16_SFLOAT, abi.FMT_R16_SFLOAT):

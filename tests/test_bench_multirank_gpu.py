@@ -40,3 +40,17 @@ def test_bench_line_of_a_multi_rank_run(world):
     assert abs(d["value"] - 512 * 288 * world / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
     assert d["roofline"]["kernel"] in d["per_pass_ms"] and d["roofline"]["frac"] > 0
     assert "cpu_baseline" not in d  # rank 0, N = 1 only
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the parent starts the ranks as child processes before
+    it touches the GPU, relays rank 0's one line and exits with their status."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VKR_BENCH_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--frame", "512x576"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["grid"] == [1, 2] and d["config"]["launcher"] == "self (bench.py started its ranks)"

@@ -151,6 +151,15 @@ def _launch(world, script_args, env, timeout):
     return p.returncode, out, err
 
 
+def _workers_stderr(err, keep=6000):
+    """what the ranks themselves wrote: torchrun's per-rank failure table (8 lines per rank, after the workers' own
+    tracebacks) used to push the cause out of the last 3000 characters the assertion shows"""
+    lines = err.splitlines()
+    cut = next((i for i, ln in enumerate(lines) if "ChildFailedError" in ln or "Root Cause (first observed failure)" in ln), len(lines))
+    own = [ln for ln in lines[:cut] if ln.strip() and not ln.startswith(("W1", "W0", "E1", "E0", "I1", "I0")) or "Error" in ln]
+    return "\n".join(own)[-keep:]
+
+
 def _wire_log(path, world):
     rows = {}
     for ln in open(path).read().splitlines():
@@ -167,7 +176,11 @@ def _wire_log(path, world):
     ([0, 160, 400, 480], True, 4, False),          # strips of different heights: vkr_all_gather_v (grouped Send / Recv to every peer), camera moving
     ([0, 160, 400, 480], True, 4, True),           # the same through VKR_GATHER_V_BROADCAST=1 (one ncclBroadcast per surface and owner)
     ([0, 96, 168, 304, 480], False, 3, False),     # 168 = 8 * 21: only depth mips 1..3 travel
-    ([0, 128, 224, 352, 480, 640], True, 3, False),  # five ranks (one below the box's limit of processes on the card), uneven strips
+    # uneven strips of a frame whose height (592) does not divide by the number of ranks (3): the Python driver refused such a
+    # frame before it looked at the bounds (round 3's w5.log, five strips of a 256x576 frame: `assert H % rows == 0`).  The
+    # five-rank case of round 3 stood AT the box's limit of six processes on the card (five ranks + this process) and a run
+    # of round 4 was killed by the guard with seven counted; no case here needs more than four ranks.
+    ([0, 160, 368, 592], True, 3, False),
 ])
 def test_native_tiled_frame_between_real_processes(bounds, moving, frames, by_broadcast, tmp_path):
     world = len(bounds) - 1
@@ -180,7 +193,7 @@ def test_native_tiled_frame_between_real_processes(bounds, moving, frames, by_br
     if by_broadcast:
         env["VKR_GATHER_V_BROADCAST"] = "1"
     rc, out, err = _launch(world, [str(script)], env, timeout=420)
-    assert rc == 0, out[-3000:] + err[-3000:]
+    assert rc == 0, out[-3000:] + "\n--- the ranks' own stderr ---\n" + _workers_stderr(err)
     rows = _wire_log(log, world)
     equal = all(bounds[r + 1] - bounds[r] == bounds[1] for r in range(world))
     for r, k in rows.items():

@@ -105,6 +105,39 @@ def test_chain_stagewise(size, oracle_lib, budget=8):
         _compare(ref, gpu, outs, budget=budget)
 
 
+@pytest.mark.parametrize("size", [(256, 144), (640, 360), (3840, 2160)])
+def test_chain_stagewise_textured_roughness(size, oracle_lib, parity_table):
+    """The second material mode (VKR_SYNTH_TEXTURED_ROUGHNESS: roughness perturbed per texel, so the blur's sigma and the
+    trace's lobe vary inside every wavefront — blur.comp:44-75 takes sigma per pixel from the material texture; the frozen
+    scene has one roughness per object and 93 % of its blur waves take the wave-uniform-sigma path).  Same stagewise rule
+    as the frozen scene, budget 0 at 3840x2160 (table -> profiles/parity_c2_textured.json); the generator itself bit-exact."""
+    from vk_renderer_amd.camera import FrameSetup
+
+    ref, gpu = _pair(*size, oracle_lib, setup=FrameSetup(*size, material="textured"))
+    ref.synth()
+    gpu.synth()
+    gpu.sync()
+    for name in ("depth", "normal", "albedo", "material", "velocity", "prev_depth"):
+        a, b = getattr(gpu, name).raw(0), getattr(ref, name).raw(0)
+        if name in ("depth", "prev_depth"):
+            a, b = a & 0xFFFFFF, b & 0xFFFFFF
+        assert int((a != b).any(axis=-1).sum()) == 0, f"textured generator: {name} differs"
+    flat = PostFxChain(*size, backend="oracle")
+    flat.synth()
+    rough, rough_flat = ref.material.raw(0)[..., 1], flat.material.raw(0)[..., 1]
+    changed = float((rough != rough_flat).mean())
+    print(f"[parity] textured roughness: {changed:.3f} of the material texels differ from the flat scene")
+    assert changed > 0.5 and np.array_equal(ref.material.raw(0)[..., [0, 2, 3]], flat.material.raw(0)[..., [0, 2, 3]])
+    ref.build_prev_hiz()
+    ref.init_histories()
+    ref.preintegrate_pdf()
+    for stage, outs in STAGES:
+        _sync_inputs(ref, gpu)
+        getattr(ref, stage)()
+        getattr(gpu, stage)()
+        _compare(ref, gpu, outs, budget=0 if size[0] >= 3840 else 8)
+
+
 def test_chain_stagewise_full_size(oracle_lib, parity_table):
     """The BASELINE.json frame itself (c2): every pass at 3840x2160 against the oracle on the same bytes.  The table
     of counts goes to gpurun_out/parity_test_chain_stagewise_full_size.json (-> profiles/parity_c2.json)."""

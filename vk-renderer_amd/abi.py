@@ -34,6 +34,7 @@ NORMALIZE_REFLECTIONS = 1
 ACCUMULATE_REFLECTIONS = 2
 BILATERAL_FILTER = 4
 SYNTH_DEPTH_ONLY = 1
+SYNTH_TEXTURED_ROUGHNESS = 2
 
 
 class VkrImg(C.Structure):

@@ -61,8 +61,14 @@ class FrameSetup:
     angle_offset = 60/360, weight_ratio 1, max_roughness 1, render_flags 7, accumulate 1."""
 
     def __init__(self, width, height, frame_random=0, use_mis=1, eye=(0.0, 1.0, -1.0), yaw=90.0,
-                 prev_delta=(0.02, 0.0, 0.01), prev_yaw_delta=0.2):
+                 prev_delta=(0.02, 0.0, 0.01), prev_yaw_delta=0.2, material="flat"):
         self.width, self.height = width, height
+        # "flat": one roughness per object (the frozen scene of SURVEY 8(d)); "textured": per-texel roughness
+        # (VKR_SYNTH_TEXTURED_ROUGHNESS, include/vkr_postfx.h)
+        if material not in ("flat", "textured"):
+            raise ValueError(f"material {material!r}: 'flat' or 'textured'")
+        self.material = material
+        self.synth_flags = abi.SYNTH_TEXTURED_ROUGHNESS if material == "textured" else 0
         self.aspect = float(width) / float(height)
         # glm computes in float32; here every *input* matrix is rounded to float32 first and every
         # derived matrix is evaluated in float64 from those and rounded once (host/glm_compat.hpp does
@@ -97,7 +103,7 @@ class FrameSetup:
             p.prev_mvp = abi.Mat4.from_np(self.prev_mvp)
         p.fovy, p.aspect, p.znear, p.zfar = [float(v) for v in self.fazz]
         p.seed = SEED
-        p.flags = abi.SYNTH_DEPTH_ONLY if depth_only else 0
+        p.flags = abi.SYNTH_DEPTH_ONLY if depth_only else self.synth_flags
         return p
 
     def gtao_params(self):

@@ -83,7 +83,8 @@ VKR_DEV float find_horizon(const DepthTile& depth, const Tex& depth_tex, const P
 // One thread per half-res pixel.  The slice-direction pattern repeats every 4x4 pixels
 // (main.comp:276-278), so its 16 (cos,sin) pairs are kernel arguments evaluated once on the host
 // instead of per pixel.
-template <bool TILED>
+// MIS: use_mis as a compile-time constant (one slice, no loop-carried sum: fewer live values across the horizon search).
+template <bool TILED, bool MIS>
 // (a block is 16 waves: with more than 64 VGPRs only one block fits a CU — 4 waves per SIMD — and the pass is 11 % slower)
 __global__ __launch_bounds__(GT_BX * GT_BY, 8) void k_gtao_main(GtaoArgs a) {
   const i2 blk = xcd_block<2, 4>();  // chunks of 128 x 64 output pixels
@@ -123,12 +124,13 @@ __global__ __launch_bounds__(GT_BX * GT_BY, 8) void k_gtao_main(GtaoArgs a) {
   const f2 screen_uv = mk2(pixel_centre_uv(gx, (float)a.tex_w), pixel_centre_uv(gy, (float)a.tex_h));
   const float pdf_uniform = 1.0f / (2.0f * VKR_PI);
   float occ_x = 0.0f, occ_y = pdf_uniform;
-  uint2* dst = texel_ptr<uint2>(a.out, lx, ly);
+  // the output texel as a 32-bit offset (a 64-bit pointer formed here would be live, two registers, across the horizon search)
+  const uint32_t dst_off = toff(a.out, lx, ly, 8);
 
   const float frag_depth = depth_sample<TILED>(tile, a.depth, screen_uv);
   if (frag_depth >= 1.0f) {  // sky: mis -> (0,1), non-mis -> 0 (main.comp:187-189,221-223)
     occ_x = 0.0f;
-    occ_y = a.use_mis ? 1.0f : pdf_uniform;
+    occ_y = MIS ? 1.0f : pdf_uniform;
   } else {
     // Exact: camera_pos, the sample radius / direction (they place the horizon samples and feed the
     // break test) and w0 / camera_normal / L (coordinates of the ill-conditioned PDF lookup).
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(GT_BX * GT_BY, 8) void k_gtao_main(GtaoArgs a) {
     const float rad = vmin(100.0f / length(camera_pos), 16.0f);
     const f2 dir_radius = mk2(rad / (float)a.depth.fw, rad / (float)a.depth.fh);
     const int dir_slot = (((gx + gy) & 3) << 2) + (gx & 3);  // 16 * gtao_direction(pos)
-    const int dirs = a.use_mis ? 1 : (a.two_directions ? 2 : 1);
+    const int dirs = MIS ? 1 : (a.two_directions ? 2 : 1);
     float sum = 0.0f, occlusion = 0.0f;
     f3 L = mk3(0, 0, 0);
     for (int di = 0; di < dirs; di++) {
@@ -167,20 +169,20 @@ __global__ __launch_bounds__(GT_BX * GT_BY, 8) void k_gtao_main(GtaoArgs a) {
       float h = acosf(h_cos);
       h = vmin(n + vmin(h - n, VKR_PI / 2.0f), h);
       const float arc = vmax((-cosf(2.0f * h - n) + cosf(n)) + (2.0f * h) * sinf(n), 0.0f);
-      if (a.use_mis) {
+      if (MIS) {
         occlusion = (((1.0f / VKR_PI) * np_len) * 0.25f) * arc;
         L = normalize(sample_end_pos - camera_pos);
       } else {
         sum += (np_len * 0.25f) * arc;
       }
     }
-    if (!a.use_mis) {
+    if (!MIS) {
       occ_x = (2.0f * sum) / (float)dirs;  // main.comp:216
     } else {
       // main.comp:250-273
       const float roughness = sample_srgb_channel(a.material, screen_uv, 1, s_lut);
       const float pdf_ggx = sampleGGXdirPDF(a.pdf, w0, camera_normal, L, roughness * roughness);
-      const uint2 prev = *dst;  // imageLoad(gtao_out): (occlusion, pdf) written by the SSR trace
+      const uint2 prev = *(const uint2*)(a.out.p + dst_off);  // imageLoad(gtao_out): (occlusion, pdf) written by the SSR trace
       const float ao_x = half_bits_to_float(prev.x & 0xFFFFu), ao_y = half_bits_to_float(prev.x >> 16);
       if (a.reflections_only != 0) {
         float res = ao_x / ao_y;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(GT_BX * GT_BY, 8) void k_gtao_main(GtaoArgs a) {
   uint2 o;
   o.x = float_to_half_bits(occ_x) | (float_to_half_bits(occ_y) << 16);
   o.y = 0u;
-  *dst = o;
+  *(uint2*)(const_cast<uint8_t*>(a.out.p) + dst_off) = o;
 }
 
 // filter.comp:17-51: 4x4 taps at offsets -2..+1, depth-weighted mean of raw.r.  The block stages
@@ -331,10 +333,10 @@ extern "C" int vkr_gtao_main(const vkr_img* depth, const vkr_gtao_params* params
     }
   }
   dim3 block(GT_BX, GT_BY);
-  if (a.tex_w == a.out.fw && a.tex_h == a.out.fh && same_window(a.depth, a.out))
-    hipLaunchKernelGGL(k_gtao_main<true>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(k_gtao_main<false>, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
+  const bool tiled = a.tex_w == a.out.fw && a.tex_h == a.out.fh && same_window(a.depth, a.out);
+  void (*kernel)(GtaoArgs) = tiled ? (a.use_mis ? k_gtao_main<true, true> : k_gtao_main<true, false>)
+                                   : (a.use_mis ? k_gtao_main<false, true> : k_gtao_main<false, false>);
+  hipLaunchKernelGGL(kernel, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);
   return launch_status("gtao_main");
 }
 

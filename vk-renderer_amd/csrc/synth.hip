@@ -21,7 +21,7 @@ struct SynthArgs {
   Tex depth, normal, albedo, material, velocity;
   Mat4 c2w, prev_mvp, mvp;
   Proj pr;
-  uint32_t seed, depth_only;
+  uint32_t seed, depth_only, textured_roughness;
 };
 
 __global__ __launch_bounds__(256) void k_synth_gbuffer(SynthArgs a) {
@@ -85,7 +85,12 @@ __global__ __launch_bounds__(256) void k_synth_gbuffer(SynthArgs a) {
       const f3 P = eye + best_t * dir;
       const f3 base = mk3(0.3f + 0.7f * u01(hash3(id, 1u, a.seed)), 0.3f + 0.7f * u01(hash3(id, 2u, a.seed)),
                           0.3f + 0.7f * u01(hash3(id, 3u, a.seed)));
-      const float roughness = 0.1f + 0.8f * u01(hash3(id, 4u, a.seed));
+      float roughness = 0.1f + 0.8f * u01(hash3(id, 4u, a.seed));
+      if (a.textured_roughness) {  // VKR_SYNTH_TEXTURED_ROUGHNESS: per-texel roughness
+        const float n = u01(hash3((uint32_t)gx, (uint32_t)gy, a.seed ^ 0x7E57u)) - 0.5f;
+        roughness = roughness + 0.3f * n;
+        roughness = roughness < 0.02f ? 0.02f : (roughness > 1.0f ? 1.0f : roughness);
+      }
       const float metallic = (hash3(id, 5u, a.seed) & 1u) ? 1.0f : 0.0f;
       const f2 en = encode_normal(nrm);
       int cx, cy;
@@ -199,6 +204,7 @@ extern "C" int vkr_synth_gbuffer(const vkr_img* depth, const vkr_img* normal, co
   if (!params) { set_error("synth_gbuffer: NULL params"); return VKR_ERR_NULL; }
   SynthArgs a;
   a.depth_only = (params->flags & VKR_SYNTH_DEPTH_ONLY) ? 1u : 0u;
+  a.textured_roughness = (params->flags & VKR_SYNTH_TEXTURED_ROUGHNESS) ? 1u : 0u;
   VKR_TRY(make_tex(depth, 0, VKR_FMT_D24_UNORM_S8, "synth_gbuffer.depth", &a.depth));
   if (!a.depth_only) {
     VKR_TRY(make_tex(normal, 0, VKR_FMT_RG16_UNORM, "synth_gbuffer.normal", &a.normal));

@@ -69,6 +69,7 @@ def lib():
         l.vkrh_set_camera.argtypes = [C.c_void_p, C.POINTER(HostCamera)]
         l.vkrh_pin_randoms.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32]
         l.vkrh_set_gtao_mode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        l.vkrh_set_synth_flags.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_set_gathered_mips.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_run.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_end_frame.argtypes = [C.c_void_p, C.c_uint32]
@@ -210,6 +211,7 @@ class HostFrame:
         self._check(lib().vkrh_set_camera(self.h, C.byref(cam)))
         self.pin_randoms()
         self._check(lib().vkrh_set_gtao_mode(self.h, setup.use_mis, 0))
+        self._check(lib().vkrh_set_synth_flags(self.h, getattr(setup, "synth_flags", 0)))
 
     def _check(self, rc):
         if rc != 0:

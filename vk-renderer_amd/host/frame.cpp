@@ -754,6 +754,13 @@ int vkrh_pin_screen_trace(void* frame, float angle_jitter, float random_offset, 
 int vkrh_set_gtao_mode(void* frame, uint32_t use_mis, uint32_t two_directions) {
   return guarded([&] { auto* f = (PostFxFrame*)frame; f->gtao.set_mis(use_mis != 0); f->gtao.set_two_directions(two_directions != 0); });
 }
+int vkrh_set_synth_flags(void* frame, uint32_t flags) {
+  return guarded([&] {
+    if (!frame) throw std::runtime_error{"NULL argument"};
+    if (flags & ~uint32_t(VKR_SYNTH_TEXTURED_ROUGHNESS)) throw std::runtime_error{"vkrh_set_synth_flags: unknown flag"};
+    ((PostFxFrame*)frame)->synth.set_material_flags(flags);
+  });
+}
 int vkrh_set_gathered_mips(void* frame, uint32_t mips) {
   return guarded([&] {
     if (mips < 1 || mips > 4) throw std::runtime_error{"vkrh_set_gathered_mips: 1..4"};

@@ -78,6 +78,8 @@ int vkrh_load_scene(void* frame, const vkr_raster_vertex* vertices, uint32_t ver
 /* pin ScreenSpaceTrace's per-frame randoms (screen_trace.cpp:49-53) */
 int vkrh_pin_screen_trace(void* frame, float angle_jitter, float random_offset, uint32_t frame_count);
 int vkrh_set_gtao_mode(void* frame, uint32_t use_mis, uint32_t two_directions);
+/* material mode of the synthetic G-buffer (VKRH_STAGE_GBUFFER): 0, or VKR_SYNTH_TEXTURED_ROUGHNESS (include/vkr_postfx.h) */
+int vkrh_set_synth_flags(void* frame, uint32_t flags);
 /* tiled frames: whole-frame Hi-Z view mips 0..mips-1 (image mips 1..mips) arrive by all-gather (default 4; tiles whose
  * extent is only divisible by 8, like the 15360x1080 strips of config 4, gather 3); VKRH_STAGE_HIZ_TAIL rebuilds the rest */
 int vkrh_set_gathered_mips(void* frame, uint32_t mips);

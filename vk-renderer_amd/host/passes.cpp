@@ -739,7 +739,7 @@ static vkr_synth_params synth_params(const glm::mat4 &camera, const glm::mat4 &m
 // same attachments, in the same order, as SceneRenderer::draw_taa
 void SyntheticGbuffer::draw_taa(RenderGraph &graph, const Gbuffer &gbuffer, const DrawTAAParams &params) {
   rec::fullscreen(graph, "GbufferPass", pipeline,
-    {rec::uniform(0, synth_params(params.camera, params.mvp, params.prev_mvp, params.fovy_aspect_znear_zfar, seed, 0)),
+    {rec::uniform(0, synth_params(params.camera, params.mvp, params.prev_mvp, params.fovy_aspect_znear_zfar, seed, material_flags & VKR_SYNTH_TEXTURED_ROUGHNESS)),
      rec::color_target(gbuffer.albedo), rec::color_target(gbuffer.normal), rec::color_target(gbuffer.material),
      rec::color_target(gbuffer.velocity_vectors), rec::depth_target(gbuffer.depth)},
     rec::no_push(), gbuffer.w, gbuffer.h);

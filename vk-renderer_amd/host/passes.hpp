@@ -634,10 +634,13 @@ struct SyntheticGbuffer {
   // fills mip 0 of `depth_target` only, as seen from `camera` (used to seed prev_depth)
   void draw_depth(rendergraph::RenderGraph &graph, rendergraph::ImageResourceId depth_target, const glm::mat4 &camera, const glm::mat4 &mvp,
                   const glm::vec4 &fovy_aspect_znear_zfar);
+  // VKR_SYNTH_TEXTURED_ROUGHNESS (include/vkr_postfx.h): the material mode of draw_taa; 0 = one roughness per object
+  void set_material_flags(uint32_t flags) { material_flags = flags; }
 
 private:
   gpu::GraphicsPipeline pipeline;
   uint32_t seed;
+  uint32_t material_flags = 0;
 };
 
 

@@ -135,11 +135,13 @@ class TiledFrame:
         assert cols * rows == world
         self.setup, self.rank, self.world, self.cols, self.rows_n = setup, rank, world, cols, rows
         W, H = setup.width, setup.height
-        assert W % cols == 0 and H % rows == 0
+        # equal tiles need a frame that divides by the grid; strips with explicit bounds only need the bounds to cover the frame
+        # (round 3's five-process wire test on a 256x576 frame died on this assertion before its bounds were looked at)
+        assert W % cols == 0 and (H % rows == 0 or row_bounds is not None), f"a {W}x{H} frame does not divide into a {cols}x{rows} grid (pass row_bounds)"
         self.tw, self.th = W // cols, H // rows
         self.halo = halo if world > 1 else 0
         self.row_bounds = None
-        if row_bounds is not None and list(row_bounds) != [r * self.th for r in range(world + 1)]:
+        if row_bounds is not None and (H % rows != 0 or list(row_bounds) != [r * self.th for r in range(world + 1)]):
             assert native and cols == 1 and len(row_bounds) == world + 1 and row_bounds[0] == 0 and row_bounds[-1] == H
             self.row_bounds = [int(v) for v in row_bounds]
             self.th = self.row_bounds[rank + 1] - self.row_bounds[rank]
