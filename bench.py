@@ -463,13 +463,18 @@ def main():
             if not os.path.exists(path):
                 return None, None
             with open(path) as f:
-                d = json.load(f)
-            return d.get(dominant), f"profiles/{fname}" + (f" ({d['_source']})" if "_source" in d else "")
+                d = json.load(f).get(args.config)  # one digest per BASELINE config
+            if not d:
+                return None, None
+            return d.get(dominant), f"profiles/{fname}[{args.config}]" + (f" ({d['_source']})" if "_source" in d else "")
 
         # HBM bytes / VALU-busy of the dominant kernel are NOT measured in this run: they are the committed rocprofv3
-        # --pmc digests of the same command at 3840x2160 (tools/profile_run.sh + tools/profile_digest.py), valid for c2 / c5 only.
-        traffic, traffic_src = from_profiles("traffic.json") if (W, H) == (TILE_W, TILE_H) else (None, None)
-        valu_busy, valu_src = from_profiles("valu_busy.json") if (W, H) == (TILE_W, TILE_H) else (None, None)
+        # --pmc digests of the same command (tools/profile_run.sh + tools/profile_digest.py --config), kept per BASELINE
+        # config and only valid for that config's own frame, the frozen scene and one GPU.
+        own_frame = world == 1 and args.material == "flat" and not args.shading and not args.raster and (W, H) == {
+            "c1": (1920, 1080), "c2": (TILE_W, TILE_H), "c3": (7680, 4320), "c4": (C4_W, C4_H), "c5": (TILE_W, TILE_H)}[args.config]
+        traffic, traffic_src = from_profiles("traffic.json") if own_frame else (None, None)
+        valu_busy, valu_src = from_profiles("valu_busy.json") if own_frame else (None, None)
         workload = {"c1": f"{W}x{H} synthetic G-buffer: GTAO main pass only (non-MIS)",
                     "c5": f"{W}x{H} synthetic G-buffer: Hi-Z downsample + 8 x SSR (trace, filter, blur) + TAA"}.get(
             args.config, f"{W}x{H} synthetic G-buffer: Hi-Z downsample + SSR (trace, filter, blur) + GTAO (main, filter, accumulate)"

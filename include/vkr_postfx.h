@@ -260,6 +260,19 @@ int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const vkr_img* m
                    const vkr_img* out_ray, const vkr_img* out_occlusion, const vkr_img* pdf_tex,
                    const vkr_trace_push* push, void* stream);
 
+/* "sssr_trace" in two launches, same images as vkr_sssr_trace bit for bit.  The head launch runs every ray's prologue, its 16
+ * pinned steps and `park_after_rounds` (0..4) of the compacted 16-step rounds, and finishes the pixels whose rays have ended;
+ * a ray that has not is PARKED: written, with what the rest of its march and its epilogue need (80 bytes), to a frame-wide
+ * queue in `workspace`.  The resume launch takes 256 consecutive parked rays per block — the stragglers of many tiles in one
+ * pool — marches them to their end and writes their pixels.  workspace: device memory of at least
+ * vkr_sssr_trace_workspace_bytes(rays width, rays height) bytes, 16-byte aligned, no initialisation needed; a workspace
+ * belongs to one stream at a time.                                                                                      */
+uint64_t vkr_sssr_trace_workspace_bytes(uint32_t rays_width, uint32_t rays_height);
+int vkr_sssr_trace_split(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                         const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                         const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_trace_push* push,
+                         void* workspace, uint64_t workspace_bytes, uint32_t park_after_rounds, void* stream);
+
 /* Multi-GPU variant of "sssr_trace" (no reference counterpart; host/frame.hpp): `normal` is the whole-frame image but only
  * frame rows [normal_row0, normal_row1) of it are in memory when the march ends (the rank's window).  A ray that passes
  * every other validity test and whose hit-normal footprint (trace.comp:103-109) has a row outside them is stored as a
@@ -499,7 +512,7 @@ int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_img* frame_normals, c
                     uint32_t count, void* stream);
 
 /* Measurement switches — the library's only process-wide state.  The environment (VKR_BLUR_NO_SKIP, VKR_FILTER_NO_SKIP,
- * VKR_TAA_GENERIC, VKR_SHADING_GENERIC, VKR_BLUR_GENERIC) is read once, at the first launch that asks; afterwards only vkr_set_switches
+ * VKR_TAA_GENERIC, VKR_SHADING_GENERIC, VKR_BLUR_GENERIC, VKR_TRACE_ONE_LAUNCH) is read once, at the first launch that asks; afterwards only vkr_set_switches
  * changes them.  NO_SKIP: evaluate every tap of the blur / filter even in tiles without a reflection / hit (a
  * content-independent time; the stored texels are the same wherever every weight is finite).  GENERIC: the TAA /
  * shading instantiations that do not assume equal window layouts.                                                  */
@@ -508,6 +521,8 @@ int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_img* frame_normals, c
 #define VKR_SWITCH_TAA_GENERIC     4u
 #define VKR_SWITCH_SHADING_GENERIC 8u
 #define VKR_SWITCH_BLUR_GENERIC    16u /* every wave of the blur on the per-lane Gaussian loop (no wave-uniform-sigma path) */
+#define VKR_SWITCH_TRACE_ONE_LAUNCH 32u /* read by the HOST layer (host/gpu): program "sssr_trace" as one launch (vkr_sssr_trace) instead of
+                                          * head + resume (vkr_sssr_trace_split); the library's entries do what their names say either way */
 uint32_t vkr_get_switches(void);
 void vkr_set_switches(uint32_t mask);
 

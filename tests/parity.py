@@ -51,8 +51,10 @@ def storage_step(fmt, ref):
     return np.zeros_like(ref)
 
 
-def mismatches(fmt, got, ref):
-    """got/ref: decoded float arrays.  Returns boolean array of failing texels (any channel)."""
+def mismatches(fmt, got, ref, input_fmt=None):
+    """got/ref: decoded float arrays.  Returns boolean array of failing texels (any channel).
+    input_fmt: the surface is a blend of an input stored in that (coarser) format whose two versions may differ by one code
+    (the TAA target resolves the sRGB8 composite): one storage step of the INPUT at the value is allowed as well."""
     got = got.astype(np.float64)
     ref64 = ref.astype(np.float64)
     both_nan = np.isnan(got) & np.isnan(ref64)
@@ -60,6 +62,8 @@ def mismatches(fmt, got, ref):
     with np.errstate(invalid="ignore"):
         diff = np.abs(got - ref64)
         ok = (diff <= REL_TOL * np.abs(ref64)) | (diff <= storage_step(fmt, ref.astype(np.float32)).astype(np.float64) * 1.0001)
+        if input_fmt is not None:
+            ok = ok | (diff <= storage_step(input_fmt, ref.astype(np.float32)).astype(np.float64) * 1.0001)
     ok = ok | both_nan | same_inf
     return ~ok.all(axis=-1)
 

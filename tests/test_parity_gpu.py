@@ -138,6 +138,28 @@ def test_chain_stagewise_textured_roughness(size, oracle_lib, parity_table):
         _compare(ref, gpu, outs, budget=0 if size[0] >= 3840 else 8)
 
 
+@pytest.mark.parametrize("size", [(70, 38), (206, 226), (640, 360), (3840, 2160)])
+def test_trace_in_two_launches_is_the_same_image(size, oracle_lib):
+    """vkr_sssr_trace_split (head launch, frame-wide queue of parked rays, resume launch — what the host layer runs for program
+    "sssr_trace") against vkr_sssr_trace: `rays` and `raw` bit for bit, for every number of rounds the head may keep, and
+    the rays against the oracle within the usual rule."""
+    ref, gpu = _pair(*size, oracle_lib)
+    ref.synth(); ref.build_prev_hiz(); ref.init_histories(); ref.preintegrate_pdf(); ref.downsample()
+    _sync_inputs(ref, gpu)
+    ref.ssr_trace()
+    gpu.ssr_trace()
+    gpu.sync()
+    want_rays, want_raw = gpu.rays.raw(0).copy(), gpu.raw.raw(0).copy()
+    for rounds in (0, 1, 2, 3, 4):
+        for img in (gpu.rays, gpu.raw):  # a pixel the two launches forget to write must not pass on what the last run left there
+            img.upload(np.full(img.to_host().shape, 0x5A, dtype=np.uint8))
+        gpu.ssr_trace(split=rounds)
+        gpu.sync()
+        assert int((gpu.rays.raw(0) != want_rays).any(axis=-1).sum()) == 0, f"rays differ with {rounds} rounds in the head launch"
+        assert int((gpu.raw.raw(0) != want_raw).any(axis=-1).sum()) == 0, f"raw differs with {rounds} rounds in the head launch"
+    _compare(ref, gpu, ("rays", "raw"), budget=0 if size[0] >= 3840 else 8)
+
+
 def test_chain_stagewise_full_size(oracle_lib, parity_table):
     """The BASELINE.json frame itself (c2): every pass at 3840x2160 against the oracle on the same bytes.  The table
     of counts goes to gpurun_out/parity_test_chain_stagewise_full_size.json (-> profiles/parity_c2.json)."""

@@ -68,8 +68,10 @@ WORKER = textwrap.dedent("""
                 bad = int((a != b).any(axis=-1).sum())
                 assert bad == 0, (hname, mip, bad)
             else:
-                bad = int(mismatches(rimg.format, got.decode(mip), rimg.decode(mip)).sum())
-                # one stored code is one storage step on sRGB8 surfaces too (tests/parity.py: storage_step): every surface has the same budget
+                # one stored code is one storage step on sRGB8 surfaces too (tests/parity.py: storage_step), and the TAA history is a
+                # blend of that sRGB8 composite (taa/resolve.comp): where the composite is one code apart (measured: 127 texels at
+                # 1920x1080) the resolved colour may be one code gap apart.  Every surface has the same budget.
+                bad = int(mismatches(rimg.format, got.decode(mip), rimg.decode(mip), input_fmt=abi.FMT_RGBA8_SRGB if hname == 'taa_hist' else None).sum())
                 assert bad <= 8, (hname, bad)
             bad_total += bad
         print(f'[dropin] {hname:13s} outside-tol / differing {bad}')

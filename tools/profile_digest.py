@@ -22,6 +22,7 @@ TASK_OF = {  # kernel -> (rendergraph task, launches of that kernel per task)
     "vkr::k_downsample_gbuffer": ("DownsampleGbuffer", 1),
     "vkr::k_depth_mips_fused": ("DownsampleDepth", 2),
     "vkr::k_sssr_trace": ("SSSR_trace", 1),
+    "vkr::k_sssr_trace_resume": ("SSSR_trace", 1),  # the second launch of the same task (vkr_sssr_trace_split)
     "vkr::k_sssr_filter": ("SSSR_filter", 1),
     "vkr::k_sssr_blur": ("SSSR_blur", 1),
     "vkr::k_gtao_main": ("GTAO_main", 1),
@@ -69,6 +70,19 @@ def counters(d, skip_first=2):
     return out
 
 
+def merge_by_config(path, config, digest):
+    """profiles/traffic.json / valu_busy.json: {config: {task: value, "_source": ...}} — one digest per BASELINE config"""
+    table = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            table = json.load(f)
+        if "_source" in table:  # the round-3 layout: one flat digest, of c2
+            table = {"c2": table}
+    table[config] = digest
+    with open(path, "w") as g:
+        json.dump(table, g, indent=1, sort_keys=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
@@ -77,6 +91,9 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--sq", nargs="*", default=[])
     ap.add_argument("--note", default="")
+    ap.add_argument("--config", default="c2", help="BASELINE config the profiled command ran (bench.py --config): the key under which "
+                    "profiles/traffic.json and profiles/valu_busy.json keep this digest")
+    ap.add_argument("--frame", default="3840x2160")
     a = ap.parse_args()
     os.makedirs("profiles", exist_ok=True)
 
@@ -107,9 +124,8 @@ def main():
                 b = (2.0 * f_kb + w_kb) * 1024.0 * n
                 traffic[task] = traffic.get(task, 0.0) + b  # a task of several kernels: their sum
                 g.write(f"{task},{k},{cnt},{f_kb:.1f},{w_kb:.1f},{n},{b:.0f}\n")
-        traffic["_source"] = f"{a.tag}_pmc_traffic.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py` at 3840x2160, bytes = 2 x FETCH_SIZE KB + WRITE_SIZE KB per task"
-        with open("profiles/traffic.json", "w") as g:
-            json.dump(traffic, g, indent=1)
+        traffic["_source"] = f"{a.tag}_pmc_traffic.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --config {a.config}` at {a.frame}, bytes = 2 x FETCH_SIZE KB + WRITE_SIZE KB per task"
+        merge_by_config("profiles/traffic.json", a.config, traffic)
         print("wrote", f"profiles/{a.tag}_pmc_traffic.csv", "profiles/traffic.json")
 
     if a.sq:
@@ -140,9 +156,8 @@ def main():
                 busy[task] = busy.get(task, 0.0) + 4.0 * cs["SQ_ACTIVE_INST_VALU"] / 1024.0 / 2.4
                 weight[task] = weight.get(task, 0.0) + cs["_duration_ns"]
         busy = {t: v / weight[t] for t, v in busy.items()}
-        busy["_source"] = f"{a.tag}_sq_counters.md: rocprofv3 --pmc SQ_ACTIVE_INST_VALU of `bench.py` at 3840x2160, 4 x count / 1024 SIMDs / (duration x 2.4 GHz)"
-        with open("profiles/valu_busy.json", "w") as g:
-            json.dump(busy, g, indent=1)
+        busy["_source"] = f"{a.tag}_sq_counters.md: rocprofv3 --pmc SQ_ACTIVE_INST_VALU of `bench.py --config {a.config}` at {a.frame}, 4 x count / 1024 SIMDs / (duration x 2.4 GHz)"
+        merge_by_config("profiles/valu_busy.json", a.config, busy)
         print("wrote profiles/valu_busy.json")
 
 

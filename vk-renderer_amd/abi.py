@@ -209,6 +209,8 @@ ENTRY_ARGS = {
     "depth_mips": [_IMG, C.c_uint32],
     "pdf_preintegrate": [_IMG],
     "sssr_trace": [_IMG, _IMG, _IMG, P(TraceParams), C.c_void_p, _IMG, _IMG, _IMG, P(TracePush)],
+    # the same program in two launches (head + resume over a frame-wide queue of parked rays): workspace, bytes, park_after_rounds
+    "sssr_trace_split": [_IMG, _IMG, _IMG, P(TraceParams), C.c_void_p, _IMG, _IMG, _IMG, P(TracePush), C.c_void_p, C.c_uint64, C.c_uint32],
     "sssr_filter": [_IMG, _IMG, _IMG, _IMG, _IMG, _IMG, P(TraceParams), P(FilterPush)],
     "sssr_blur": [_IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, _IMG, P(ReprojectParams), P(BlurPush)],
     "gtao_main": [_IMG, P(GtaoParams), _IMG, _IMG, _IMG, _IMG, P(GtaoPush)],
@@ -241,6 +243,10 @@ ENTRY_ARGS = {
     "hit_reply": [_IMG, _IMG, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p],
     "hit_scatter": [_IMG, _IMG, C.c_void_p, C.c_void_p, C.c_uint32],
 }
+
+
+# entries that are a different SCHEDULE of another entry (same images bit for bit): no twin in a checker library
+SCHEDULE_VARIANTS = {"sssr_trace_split": "sssr_trace"}
 
 
 class RectCopy(C.Structure):  # vkr_rect_copy
@@ -289,6 +295,8 @@ def product():
         lib.vkr_set_switches.restype = None
         lib.vkr_comm_available.restype = C.c_int
         lib.vkr_copy_rects.restype = C.c_int
+        lib.vkr_sssr_trace_workspace_bytes.argtypes = [C.c_uint32, C.c_uint32]
+        lib.vkr_sssr_trace_workspace_bytes.restype = C.c_uint64
         lib.vkr_raster_scratch_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         lib.vkr_raster_scratch_bytes.restype = C.c_uint64
         lib.vkr_halton23_fill.argtypes = [C.c_void_p, C.c_uint32]
@@ -311,7 +319,7 @@ def check(rc, lib=None):
 
 COMM_ID_BYTES = 128
 # measurement switches (include/vkr_postfx.h VKR_SWITCH_*): vkr_get_switches / vkr_set_switches
-SWITCH_BLUR_NO_SKIP, SWITCH_FILTER_NO_SKIP, SWITCH_TAA_GENERIC, SWITCH_SHADING_GENERIC, SWITCH_BLUR_GENERIC = 1, 2, 4, 8, 16
+SWITCH_BLUR_NO_SKIP, SWITCH_FILTER_NO_SKIP, SWITCH_TAA_GENERIC, SWITCH_SHADING_GENERIC, SWITCH_BLUR_GENERIC, SWITCH_TRACE_ONE_LAUNCH = 1, 2, 4, 8, 16, 32
 
 
 class Comm:

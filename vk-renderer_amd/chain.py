@@ -235,12 +235,24 @@ class PostFxChain:
     def preintegrate_pdf(self):
         self.call("pdf_preintegrate", C.byref(self.pdf.desc()))
 
-    def ssr_trace(self, frame_random=None, max_roughness=1.0):
+    def ssr_trace(self, frame_random=None, max_roughness=1.0, split=None):
+        """split: None = one launch (vkr_sssr_trace); 0..4 = vkr_sssr_trace_split with that many compacted rounds in the
+        head launch (product backend only: the images are the same bit for bit, so the oracle has no counterpart)."""
         tp = self.setup.trace_params(frame_random)
         push = abi.TracePush(max_roughness)
         # advanced_ssr.cpp:186: depth view = mips 1..L-1 (tiled: the gathered whole-frame pyramid)
         hiz = self.frame_hiz.desc() if self.tiled else self.depth.desc(1, self.depth.mips - 1)
         dn = self.frame_normals.desc() if self.tiled else self.dn.desc()
+        if split is not None and self.backend == "product":
+            import torch
+
+            need = int(self.lib.vkr_sssr_trace_workspace_bytes(self.rays.width, self.rays.height))
+            if getattr(self, "_trace_workspace", None) is None or self._trace_workspace.numel() < need:
+                self._trace_workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            self.call("sssr_trace_split", C.byref(hiz), C.byref(dn), C.byref(self.material.desc()), C.byref(tp), self._halton_ptr(),
+                      C.byref(self.rays.desc()), C.byref(self.raw.desc()), C.byref(self.pdf.desc()), C.byref(push),
+                      self._trace_workspace.data_ptr(), need, int(split))
+            return
         self.call("sssr_trace", C.byref(hiz), C.byref(dn),
                   C.byref(self.material.desc()), C.byref(tp), self._halton_ptr(), C.byref(self.rays.desc()),
                   C.byref(self.raw.desc()), C.byref(self.pdf.desc()), C.byref(push))

@@ -56,6 +56,9 @@ struct TraceArgs {
   // vkr_sssr_validate — pend_mask (R8, every pixel) says which, pend_data (two float4 per pixel) keeps R and the hit uv
   int nrm_row0, nrm_row1;
   Tex pend_mask, pend_data;
+  // vkr_sssr_trace_split: the frame-wide queue of the rays the head launch parks after park_after compacted rounds
+  struct { uint4* records; uint32_t* counters; uint32_t capacity; } q;
+  int park_after;
 };
 
 #define TP_VEC 5  // uint4 per parked-ray record (18 dwords used): 80-byte stride, conflict-free for consecutive rays
@@ -108,141 +111,82 @@ VKR_DEV void pool_load_result(const uint4* p, RayState& s) {
 #endif
 #define TRACE_PIN_ROUND 16  // round 0: the pinned steps, run by every ray
 #define TRACE_THREADS (256 * TRACE_WY)
-template <bool WINDOWED>
-__global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
-  const i2 blk = xcd_block<4, 8 / TRACE_WY>();  // chunks of 128 x 64 output pixels
-  __shared__ uint4 s_mip[16];
-  __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
-  __shared__ uint4 s_ray[TRACE_THREADS * TP_VEC];  // record of ray (= owner thread) r: RayConst, t, h, mip | i << 8
-  __shared__ uint16_t s_list[2][TRACE_THREADS];
-  __shared__ int s_count[2];
-  const int tid = threadIdx.x;
-  // wave w owns the 8x8 tile (blk.x*4 + w % 4, blk.y*TRACE_WY + w / 4)
-  const int wave = tid >> 6, lane = tid & 63;
-  const int lx = (blk.x * 4 + (wave & 3)) * 8 + (lane & 7);
-  const int ly = (blk.y * TRACE_WY + (wave >> 2)) * 8 + (lane >> 3);
-  const bool active = lx < a.out_ray.w && ly < a.out_ray.h;
-  const int gx = a.out_ray.ox + lx, gy = a.out_ray.oy + ly;
-  const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
-  const f2 screen_uv = mk2(pixel_centre_uv(gx, tex_size.x), pixel_centre_uv(gy, tex_size.y));
-  const Proj pr = a.pr;
-  const Tex& depth0 = a.depth.mip[0];
-  // the pixel's three samples (trace.comp:49-58) are in flight before the block waits for its tables
-  // (every lane: the texel indices are clamped into the images, and a conditional load would have to be waited for at once)
-  const BilinearTaps taps_material = bilinear_taps_u32(a.material, screen_uv);
-  const BilinearTaps taps_depth = bilinear_taps_u32(depth0, screen_uv);
-  const BilinearTaps taps_normal = bilinear_taps_u32(a.normal, screen_uv);
-  const uint4 my_mip = mip_descriptor(a.depth.mip[(tid & 15) < a.depth.count ? (tid & 15) : 0]);  // (a load from the kernel arguments: every lane, with the others)
-  srgb_lut_stage(s_lut, tid, TRACE_THREADS);
-  if (tid < 16) s_mip[tid] = my_mip;
-  if (tid < 2) s_count[tid] = 0;
-  __syncthreads();
 
-  MarchEnv env;
-  env.mip_table = s_mip;
-  env.mip_count = a.depth.count;
-  env.screen_size = mk2((float)depth0.fw, (float)depth0.fh);
-  env.screen_size_inv = a.screen_size_inv;
-  env.uv_offset_abs = a.uv_offset_abs;  // most_detailed_mip = 0
-  env.pr = pr;
-  env.horizon_d2 = a.horizon_d2;
+// LDS of a trace block: the parked rays of the block and the two lists of the compacted rounds
+struct TracePool {
+  uint4 ray[TRACE_THREADS * TP_VEC];  // record of ray (= owner thread) r: RayConst, t, h, mip | i << 8; word 15: parked slot + 1
+  uint16_t list[2][TRACE_THREADS];
+  int count[2];
+  uint32_t queue_base;
+};
 
-  RayConst rc;
-  RayState st;
-  f3 R = mk3(0, 0, 0), ray_start = mk3(0, 0, 0);
-  float roughness = 0.0f, pixel_depth = 1.0f;
-  bool running = false;
-  if (active) {
-    // trace.comp:49-58
-    roughness = taps_srgb_channel(taps_material, 1, s_lut);
-    const float mg = mixf(0.0f, a.max_roughness, roughness);
-    roughness = mg * mg;
-    pixel_depth = taps_resolve<FmtD24>(taps_depth);
-    const f3 pixel_normal_world = decode_normal(taps_resolve<FmtRG16U>(taps_normal));
-    rc.normal = normalize(xyz(mul(a.normal_mat, mk4(pixel_normal_world.x, pixel_normal_world.y, pixel_normal_world.z, 0.0f))));
-    rc.view_vec = reconstruct_view_vec(screen_uv, pixel_depth, pr);
-
-    // trace.comp:61-63,156-158: rand() -> Halton index; sin evaluated in double
-    const float rdot = dot(screen_uv, mk2(12.9898f, 78.233f));
-    const float rnd01 = fractf(sin_hash_arg(rdot) * 43758.5453f);
-    const uint32_t base_index = f2u(rnd01 * (float)VKR_HALTON_SEQ_SIZE);
-    const uint32_t index = (base_index + a.frame_random) & (VKR_HALTON_SEQ_SIZE - 1);
-    const float4 hv = a.halton[index];
-
-    // trace.comp:65-77
-    f3 tangent = get_tangent(rc.normal);
-    const f3 bitangent = normalize(cross(rc.normal, tangent));
-    tangent = normalize(cross(bitangent, rc.normal));
-    f3 view_dir = -normalize(rc.view_vec);
-    view_dir = mk3(dot(view_dir, tangent), dot(view_dir, bitangent), dot(view_dir, rc.normal));
-    const f3 brdf_norm = sampleGGXVNDF(view_dir, roughness, roughness, hv.x, hv.z, hv.w);
-    const f3 N = (brdf_norm.x * tangent + brdf_norm.y * bitangent) + brdf_norm.z * rc.normal;
-    R = reflect(rc.view_vec, N);
-
-    // trace.comp:79-84
-    ray_start = project_view_vec(rc.view_vec + 0.001f * rc.normal, pr, a.f_over_fn);
-    ray_start.z -= 0.0001f;
-    f3 ray_dir = project_view_vec(rc.view_vec + R, pr, a.f_over_fn);
-    ray_dir = ray_dir - ray_start;
-    ray_dir = ray_dir * ((1.0f - ray_start.z) / ray_dir.z);
-
-    rc.origin = ray_start;
-    rc.direction = ray_dir;
-    rc.inv_direction = safe_inverse(ray_dir);
-    st.t = initial_advance(env, rc);
-    st.h = 0.0f;  // trace.comp:239
-    st.mip = 0;
-    st.i = 0;
-    // round 0: the first 15 steps never leave mip 0 (specialised step), step 16 (i = 15) is the first that may
-    {
-      const auto fetch0 = [&](int x, int y) -> float {
-        return ((uint32_t)x < (uint32_t)depth0.w && (uint32_t)y < (uint32_t)depth0.h) ? d24_to_float(*(const uint32_t*)(depth0.p + toff(depth0, x, y, 4))) : 0.0f;
-      };
-#pragma unroll 1
-      for (int k = 0; k < 15; k++) march_step_pinned0(env, rc, st, fetch0);
-    }
-    running = march_step<true, 15>(env, rc, st, 80);
+// park this thread's unfinished ray (one list reservation per wave: rank within the ballot)
+VKR_DEV void pool_park(TracePool& pool, bool running, int tid, int lane, const RayConst& rc, const RayState& st) {
+  const uint64_t rm = __ballot(running);
+  int base = 0;
+  if (lane == 0 && rm) base = atomicAdd(&pool.count[0], __popcll(rm));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (running) {
+    pool.list[0][base + wave_rank(rm)] = (uint16_t)tid;
+    pool_store(pool.ray + tid * TP_VEC, rc, st);
   }
-  // park the unfinished rays in LDS (one list reservation per wave: rank within the ballot)
-  {
-    const uint64_t rm = __ballot(running);
-    int base = 0;
-    if (lane == 0 && rm) base = atomicAdd(&s_count[0], __popcll(rm));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (running) {
-      s_list[0][base + wave_rank(rm)] = (uint16_t)tid;
-      pool_store(s_ray + tid * TP_VEC, rc, st);
-    }
-  }
-  // compacted rounds: thread k of the block advances the k-th unfinished ray by TRACE_ROUND steps
-  for (int cur = 0;; cur ^= 1) {
+}
+
+// Compacted rounds: thread k of the block advances the k-th unfinished ray by TRACE_ROUND steps, at most max_rounds times.
+// Returns the list that holds the rays still unfinished (pool.count[that] of them; none when the march ran to its end).
+VKR_DEV int trace_rounds(const MarchEnv& env, TracePool& pool, int tid, int lane, int max_rounds) {
+  int cur = 0;
+  for (int round = 0;; cur ^= 1, round++) {
     __syncthreads();
-    const int n = s_count[cur];
-    if (n == 0) break;
-    if (tid == 0) s_count[cur ^ 1] = 0;
+    const int n = pool.count[cur];
+    if (n == 0 || round == max_rounds) break;
+    if (tid == 0) pool.count[cur ^ 1] = 0;
     __syncthreads();
     bool more = false;
     int ray = 0;
     if (tid < n) {
-      ray = s_list[cur][tid];
+      ray = pool.list[cur][tid];
       RayConst q;
       RayState rs;
-      pool_load(s_ray + ray * TP_VEC, q, rs);
+      pool_load(pool.ray + ray * TP_VEC, q, rs);
       more = true;
 #pragma unroll 1
       for (int k = 0; k < TRACE_ROUND && more; k++) more = march_step<true, 15>(env, q, rs, 80);
-      pool_store_state(s_ray + ray * TP_VEC, rs);
+      pool_store_state(pool.ray + ray * TP_VEC, rs);
     }
     const uint64_t mm = __ballot(more);
     if (mm) {
       int base = 0;
-      if (lane == 0) base = atomicAdd(&s_count[cur ^ 1], __popcll(mm));
+      if (lane == 0) base = atomicAdd(&pool.count[cur ^ 1], __popcll(mm));
       base = __builtin_amdgcn_readfirstlane(base);
-      if (more) s_list[cur ^ 1][base + wave_rank(mm)] = (uint16_t)ray;
+      if (more) pool.list[cur ^ 1][base + wave_rank(mm)] = (uint16_t)ray;
     }
   }
-  if (!active) return;
-  if (running) pool_load_result(s_ray + tid * TP_VEC, st);  // this thread's ray was finished by another lane
+  return cur;
+}
+
+// ---- frame-wide queue of parked rays (vkr_sssr_trace_split: head launch -> resume launch) -----------------------------------
+// A ray the head launch does not finish is written here with everything the rest of its march and its epilogue need —
+// 80 bytes: {origin, t} {direction, h} {pixel normal, mip | i << 8} {R, roughness} {pixel depth, lx | ly << 16, -, -} —
+// and the resume launch loads 256 consecutive records per block: rays of many tiles in one pool, so its rounds run on full
+// waves where a tile's own stragglers would leave one nearly empty wave per round.  inv_direction and view_vec are
+// recomputed from the record by the very operations that made them (safe_inverse, reconstruct_view_vec: bit-identical).
+#define TQ_VEC 5
+VKR_DEV void queue_store(uint4* r, const RayConst& c, const RayState& s, f3 R, float roughness, float pixel_depth, int lx, int ly) {
+  r[0] = make_uint4(__float_as_uint(c.origin.x), __float_as_uint(c.origin.y), __float_as_uint(c.origin.z), __float_as_uint(s.t));
+  r[1] = make_uint4(__float_as_uint(c.direction.x), __float_as_uint(c.direction.y), __float_as_uint(c.direction.z), __float_as_uint(s.h));
+  r[2] = make_uint4(__float_as_uint(c.normal.x), __float_as_uint(c.normal.y), __float_as_uint(c.normal.z), (uint32_t)(s.mip & 0xFF) | ((uint32_t)s.i << 8));
+  r[3] = make_uint4(__float_as_uint(R.x), __float_as_uint(R.y), __float_as_uint(R.z), __float_as_uint(roughness));
+  r[4] = make_uint4(__float_as_uint(pixel_depth), (uint32_t)lx | ((uint32_t)ly << 16), 0u, 0u);
+}
+
+// the part of trace.comp after the march (:94-139): validity tests, the two stores
+template <bool WINDOWED>
+VKR_DEV void trace_epilogue(const TraceArgs& a, const RayConst& rc, const RayState& st, f3 R, float roughness, float pixel_depth, int lx, int ly) {
+  const Proj pr = a.pr;
+  const Tex& depth0 = a.depth.mip[0];
+  const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
+  const f3 ray_start = rc.origin;
   const f3 out_ray = madd(rc.origin, st.t, rc.direction);
   const float h = st.h;
   const f3 pixel_normal = rc.normal, view_vec = rc.view_vec;
@@ -319,6 +263,190 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
     o.x = float_to_half_bits(result) | (float_to_half_bits(pdf) << 16);
     o.y = 0u;
     *texel_ptr<uint2>(a.out_occ, lx, ly) = o;
+  }
+}
+
+VKR_DEV MarchEnv trace_env(const TraceArgs& a, const uint4* s_mip) {
+  MarchEnv env;
+  env.mip_table = s_mip;
+  env.mip_count = a.depth.count;
+  env.screen_size = mk2((float)a.depth.mip[0].fw, (float)a.depth.mip[0].fh);
+  env.screen_size_inv = a.screen_size_inv;
+  env.uv_offset_abs = a.uv_offset_abs;  // most_detailed_mip = 0
+  env.pr = a.pr;
+  env.horizon_d2 = a.horizon_d2;
+  return env;
+}
+
+// PARK: the head launch of vkr_sssr_trace_split — rays still unfinished after a.park_after compacted rounds leave for the
+// frame-wide queue (their pixels are written by k_sssr_trace_resume)
+template <bool WINDOWED, bool PARK>
+__global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
+  const i2 blk = xcd_block<4, 8 / TRACE_WY>();  // chunks of 128 x 64 output pixels
+  __shared__ uint4 s_mip[16];
+  __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
+  __shared__ TracePool pool;
+  const int tid = threadIdx.x;
+  // wave w owns the 8x8 tile (blk.x*4 + w % 4, blk.y*TRACE_WY + w / 4)
+  const int wave = tid >> 6, lane = tid & 63;
+  const int lx = (blk.x * 4 + (wave & 3)) * 8 + (lane & 7);
+  const int ly = (blk.y * TRACE_WY + (wave >> 2)) * 8 + (lane >> 3);
+  const bool active = lx < a.out_ray.w && ly < a.out_ray.h;
+  const int gx = a.out_ray.ox + lx, gy = a.out_ray.oy + ly;
+  const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
+  const f2 screen_uv = mk2(pixel_centre_uv(gx, tex_size.x), pixel_centre_uv(gy, tex_size.y));
+  const Proj pr = a.pr;
+  const Tex& depth0 = a.depth.mip[0];
+  // the pixel's three samples (trace.comp:49-58) are in flight before the block waits for its tables
+  // (every lane: the texel indices are clamped into the images, and a conditional load would have to be waited for at once)
+  const BilinearTaps taps_material = bilinear_taps_u32(a.material, screen_uv);
+  const BilinearTaps taps_depth = bilinear_taps_u32(depth0, screen_uv);
+  const BilinearTaps taps_normal = bilinear_taps_u32(a.normal, screen_uv);
+  const uint4 my_mip = mip_descriptor(a.depth.mip[(tid & 15) < a.depth.count ? (tid & 15) : 0]);  // (a load from the kernel arguments: every lane, with the others)
+  srgb_lut_stage(s_lut, tid, TRACE_THREADS);
+  if (tid < 16) s_mip[tid] = my_mip;
+  if (tid < 2) pool.count[tid] = 0;
+  __syncthreads();
+
+  const MarchEnv env = trace_env(a, s_mip);
+
+  RayConst rc;
+  RayState st;
+  f3 R = mk3(0, 0, 0);
+  float roughness = 0.0f, pixel_depth = 1.0f;
+  bool running = false;
+  if (active) {
+    // trace.comp:49-58
+    roughness = taps_srgb_channel(taps_material, 1, s_lut);
+    const float mg = mixf(0.0f, a.max_roughness, roughness);
+    roughness = mg * mg;
+    pixel_depth = taps_resolve<FmtD24>(taps_depth);
+    const f3 pixel_normal_world = decode_normal(taps_resolve<FmtRG16U>(taps_normal));
+    rc.normal = normalize(xyz(mul(a.normal_mat, mk4(pixel_normal_world.x, pixel_normal_world.y, pixel_normal_world.z, 0.0f))));
+    rc.view_vec = reconstruct_view_vec(screen_uv, pixel_depth, pr);
+
+    // trace.comp:61-63,156-158: rand() -> Halton index; sin evaluated in double
+    const float rdot = dot(screen_uv, mk2(12.9898f, 78.233f));
+    const float rnd01 = fractf(sin_hash_arg(rdot) * 43758.5453f);
+    const uint32_t base_index = f2u(rnd01 * (float)VKR_HALTON_SEQ_SIZE);
+    const uint32_t index = (base_index + a.frame_random) & (VKR_HALTON_SEQ_SIZE - 1);
+    const float4 hv = a.halton[index];
+
+    // trace.comp:65-77
+    f3 tangent = get_tangent(rc.normal);
+    const f3 bitangent = normalize(cross(rc.normal, tangent));
+    tangent = normalize(cross(bitangent, rc.normal));
+    f3 view_dir = -normalize(rc.view_vec);
+    view_dir = mk3(dot(view_dir, tangent), dot(view_dir, bitangent), dot(view_dir, rc.normal));
+    const f3 brdf_norm = sampleGGXVNDF(view_dir, roughness, roughness, hv.x, hv.z, hv.w);
+    const f3 N = (brdf_norm.x * tangent + brdf_norm.y * bitangent) + brdf_norm.z * rc.normal;
+    R = reflect(rc.view_vec, N);
+
+    // trace.comp:79-84
+    f3 ray_start = project_view_vec(rc.view_vec + 0.001f * rc.normal, pr, a.f_over_fn);
+    ray_start.z -= 0.0001f;
+    f3 ray_dir = project_view_vec(rc.view_vec + R, pr, a.f_over_fn);
+    ray_dir = ray_dir - ray_start;
+    ray_dir = ray_dir * ((1.0f - ray_start.z) / ray_dir.z);
+
+    rc.origin = ray_start;
+    rc.direction = ray_dir;
+    rc.inv_direction = safe_inverse(ray_dir);
+    st.t = initial_advance(env, rc);
+    st.h = 0.0f;  // trace.comp:239
+    st.mip = 0;
+    st.i = 0;
+    // round 0: the first 15 steps never leave mip 0 (specialised step), step 16 (i = 15) is the first that may
+    {
+      const auto fetch0 = [&](int x, int y) -> float {
+        return ((uint32_t)x < (uint32_t)depth0.w && (uint32_t)y < (uint32_t)depth0.h) ? d24_to_float(*(const uint32_t*)(depth0.p + toff(depth0, x, y, 4))) : 0.0f;
+      };
+#pragma unroll 1
+      for (int k = 0; k < 15; k++) march_step_pinned0(env, rc, st, fetch0);
+    }
+    running = march_step<true, 15>(env, rc, st, 80);
+  }
+  pool_park(pool, running, tid, lane, rc, st);
+  const int left = trace_rounds(env, pool, tid, lane, PARK ? a.park_after : 1 << 30);
+  uint32_t parked = 0u;  // slot + 1 of this thread's ray in the block's share of the queue
+  if (PARK) {
+    const int n_left = pool.count[left];  // (uniform: nothing writes the counts after the rounds' last barrier)
+    if (n_left) {
+      if (tid < n_left) ((uint32_t*)(pool.ray + pool.list[left][tid] * TP_VEC))[15] = (uint32_t)tid + 1u;
+      if (tid == 0) pool.queue_base = atomicAdd(a.q.counters, (uint32_t)n_left);
+      __syncthreads();
+    }
+  }
+  if (!active) return;
+  if (running) {  // this thread's ray was advanced by other lanes
+    pool_load_result(pool.ray + tid * TP_VEC, st);
+    if (PARK) {
+      const uint32_t* w = (const uint32_t*)(pool.ray + tid * TP_VEC);
+      parked = w[15];
+      if (parked) { st.mip = (int)(int8_t)(w[11] & 0xFFu); st.i = (int)(w[11] >> 8); }
+    }
+  }
+  if (PARK && parked) {
+    const uint32_t slot = pool.queue_base + parked - 1u;
+    if (slot < a.q.capacity) queue_store(a.q.records + (uint64_t)slot * TQ_VEC, rc, st, R, roughness, pixel_depth, lx, ly);
+    return;
+  }
+  trace_epilogue<WINDOWED>(a, rc, st, R, roughness, pixel_depth, lx, ly);
+}
+
+// The resume launch of vkr_sssr_trace_split: every block takes 256 consecutive records of the queue (the rays of many tiles),
+// marches them to their end in the same compacted rounds and runs the epilogue for their pixels.  The record stays in the
+// queue while its ray marches, so a thread holds nothing across the rounds but its record's index.
+template <bool WINDOWED>
+__global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace_resume(TraceArgs a) {
+  __shared__ uint4 s_mip[16];
+  __shared__ TracePool pool;
+  __shared__ uint32_t s_total;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint4 my_mip = mip_descriptor(a.depth.mip[(tid & 15) < a.depth.count ? (tid & 15) : 0]);
+  if (tid < 16) s_mip[tid] = my_mip;
+  if (tid == 0) {
+    const uint32_t n = *a.q.counters;  // written by the head launch's atomics; the launch boundary makes it visible
+    s_total = n < a.q.capacity ? n : a.q.capacity;
+  }
+  __syncthreads();
+  const uint32_t total = s_total;
+  const MarchEnv env = trace_env(a, s_mip);
+  const Proj pr = a.pr;
+  const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
+  for (uint32_t first = blockIdx.x * TRACE_THREADS; first < total; first += gridDim.x * TRACE_THREADS) {
+    if (tid < 2) pool.count[tid] = 0;
+    __syncthreads();
+    const uint32_t idx = first + (uint32_t)tid;
+    const bool have = idx < total;
+    const uint4* rec = a.q.records + (uint64_t)idx * TQ_VEC;
+    RayConst rc;
+    RayState st;
+    int lx = 0, ly = 0;
+    float pixel_depth = 1.0f;
+    auto load_ray = [&]() {
+      const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r4 = rec[4];
+      rc.origin = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+      rc.direction = mk3(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z));
+      rc.inv_direction = safe_inverse(rc.direction);
+      rc.normal = mk3(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z));
+      pixel_depth = __uint_as_float(r4.x);
+      lx = (int)(r4.y & 0xFFFFu); ly = (int)(r4.y >> 16);
+      const f2 screen_uv = mk2(pixel_centre_uv(a.out_ray.ox + lx, tex_size.x), pixel_centre_uv(a.out_ray.oy + ly, tex_size.y));
+      rc.view_vec = reconstruct_view_vec(screen_uv, pixel_depth, pr);
+      st.t = __uint_as_float(r0.w); st.h = __uint_as_float(r1.w);
+      st.mip = (int)(int8_t)(r2.w & 0xFFu); st.i = (int)(r2.w >> 8);
+    };
+    if (have) load_ray();
+    pool_park(pool, have, tid, lane, rc, st);
+    trace_rounds(env, pool, tid, lane, 1 << 30);
+    if (have) {
+      load_ray();  // (again: cheaper than five more live vectors across the rounds)
+      pool_load_result(pool.ray + tid * TP_VEC, st);
+      const uint4 r3 = rec[3];
+      trace_epilogue<WINDOWED>(a, rc, st, mk3(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z)), __uint_as_float(r3.w), pixel_depth, lx, ly);
+    }
+    __syncthreads();  // the pool is reused by the next chunk
   }
 }
 
@@ -918,6 +1046,7 @@ static int make_trace_args(TraceArgs& a, const vkr_img* depth, const vkr_img* no
   }
   a.nrm_row0 = 0; a.nrm_row1 = a.normal.fh;
   a.pend_mask = a.out_ray; a.pend_data = a.out_ray;  // unused unless windowed
+  a.q.records = nullptr; a.q.counters = nullptr; a.q.capacity = 0; a.park_after = 0;
   return VKR_OK;
 }
 
@@ -929,8 +1058,51 @@ extern "C" int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const
   VKR_TRY(make_trace_args(a, depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, push));
   dim3 block(TRACE_THREADS, 1);
   dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 8 * TRACE_WY - 1) / (8 * TRACE_WY));
-  hipLaunchKernelGGL(k_sssr_trace<false>, grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_sssr_trace<false, false>), grid, block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_trace");
+}
+
+// ---- sssr_trace in two launches (include/vkr_postfx.h: vkr_sssr_trace_split) --------------------------------------------
+#define TQ_HEADER_BYTES 256u
+extern "C" uint64_t vkr_sssr_trace_workspace_bytes(uint32_t rays_width, uint32_t rays_height) {
+  return (uint64_t)TQ_HEADER_BYTES + (uint64_t)rays_width * rays_height * (TQ_VEC * sizeof(uint4));
+}
+
+static int bind_trace_queue(TraceArgs& a, void* workspace, uint64_t workspace_bytes, const char* what) {
+  if (!workspace || ((uintptr_t)workspace % 16) != 0) { set_error("%s: workspace NULL or not 16-byte aligned", what); return VKR_ERR_NULL; }
+  const uint64_t need = vkr_sssr_trace_workspace_bytes((uint32_t)a.out_ray.w, (uint32_t)a.out_ray.h);
+  if (workspace_bytes < need) { set_error("%s: workspace of %llu bytes, %llu needed (vkr_sssr_trace_workspace_bytes)", what, (unsigned long long)workspace_bytes, (unsigned long long)need); return VKR_ERR_EXTENT; }
+  if (a.out_ray.w > 65535 || a.out_ray.h > 65535) { set_error("%s: a parked ray names its pixel in 16 + 16 bits", what); return VKR_ERR_EXTENT; }
+  a.q.counters = (uint32_t*)workspace;
+  a.q.records = (uint4*)((uint8_t*)workspace + TQ_HEADER_BYTES);
+  a.q.capacity = (uint32_t)a.out_ray.w * (uint32_t)a.out_ray.h;
+  return VKR_OK;
+}
+
+// blocks of the resume launch: they loop over the queue, so the grid only has to fill the machine
+static dim3 resume_grid(const TraceArgs& a) {
+  const uint32_t chunks = (a.q.capacity + TRACE_THREADS - 1) / TRACE_THREADS;
+  return dim3(chunks < 2048u ? chunks : 2048u);
+}
+
+extern "C" int vkr_sssr_trace_split(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                                    const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                                    const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_trace_push* push,
+                                    void* workspace, uint64_t workspace_bytes, uint32_t park_after_rounds, void* stream) {
+  TraceArgs a;
+  VKR_TRY(make_trace_args(a, depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, push));
+  VKR_TRY(bind_trace_queue(a, workspace, workspace_bytes, "sssr_trace_split"));
+  if (park_after_rounds > 4) { set_error("sssr_trace_split: park_after_rounds %u (0..4: a march has at most four compacted rounds)", park_after_rounds); return VKR_ERR_EXTENT; }
+  a.park_after = (int)park_after_rounds;
+  dim3 block(TRACE_THREADS, 1);
+  dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 8 * TRACE_WY - 1) / (8 * TRACE_WY));
+  // the queue's counter: zeroed on the stream ahead of the head launch (a reset by the resume launch itself needs every one of
+  // its blocks to report that it has read the count: 2048 atomics on one word, 11 ns each, measured as 22 us)
+  if (hipMemsetAsync(a.q.counters, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) { set_error("sssr_trace_split: memset failed"); return VKR_ERR_LAYOUT; }
+  hipLaunchKernelGGL((k_sssr_trace<false, true>), grid, block, 0, (hipStream_t)stream, a);
+  VKR_TRY(launch_status("sssr_trace_split (head)"));
+  hipLaunchKernelGGL((k_sssr_trace_resume<false>), resume_grid(a), block, 0, (hipStream_t)stream, a);
+  return launch_status("sssr_trace_split (resume)");
 }
 
 extern "C" int vkr_sssr_trace_windowed(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
@@ -958,7 +1130,7 @@ extern "C" int vkr_sssr_trace_windowed(const vkr_img* depth, const vkr_img* norm
   }
   dim3 block(TRACE_THREADS, 1);
   dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 8 * TRACE_WY - 1) / (8 * TRACE_WY));
-  hipLaunchKernelGGL(k_sssr_trace<true>, grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_sssr_trace<true, false>), grid, block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_trace_windowed");
 }
 

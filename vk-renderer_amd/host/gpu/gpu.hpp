@@ -226,6 +226,11 @@ struct LaunchState {
   void* scratch = nullptr;                    // device scratch owned by the command context
   uint64_t scratch_bytes = 0;
   void* stream = nullptr;
+  // a second device buffer of the command context, for programs that need room between their own launches (sssr_trace: the
+  // frame-wide queue of parked rays); grows on demand, lives as long as the context
+  void* workspace = nullptr;
+  uint64_t workspace_bytes = 0;
+  void* require_workspace(uint64_t bytes);
 };
 using ProgramFn = std::function<int(LaunchState&)>;
 // Registers `name` -> C-ABI thunk.  The hot-path programs of src/shaders/config.json are
