@@ -284,6 +284,25 @@ int vkr_sssr_trace_windowed(const vkr_img* depth, const vkr_img* normal, const v
                             const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
                             const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_img* pending_mask,
                             const vkr_img* pending_data, const vkr_trace_window_push* push, void* stream);
+/* vkr_sssr_trace_windowed in two launches AROUND the arrival of the whole-frame pyramid (the depth all-gather of the tiled frame):
+ * the head launch marches on `local_depth` alone — the levels of the pyramid this rank built itself, as the window image
+ * holds them: full-width strips of the frame's levels, rows [origin_y, origin_y + height) each — and parks a ray in
+ * `workspace` (vkr_sssr_trace_split above: same queue, same records) at its first fetch of a texel of the frame that is not
+ * there: a row outside the strip, or a level the window image does not have.  A ray whose march has ended is parked as well
+ * when its hit-depth sample (trace.comp:111-117) needs such a row; rays still marching after park_after_rounds compacted
+ * rounds are parked as in the split.  `frame_depth` gives the head launch the frame's extents and level count only (not
+ * read); once it is complete the resume launch finishes every parked ray on it.  Both launches take the arguments of
+ * vkr_sssr_trace_windowed and leave, together, exactly its images.                                                      */
+int vkr_sssr_trace_windowed_head(const vkr_img* local_depth, const vkr_img* frame_depth, const vkr_img* normal, const vkr_img* material,
+                                 const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                                 const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_img* pending_mask,
+                                 const vkr_img* pending_data, const vkr_trace_window_push* push, void* workspace,
+                                 uint64_t workspace_bytes, uint32_t park_after_rounds, void* stream);
+int vkr_sssr_trace_windowed_resume(const vkr_img* frame_depth, const vkr_img* normal, const vkr_img* material,
+                                   const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                                   const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_img* pending_mask,
+                                   const vkr_img* pending_data, const vkr_trace_window_push* push, void* workspace,
+                                   uint64_t workspace_bytes, void* stream);
 int vkr_sssr_validate(const vkr_img* rays, const vkr_img* pending_mask, const vkr_img* pending_data, const vkr_img* frame_normals,
                       const vkr_trace_params* params, void* stream);
 

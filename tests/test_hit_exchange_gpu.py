@@ -112,3 +112,41 @@ def test_windowed_trace_requests_replies_scatter_validate(oracle_lib):
     a = lower_g.reflections.raw(0)[y0 - oy:], lower_r.reflections.raw(0)[y0 - oy:]
     b = rp.reflections.raw(0)[y0:]
     assert np.array_equal(a[1], b) and np.array_equal(a[0], b), "reflections of the strip differ from the plain frame"
+
+
+@pytest.mark.parametrize("rank,levels,park_after", [(1, 4, 2), (0, 4, 2), (1, 3, 0), (1, 1, 4), (0, 2, 1)])
+def test_windowed_trace_local_rows_first(rank, levels, park_after, oracle_lib):
+    """vkr_sssr_trace_windowed_head + _resume — the head marches on the rank's OWN rows of the first `levels` pyramid levels
+    while the whole-frame pyramid is still poison, parks every ray at its first fetch of a texel that is not there, and the
+    resume launch finishes them on the complete pyramid — against vkr_sssr_trace_windowed on the same strip: rays, (occlusion,
+    pdf), pending mask and pending data bit for bit."""
+    import torch
+
+    _, gr = _chains("product", "cuda")
+    c = gr[rank]
+    c.ssr_trace_windowed(frame_random=0)
+    c.sync()
+    mask, data = c._pending_images()
+    want = {n: getattr(c, n).raw(0).copy() for n in ("rays", "raw")}
+    want_mask, want_data = mask.raw(0).copy(), data.to_host().copy()
+    pend = want_mask[..., 0].astype(bool)
+    for img in (c.rays, c.raw, mask, data):  # whatever the two launches forget to write shows
+        img.upload(np.full(img.nbytes, 0x5A, dtype=np.uint8))
+    hiz_bytes = c.frame_hiz.to_host().copy()
+    c.frame_hiz.upload(np.full(c.frame_hiz.nbytes, 0xEE, dtype=np.uint8))  # "not arrived yet": the head must not read a byte of it
+    c.ssr_trace_windowed_head(levels, frame_random=0, park_after=park_after)
+    c.sync()
+    parked = int(c._trace_workspace[:4].view(torch.int32)[0].item())
+    total = c.rays.width * c.rays.height
+    print(f"[local-first] rank {rank}, {levels} local levels, park after {park_after} rounds: {parked} of {total} rays parked ({parked / total:.3f})")
+    assert 0 < parked < total
+    c.frame_hiz.upload(hiz_bytes)
+    c.ssr_trace_windowed_resume(frame_random=0)
+    c.sync()
+    for n in ("rays", "raw"):
+        assert np.array_equal(getattr(c, n).raw(0), want[n]), f"{n} differs from the one-launch windowed trace"
+    assert np.array_equal(mask.raw(0), want_mask), "pending mask differs"
+    d = data.to_host().reshape(-1)
+    rows_g = d[: data.pitch[0] * data.height].reshape(data.height, data.pitch[0])[:, : data.width * 16].view(np.float32).reshape(data.height, data.width // 2, 8)
+    rows_w = want_data.reshape(-1)[: data.pitch[0] * data.height].reshape(data.height, data.pitch[0])[:, : data.width * 16].view(np.float32).reshape(data.height, data.width // 2, 8)
+    assert np.array_equal(rows_g[pend][:, [0, 1, 2, 4, 5]], rows_w[pend][:, [0, 1, 2, 4, 5]]), "pending R / hit uv differ"

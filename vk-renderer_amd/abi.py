@@ -238,6 +238,9 @@ ENTRY_ARGS = {
     "screen_trace_accumulate": [_IMG, _IMG, _IMG, _IMG, P(ScreenTraceAccumPush)],
     # multi-GPU: hit colours / hit normals by request / reply (no reference counterpart)
     "sssr_trace_windowed": [_IMG, _IMG, _IMG, P(TraceParams), C.c_void_p, _IMG, _IMG, _IMG, _IMG, _IMG, P(TraceWindowPush)],
+    # ... in two launches around the arrival of the whole-frame pyramid: local pyramid first; trailing (workspace, bytes[, park_after_rounds])
+    "sssr_trace_windowed_head": [_IMG, _IMG, _IMG, _IMG, P(TraceParams), C.c_void_p, _IMG, _IMG, _IMG, _IMG, _IMG, P(TraceWindowPush), C.c_void_p, C.c_uint64, C.c_uint32],
+    "sssr_trace_windowed_resume": [_IMG, _IMG, _IMG, P(TraceParams), C.c_void_p, _IMG, _IMG, _IMG, _IMG, _IMG, P(TraceWindowPush), C.c_void_p, C.c_uint64],
     "sssr_validate": [_IMG, _IMG, _IMG, _IMG, P(TraceParams)],
     "hit_requests": [P(HitSources), P(C.c_uint32), C.c_uint32, C.c_void_p, C.c_void_p, P(C.c_uint32), C.c_void_p],
     "hit_reply": [_IMG, _IMG, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p],
@@ -246,7 +249,7 @@ ENTRY_ARGS = {
 
 
 # entries that are a different SCHEDULE of another entry (same images bit for bit): no twin in a checker library
-SCHEDULE_VARIANTS = {"sssr_trace_split": "sssr_trace"}
+SCHEDULE_VARIANTS = {"sssr_trace_split": "sssr_trace", "sssr_trace_windowed_head": "sssr_trace_windowed", "sssr_trace_windowed_resume": "sssr_trace_windowed"}
 
 
 class RectCopy(C.Structure):  # vkr_rect_copy

@@ -277,6 +277,39 @@ class PostFxChain:
                   C.byref(tp), self._halton_ptr(), C.byref(self.rays.desc()), C.byref(self.raw.desc()), C.byref(self.pdf.desc()),
                   C.byref(mask.desc()), C.byref(data.desc()), C.byref(push))
 
+    def _trace_ws(self):
+        import torch
+
+        need = int(self.lib.vkr_sssr_trace_workspace_bytes(self.rays.width, self.rays.height))
+        if getattr(self, "_trace_workspace", None) is None or self._trace_workspace.numel() < need:
+            self._trace_workspace = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        return self._trace_workspace.data_ptr(), need
+
+    def _windowed_args(self, frame_random, max_roughness):
+        mask, data = self._pending_images()
+        tp = self.setup.trace_params(frame_random)
+        oy, h2 = self.dn.origin[1], self.dn.height
+        push = abi.TraceWindowPush(max_roughness, oy, oy + h2)
+        self._wargs = (self.frame_hiz.desc(), self.frame_normals.desc(), self.material.desc(), tp, self.rays.desc(), self.raw.desc(), self.pdf.desc(),
+                       mask.desc(), data.desc(), push)  # kept alive across the call
+        return self._wargs
+
+    def ssr_trace_windowed_head(self, local_levels, frame_random=None, max_roughness=1.0, park_after=2):
+        """vkr_sssr_trace_windowed_head: marches on the window image's own pyramid levels 1..local_levels (product backend only)"""
+        assert self.tiled and self.backend == "product"
+        hiz, nrm, mat, tp, rays, raw, pdf, mask, data, push = self._windowed_args(frame_random, max_roughness)
+        local = self.depth.desc(1, local_levels)
+        ws, need = self._trace_ws()
+        self.call("sssr_trace_windowed_head", C.byref(local), C.byref(hiz), C.byref(nrm), C.byref(mat), C.byref(tp), self._halton_ptr(),
+                  C.byref(rays), C.byref(raw), C.byref(pdf), C.byref(mask), C.byref(data), C.byref(push), ws, need, int(park_after))
+
+    def ssr_trace_windowed_resume(self, frame_random=None, max_roughness=1.0):
+        assert self.tiled and self.backend == "product"
+        hiz, nrm, mat, tp, rays, raw, pdf, mask, data, push = self._windowed_args(frame_random, max_roughness)
+        ws, need = self._trace_ws()
+        self.call("sssr_trace_windowed_resume", C.byref(hiz), C.byref(nrm), C.byref(mat), C.byref(tp), self._halton_ptr(),
+                  C.byref(rays), C.byref(raw), C.byref(pdf), C.byref(mask), C.byref(data), C.byref(push), ws, need)
+
     def ssr_validate(self):
         mask, data = self._pending_images()
         tp = self.setup.trace_params()

@@ -22,7 +22,14 @@ struct MarchEnv {
   Proj pr;
   float horizon_d2;  // smallest d2 with sqrtf(d2) >= 0.3f: |v| < 0.3 <=> dot(v,v) < horizon_d2
   int min_mip = 0;   // most_detailed_mip: the march ends when it would refine below it; uv_offset_abs carries its 2^min_mip
+  // LOCAL marches (multi-GPU head launch): only levels < local_levels are in memory, and of each only frame rows
+  // [win_table[l].x, + win_table[l].y) — mip_table[l] then describes that window image (its base is the window's first row)
+  // but keeps the FRAME's extent in .w, which decides inside / outside the frame.  A step that needs a texel of the frame
+  // that is not there leaves the ray untouched and reports MARCH_PARK.
+  const uint2* win_table = nullptr;
+  int local_levels = 0;
 };
+enum { MARCH_END = 0, MARCH_MORE = 1, MARCH_PARK = 2 };
 
 // The horizon update of trace.comp:253-262: v = reconstruct_view_vec(uv, surface_z) - camera_start, h = max(h, cos) iff
 // |v| < 0.3.  z stays on the exact quotient (div_normal): v is a small difference of two view-space positions, so a
@@ -40,8 +47,8 @@ VKR_DEV void horizon_gate(const MarchEnv& env, const RayConst& rc, RayState& st,
 // One step of the march; returns false when the ray is finished.  HORIZON / PIN_STEPS = 15 / max 80 is
 // hierarchical_raymarch_find_hor (trace.comp:206-268); no horizon / PIN_STEPS = 0 is the generic
 // hierarchical_raymarch (screen_trace.glsl:51-100).
-template <bool HORIZON, int PIN_STEPS>
-VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, int max_steps) {
+template <bool HORIZON, int PIN_STEPS, bool LOCAL>
+VKR_DEV int march_step_ex(const MarchEnv& env, const RayConst& rc, RayState& st, int max_steps) {
   const float scale = __builtin_ldexpf(1.0f, -st.mip), scale_inv = __builtin_ldexpf(1.0f, st.mip);
   const f2 res = mk2(env.screen_size.x * scale, env.screen_size.y * scale);
   const f2 res_inv = mk2(env.screen_size_inv.x * scale_inv, env.screen_size_inv.y * scale_inv);
@@ -54,7 +61,14 @@ VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, i
     const int tx = f2i_index(mip_pos.x), ty = f2i_index(mip_pos.y);
     if ((uint32_t)tx < (m.w & 0xFFFFu) && (uint32_t)ty < (m.w >> 16)) {  // 0 <= t < extent as one unsigned compare per axis
       typedef const __attribute__((address_space(1))) uint32_t* gptr_t;  // a global, not flat, address
-      const uint64_t addr = (((uint64_t)m.y << 32) | m.x) + (uint64_t)(__umul24((uint32_t)ty, m.z) + (uint32_t)tx * 4u);  // 32-bit offset, see toff()
+      uint32_t row = (uint32_t)ty;
+      if (LOCAL) {  // a texel of the frame: is it here?
+        if (st.mip >= env.local_levels) return MARCH_PARK;
+        const uint2 w = env.win_table[st.mip];
+        row -= w.x;
+        if (row >= w.y) return MARCH_PARK;
+      }
+      const uint64_t addr = (((uint64_t)m.y << 32) | m.x) + (uint64_t)(__umul24(row, m.z) + (uint32_t)tx * 4u);  // 32-bit offset, see toff()
       surface_z = d24_to_float(*(gptr_t)addr);
     }
   }
@@ -75,7 +89,11 @@ VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, i
   ++st.i;
   // trace.comp:253-262: horizon tracking around the new position
   if (HORIZON && st.mip <= 1) horizon_gate(env, rc, st, madd(xy(rc.origin), st.t, xy(rc.direction)), surface_z);
-  return st.i < max_steps && st.mip >= env.min_mip;
+  return (st.i < max_steps && st.mip >= env.min_mip) ? MARCH_MORE : MARCH_END;
+}
+template <bool HORIZON, int PIN_STEPS>
+VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, int max_steps) {
+  return march_step_ex<HORIZON, PIN_STEPS, false>(env, rc, st, max_steps) == MARCH_MORE;
 }
 
 
@@ -83,11 +101,18 @@ VKR_DEV bool march_step(const MarchEnv& env, const RayConst& rc, RayState& st, i
 // mip): march_step<true, 15> for a ray with st.mip == 0 and st.i < 15, with everything that is then known folded in —
 // the level scale is 2^0 (res = screen_size, the same floats), the mip does not change, the horizon update always
 // runs (mip 0 <= 1), the ray cannot end.  fetch0(tx, ty) returns texel (tx, ty) of pyramid level 0, 0 outside it.
-template <class Fetch0>
-VKR_DEV void march_step_pinned0(const MarchEnv& env, const RayConst& rc, RayState& st, const Fetch0& fetch0) {
+// LOCAL: fetch0(tx, ty, &z) returns false when the texel is a texel of the frame that is not in memory: the ray stays as it is and
+// the step reports false.
+template <bool LOCAL, class Fetch0>
+VKR_DEV bool march_step_pinned0(const MarchEnv& env, const RayConst& rc, RayState& st, const Fetch0& fetch0) {
   const f3 position = madd(rc.origin, st.t, rc.direction);
   const f2 mip_pos = env.screen_size * xy(position);
-  const float surface_z = fetch0(f2i_index(mip_pos.x), f2i_index(mip_pos.y));
+  float surface_z;
+  if (LOCAL) {
+    if (!fetch0(f2i_index(mip_pos.x), f2i_index(mip_pos.y), &surface_z)) return false;
+  } else {
+    fetch0(f2i_index(mip_pos.x), f2i_index(mip_pos.y), &surface_z);
+  }
   const f2 uv_offset = mk2(rc.direction.x < 0.0f ? -env.uv_offset_abs.x : env.uv_offset_abs.x,
                            rc.direction.y < 0.0f ? -env.uv_offset_abs.y : env.uv_offset_abs.y);
   const f2 floor_offset = mk2(rc.direction.x < 0.0f ? 0.0f : 1.0f, rc.direction.y < 0.0f ? 0.0f : 1.0f);
@@ -99,6 +124,7 @@ VKR_DEV void march_step_pinned0(const MarchEnv& env, const RayConst& rc, RayStat
   st.t = surface_z > position.z ? t_min : st.t;
   ++st.i;
   horizon_gate(env, rc, st, madd(xy(rc.origin), st.t, xy(rc.direction)), surface_z);
+  return true;
 }
 
 // the LDS descriptor of one pyramid level

@@ -59,6 +59,9 @@ struct TraceArgs {
   // vkr_sssr_trace_split: the frame-wide queue of the rays the head launch parks after park_after compacted rounds
   struct { uint4* records; uint32_t* counters; uint32_t capacity; } q;
   int park_after;
+  // vkr_sssr_trace_windowed_head: the rows of the pyramid this rank holds before the all-gather has arrived — the window image's
+  // own levels (local.count of them; `depth` then only tells the frame's extents and level count, it is not read)
+  Pyramid local;
 };
 
 #define TP_VEC 5  // uint4 per parked-ray record (18 dwords used): 80-byte stride, conflict-free for consecutive rays
@@ -117,7 +120,7 @@ struct TracePool {
   uint4 ray[TRACE_THREADS * TP_VEC];  // record of ray (= owner thread) r: RayConst, t, h, mip | i << 8; word 15: parked slot + 1
   uint16_t list[2][TRACE_THREADS];
   int count[2];
-  uint32_t queue_base;
+  uint32_t parked_n, queue_base;
 };
 
 // park this thread's unfinished ray (one list reservation per wave: rank within the ballot)
@@ -134,6 +137,8 @@ VKR_DEV void pool_park(TracePool& pool, bool running, int tid, int lane, const R
 
 // Compacted rounds: thread k of the block advances the k-th unfinished ray by TRACE_ROUND steps, at most max_rounds times.
 // Returns the list that holds the rays still unfinished (pool.count[that] of them; none when the march ran to its end).
+// LOCAL: a ray that needs a texel of the frame that is not in memory stops where it is (word 15 of its record: parked).
+template <bool LOCAL>
 VKR_DEV int trace_rounds(const MarchEnv& env, TracePool& pool, int tid, int lane, int max_rounds) {
   int cur = 0;
   for (int round = 0;; cur ^= 1, round++) {
@@ -149,9 +154,17 @@ VKR_DEV int trace_rounds(const MarchEnv& env, TracePool& pool, int tid, int lane
       RayConst q;
       RayState rs;
       pool_load(pool.ray + ray * TP_VEC, q, rs);
-      more = true;
+      if (LOCAL) {
+        int r = MARCH_MORE;
 #pragma unroll 1
-      for (int k = 0; k < TRACE_ROUND && more; k++) more = march_step<true, 15>(env, q, rs, 80);
+        for (int k = 0; k < TRACE_ROUND && r == MARCH_MORE; k++) r = march_step_ex<true, 15, true>(env, q, rs, 80);
+        more = r == MARCH_MORE;
+        if (r == MARCH_PARK) ((uint32_t*)(pool.ray + ray * TP_VEC))[15] = 1u;
+      } else {
+        more = true;
+#pragma unroll 1
+        for (int k = 0; k < TRACE_ROUND && more; k++) more = march_step<true, 15>(env, q, rs, 80);
+      }
       pool_store_state(pool.ray + ray * TP_VEC, rs);
     }
     const uint64_t mm = __ballot(more);
@@ -172,19 +185,20 @@ VKR_DEV int trace_rounds(const MarchEnv& env, TracePool& pool, int tid, int lane
 // waves where a tile's own stragglers would leave one nearly empty wave per round.  inv_direction and view_vec are
 // recomputed from the record by the very operations that made them (safe_inverse, reconstruct_view_vec: bit-identical).
 #define TQ_VEC 5
-VKR_DEV void queue_store(uint4* r, const RayConst& c, const RayState& s, f3 R, float roughness, float pixel_depth, int lx, int ly) {
+#define TQ_FINISHED 0x80000000u  // in the mip | i << 8 word: the march has ended, only the epilogue is owed (its hit depth lies on rows not held)
+VKR_DEV void queue_store(uint4* r, const RayConst& c, const RayState& s, f3 R, float roughness, float pixel_depth, int lx, int ly, bool finished) {
   r[0] = make_uint4(__float_as_uint(c.origin.x), __float_as_uint(c.origin.y), __float_as_uint(c.origin.z), __float_as_uint(s.t));
   r[1] = make_uint4(__float_as_uint(c.direction.x), __float_as_uint(c.direction.y), __float_as_uint(c.direction.z), __float_as_uint(s.h));
-  r[2] = make_uint4(__float_as_uint(c.normal.x), __float_as_uint(c.normal.y), __float_as_uint(c.normal.z), (uint32_t)(s.mip & 0xFF) | ((uint32_t)s.i << 8));
+  r[2] = make_uint4(__float_as_uint(c.normal.x), __float_as_uint(c.normal.y), __float_as_uint(c.normal.z),
+                    (uint32_t)(s.mip & 0xFF) | ((uint32_t)s.i << 8) | (finished ? TQ_FINISHED : 0u));
   r[3] = make_uint4(__float_as_uint(R.x), __float_as_uint(R.y), __float_as_uint(R.z), __float_as_uint(roughness));
   r[4] = make_uint4(__float_as_uint(pixel_depth), (uint32_t)lx | ((uint32_t)ly << 16), 0u, 0u);
 }
 
 // the part of trace.comp after the march (:94-139): validity tests, the two stores
 template <bool WINDOWED>
-VKR_DEV void trace_epilogue(const TraceArgs& a, const RayConst& rc, const RayState& st, f3 R, float roughness, float pixel_depth, int lx, int ly) {
+VKR_DEV void trace_epilogue(const TraceArgs& a, const Tex& depth0, const RayConst& rc, const RayState& st, f3 R, float roughness, float pixel_depth, int lx, int ly) {
   const Proj pr = a.pr;
-  const Tex& depth0 = a.depth.mip[0];
   const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
   const f3 ray_start = rc.origin;
   const f3 out_ray = madd(rc.origin, st.t, rc.direction);
@@ -278,12 +292,45 @@ VKR_DEV MarchEnv trace_env(const TraceArgs& a, const uint4* s_mip) {
   return env;
 }
 
-// PARK: the head launch of vkr_sssr_trace_split — rays still unfinished after a.park_after compacted rounds leave for the
-// frame-wide queue (their pixels are written by k_sssr_trace_resume)
-template <bool WINDOWED, bool PARK>
+// the level table of a block: levels of `depth` (whole-frame extents), bases of `local` where the march is LOCAL
+template <bool LOCAL>
+VKR_DEV void stage_mip_tables(const TraceArgs& a, int tid, uint4* s_mip, uint2* s_win) {
+  const int l = tid & 15;
+  const Tex& f = a.depth.mip[l < a.depth.count ? l : 0];  // (a load from the kernel arguments: every lane, with the others)
+  uint4 d = mip_descriptor(f);
+  uint2 w = make_uint2(0u, 0u);
+  if (LOCAL) {
+    const Tex& t = a.local.mip[l < a.local.count ? l : 0];
+    const uint64_t base = (uint64_t)t.p;
+    d = make_uint4((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)t.pitch, (uint32_t)f.w | ((uint32_t)f.h << 16));
+    w = make_uint2((uint32_t)t.oy, (uint32_t)t.h);
+  }
+  if (tid < 16) { s_mip[tid] = d; if (LOCAL) s_win[tid] = w; }
+}
+
+// LOCAL epilogue guard: does the hit-depth sample of trace.comp:111-117 (texture(depth, hit uv) on level 0) touch a row of the
+// frame that is not held?  Evaluated only for rays that pass the tests before it (same order as trace_epilogue<true>).
+VKR_DEV bool hit_depth_rows_missing(const TraceArgs& a, const RayConst& rc, const RayState& st, f3 R) {
+  const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
+  const f3 out_ray = madd(rc.origin, st.t, rc.direction);
+  const f2 ray_step = mk2(fabsf(out_ray.x - rc.origin.x) * tex_size.x, fabsf(out_ray.y - rc.origin.y) * tex_size.y);
+  if (vmax(ray_step.x, ray_step.y) < 2.0f) return false;
+  if (dot(rc.normal, R) < 0.0f) return false;
+  const Tex& l0 = a.local.mip[0];
+  const int y0 = f2i(floorf(cfma(out_ray.y, (float)l0.fh, -0.5f)));
+  const int r0 = iclamp(y0, 0, l0.fh - 1), r1 = iclamp(y0 + 1, 0, l0.fh - 1);
+  return r0 < l0.oy || r1 >= l0.oy + l0.h;
+}
+
+// PARK: a head launch (vkr_sssr_trace_split, vkr_sssr_trace_windowed_head) — rays still unfinished after a.park_after
+// compacted rounds leave for the frame-wide queue and their pixels are written by k_sssr_trace_resume.
+// LOCAL (multi-GPU head): the pyramid is `a.local`, the rows of the first levels this rank computed itself; a ray is parked
+// at its first fetch of a texel of the frame that is not there, and a finished ray whose hit-depth sample needs such rows too.
+template <bool WINDOWED, bool PARK, bool LOCAL>
 __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   const i2 blk = xcd_block<4, 8 / TRACE_WY>();  // chunks of 128 x 64 output pixels
   __shared__ uint4 s_mip[16];
+  __shared__ uint2 s_win[LOCAL ? 16 : 1];
   __shared__ float s_lut[VKR_SRGB_LUT_SIZE];
   __shared__ TracePool pool;
   const int tid = threadIdx.x;
@@ -296,25 +343,26 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
   const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
   const f2 screen_uv = mk2(pixel_centre_uv(gx, tex_size.x), pixel_centre_uv(gy, tex_size.y));
   const Proj pr = a.pr;
-  const Tex& depth0 = a.depth.mip[0];
+  const Tex& depth0 = LOCAL ? a.local.mip[0] : a.depth.mip[0];
   // the pixel's three samples (trace.comp:49-58) are in flight before the block waits for its tables
   // (every lane: the texel indices are clamped into the images, and a conditional load would have to be waited for at once)
   const BilinearTaps taps_material = bilinear_taps_u32(a.material, screen_uv);
   const BilinearTaps taps_depth = bilinear_taps_u32(depth0, screen_uv);
   const BilinearTaps taps_normal = bilinear_taps_u32(a.normal, screen_uv);
-  const uint4 my_mip = mip_descriptor(a.depth.mip[(tid & 15) < a.depth.count ? (tid & 15) : 0]);  // (a load from the kernel arguments: every lane, with the others)
   srgb_lut_stage(s_lut, tid, TRACE_THREADS);
-  if (tid < 16) s_mip[tid] = my_mip;
+  stage_mip_tables<LOCAL>(a, tid, s_mip, s_win);
   if (tid < 2) pool.count[tid] = 0;
+  if (tid == 2) pool.parked_n = 0u;
   __syncthreads();
 
-  const MarchEnv env = trace_env(a, s_mip);
+  MarchEnv env = trace_env(a, s_mip);
+  if (LOCAL) { env.win_table = s_win; env.local_levels = a.local.count; }
 
   RayConst rc;
   RayState st;
   f3 R = mk3(0, 0, 0);
   float roughness = 0.0f, pixel_depth = 1.0f;
-  bool running = false;
+  bool running = false, parked = false;
   if (active) {
     // trace.comp:49-58
     roughness = taps_srgb_channel(taps_material, 1, s_lut);
@@ -357,54 +405,80 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
     st.mip = 0;
     st.i = 0;
     // round 0: the first 15 steps never leave mip 0 (specialised step), step 16 (i = 15) is the first that may
-    {
-      const auto fetch0 = [&](int x, int y) -> float {
-        return ((uint32_t)x < (uint32_t)depth0.w && (uint32_t)y < (uint32_t)depth0.h) ? d24_to_float(*(const uint32_t*)(depth0.p + toff(depth0, x, y, 4))) : 0.0f;
+    if (!LOCAL) {
+      const auto fetch0 = [&](int x, int y, float* z) -> bool {
+        *z = ((uint32_t)x < (uint32_t)depth0.w && (uint32_t)y < (uint32_t)depth0.h) ? d24_to_float(*(const uint32_t*)(depth0.p + toff(depth0, x, y, 4))) : 0.0f;
+        return true;
       };
 #pragma unroll 1
-      for (int k = 0; k < 15; k++) march_step_pinned0(env, rc, st, fetch0);
+      for (int k = 0; k < 15; k++) march_step_pinned0<false>(env, rc, st, fetch0);
+      running = march_step<true, 15>(env, rc, st, 80);
+    } else {
+      // level 0 of the frame is depth0.fw x depth0.fh; rows [depth0.oy, + depth0.h) of it are here
+      const auto fetch0 = [&](int x, int y, float* z) -> bool {
+        *z = 0.0f;
+        if ((uint32_t)x >= (uint32_t)depth0.fw || (uint32_t)y >= (uint32_t)depth0.fh) return true;  // outside the frame: 0
+        const uint32_t row = (uint32_t)(y - depth0.oy);
+        if (row >= (uint32_t)depth0.h) return false;
+        *z = d24_to_float(*(const uint32_t*)(depth0.p + toff(depth0, x, (int)row, 4)));
+        return true;
+      };
+      bool ok = true;
+#pragma unroll 1
+      for (int k = 0; k < 15 && ok; k++) ok = march_step_pinned0<true>(env, rc, st, fetch0);
+      int r = MARCH_PARK;
+      if (ok) r = march_step_ex<true, 15, true>(env, rc, st, 80);
+      running = r == MARCH_MORE;
+      parked = r == MARCH_PARK;
     }
-    running = march_step<true, 15>(env, rc, st, 80);
   }
   pool_park(pool, running, tid, lane, rc, st);
-  const int left = trace_rounds(env, pool, tid, lane, PARK ? a.park_after : 1 << 30);
-  uint32_t parked = 0u;  // slot + 1 of this thread's ray in the block's share of the queue
+  const int left = trace_rounds<LOCAL>(env, pool, tid, lane, PARK ? a.park_after : 1 << 30);
+  bool finished_parked = false;  // LOCAL: the march has ended but its epilogue needs depth rows that are not here
   if (PARK) {
     const int n_left = pool.count[left];  // (uniform: nothing writes the counts after the rounds' last barrier)
     if (n_left) {
-      if (tid < n_left) ((uint32_t*)(pool.ray + pool.list[left][tid] * TP_VEC))[15] = (uint32_t)tid + 1u;
-      if (tid == 0) pool.queue_base = atomicAdd(a.q.counters, (uint32_t)n_left);
+      if (tid < n_left) ((uint32_t*)(pool.ray + pool.list[left][tid] * TP_VEC))[15] = 1u;
       __syncthreads();
     }
+    if (running) {  // this thread's ray was advanced by other lanes
+      const uint32_t* w = (const uint32_t*)(pool.ray + tid * TP_VEC);
+      pool_load_result(pool.ray + tid * TP_VEC, st);
+      st.mip = (int)(int8_t)(w[11] & 0xFFu); st.i = (int)(w[11] >> 8);
+      parked = w[15] != 0u;
+    }
+    if (LOCAL && active && !parked) { finished_parked = hit_depth_rows_missing(a, rc, st, R); parked = finished_parked; }
+    // slots of the queue: one reservation per wave in LDS, one per block in the frame-wide counter
+    const uint64_t pm = __ballot(parked);
+    uint32_t wbase = 0u;
+    if (lane == 0 && pm) wbase = atomicAdd(&pool.parked_n, (uint32_t)__popcll(pm));
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+    __syncthreads();
+    if (tid == 0 && pool.parked_n) pool.queue_base = atomicAdd(a.q.counters, pool.parked_n);
+    __syncthreads();
+    if (parked) {
+      const uint32_t slot = pool.queue_base + wbase + (uint32_t)wave_rank(pm);
+      if (slot < a.q.capacity) queue_store(a.q.records + (uint64_t)slot * TQ_VEC, rc, st, R, roughness, pixel_depth, lx, ly, finished_parked);
+      return;
+    }
+  } else if (running) {
+    pool_load_result(pool.ray + tid * TP_VEC, st);
   }
   if (!active) return;
-  if (running) {  // this thread's ray was advanced by other lanes
-    pool_load_result(pool.ray + tid * TP_VEC, st);
-    if (PARK) {
-      const uint32_t* w = (const uint32_t*)(pool.ray + tid * TP_VEC);
-      parked = w[15];
-      if (parked) { st.mip = (int)(int8_t)(w[11] & 0xFFu); st.i = (int)(w[11] >> 8); }
-    }
-  }
-  if (PARK && parked) {
-    const uint32_t slot = pool.queue_base + parked - 1u;
-    if (slot < a.q.capacity) queue_store(a.q.records + (uint64_t)slot * TQ_VEC, rc, st, R, roughness, pixel_depth, lx, ly);
-    return;
-  }
-  trace_epilogue<WINDOWED>(a, rc, st, R, roughness, pixel_depth, lx, ly);
+  // (LOCAL: level 0 as this rank holds it — hit_depth_rows_missing() has sent every ray that needs other rows to the queue)
+  trace_epilogue<WINDOWED>(a, depth0, rc, st, R, roughness, pixel_depth, lx, ly);
 }
 
-// The resume launch of vkr_sssr_trace_split: every block takes 256 consecutive records of the queue (the rays of many tiles),
-// marches them to their end in the same compacted rounds and runs the epilogue for their pixels.  The record stays in the
-// queue while its ray marches, so a thread holds nothing across the rounds but its record's index.
+// The resume launch: every block takes 256 consecutive records of the queue (the rays of many tiles), marches them to their
+// end in the same compacted rounds and runs the epilogue for their pixels.  The record stays in the queue while its ray
+// marches, so a thread holds nothing across the rounds but its record's index.
 template <bool WINDOWED>
 __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace_resume(TraceArgs a) {
   __shared__ uint4 s_mip[16];
   __shared__ TracePool pool;
   __shared__ uint32_t s_total;
   const int tid = threadIdx.x, lane = tid & 63;
-  const uint4 my_mip = mip_descriptor(a.depth.mip[(tid & 15) < a.depth.count ? (tid & 15) : 0]);
-  if (tid < 16) s_mip[tid] = my_mip;
+  stage_mip_tables<false>(a, tid, s_mip, nullptr);
   if (tid == 0) {
     const uint32_t n = *a.q.counters;  // written by the head launch's atomics; the launch boundary makes it visible
     s_total = n < a.q.capacity ? n : a.q.capacity;
@@ -424,6 +498,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace_resume(TraceArgs a
     RayState st;
     int lx = 0, ly = 0;
     float pixel_depth = 1.0f;
+    bool finished = false;
     auto load_ray = [&]() {
       const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r4 = rec[4];
       rc.origin = mk3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
@@ -435,16 +510,18 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace_resume(TraceArgs a
       const f2 screen_uv = mk2(pixel_centre_uv(a.out_ray.ox + lx, tex_size.x), pixel_centre_uv(a.out_ray.oy + ly, tex_size.y));
       rc.view_vec = reconstruct_view_vec(screen_uv, pixel_depth, pr);
       st.t = __uint_as_float(r0.w); st.h = __uint_as_float(r1.w);
-      st.mip = (int)(int8_t)(r2.w & 0xFFu); st.i = (int)(r2.w >> 8);
+      st.mip = (int)(int8_t)(r2.w & 0xFFu); st.i = (int)((r2.w & ~TQ_FINISHED) >> 8);
+      finished = (r2.w & TQ_FINISHED) != 0u;
     };
     if (have) load_ray();
-    pool_park(pool, have, tid, lane, rc, st);
-    trace_rounds(env, pool, tid, lane, 1 << 30);
+    const bool marching = have && !finished;
+    pool_park(pool, marching, tid, lane, rc, st);
+    trace_rounds<false>(env, pool, tid, lane, 1 << 30);
     if (have) {
       load_ray();  // (again: cheaper than five more live vectors across the rounds)
-      pool_load_result(pool.ray + tid * TP_VEC, st);
+      if (marching) pool_load_result(pool.ray + tid * TP_VEC, st);
       const uint4 r3 = rec[3];
-      trace_epilogue<WINDOWED>(a, rc, st, mk3(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z)), __uint_as_float(r3.w), pixel_depth, lx, ly);
+      trace_epilogue<WINDOWED>(a, a.depth.mip[0], rc, st, mk3(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z)), __uint_as_float(r3.w), pixel_depth, lx, ly);
     }
     __syncthreads();  // the pool is reused by the next chunk
   }
@@ -1047,6 +1124,8 @@ static int make_trace_args(TraceArgs& a, const vkr_img* depth, const vkr_img* no
   a.nrm_row0 = 0; a.nrm_row1 = a.normal.fh;
   a.pend_mask = a.out_ray; a.pend_data = a.out_ray;  // unused unless windowed
   a.q.records = nullptr; a.q.counters = nullptr; a.q.capacity = 0; a.park_after = 0;
+  a.local.count = 0;
+  for (int i = 0; i < 16; i++) a.local.mip[i] = a.depth.mip[0];
   return VKR_OK;
 }
 
@@ -1058,7 +1137,7 @@ extern "C" int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const
   VKR_TRY(make_trace_args(a, depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, push));
   dim3 block(TRACE_THREADS, 1);
   dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 8 * TRACE_WY - 1) / (8 * TRACE_WY));
-  hipLaunchKernelGGL((k_sssr_trace<false, false>), grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_sssr_trace<false, false, false>), grid, block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_trace");
 }
 
@@ -1099,39 +1178,97 @@ extern "C" int vkr_sssr_trace_split(const vkr_img* depth, const vkr_img* normal,
   // the queue's counter: zeroed on the stream ahead of the head launch (a reset by the resume launch itself needs every one of
   // its blocks to report that it has read the count: 2048 atomics on one word, 11 ns each, measured as 22 us)
   if (hipMemsetAsync(a.q.counters, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) { set_error("sssr_trace_split: memset failed"); return VKR_ERR_LAYOUT; }
-  hipLaunchKernelGGL((k_sssr_trace<false, true>), grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_sssr_trace<false, true, false>), grid, block, 0, (hipStream_t)stream, a);
   VKR_TRY(launch_status("sssr_trace_split (head)"));
   hipLaunchKernelGGL((k_sssr_trace_resume<false>), resume_grid(a), block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_trace_split (resume)");
 }
 
-extern "C" int vkr_sssr_trace_windowed(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
-                                       const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
-                                       const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_img* pending_mask,
-                                       const vkr_img* pending_data, const vkr_trace_window_push* push, void* stream) {
-  if (!push) { set_error("sssr_trace_windowed: NULL argument"); return VKR_ERR_NULL; }
-  TraceArgs a;
+static int make_windowed_args(TraceArgs& a, const vkr_img* depth, const vkr_img* normal, const vkr_img* material, const vkr_trace_params* params,
+                              const float* halton_vec4, const vkr_img* out_ray, const vkr_img* out_occlusion, const vkr_img* pdf_tex,
+                              const vkr_img* pending_mask, const vkr_img* pending_data, const vkr_trace_window_push* push, const char* what) {
+  if (!push) { set_error("%s: NULL argument", what); return VKR_ERR_NULL; }
   const vkr_trace_push base {push->max_roughness};
   VKR_TRY(make_trace_args(a, depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, &base));
   if (a.normal.ox != 0 || a.normal.oy != 0 || a.normal.w != a.normal.fw || a.normal.h != a.normal.fh) {
-    set_error("sssr_trace_windowed: `normal` must be the whole-frame image (rows outside the window are filled later)");
+    set_error("%s: `normal` must be the whole-frame image (rows outside the window are filled later)", what);
     return VKR_ERR_EXTENT;
   }
   if (push->normal_row0 >= push->normal_row1 || push->normal_row1 > (uint32_t)a.normal.fh) {
-    set_error("sssr_trace_windowed: normal rows [%u, %u) of %d", push->normal_row0, push->normal_row1, a.normal.fh);
+    set_error("%s: normal rows [%u, %u) of %d", what, push->normal_row0, push->normal_row1, a.normal.fh);
     return VKR_ERR_EXTENT;
   }
   a.nrm_row0 = (int)push->normal_row0; a.nrm_row1 = (int)push->normal_row1;
   VKR_TRY(make_tex(pending_mask, 0, VKR_FMT_R8_UNORM, "sssr_trace_windowed.pending_mask", &a.pend_mask));
   VKR_TRY(make_tex(pending_data, 0, VKR_FMT_RGBA32_SFLOAT, "sssr_trace_windowed.pending_data", &a.pend_data));
   if (a.pend_mask.w != a.out_ray.w || a.pend_mask.h != a.out_ray.h || a.pend_data.w != 2 * a.out_ray.w || a.pend_data.h != a.out_ray.h) {
-    set_error("sssr_trace_windowed: pending_mask must have the rays' extent, pending_data twice its width");
+    set_error("%s: pending_mask must have the rays' extent, pending_data twice its width", what);
     return VKR_ERR_EXTENT;
   }
+  return VKR_OK;
+}
+
+extern "C" int vkr_sssr_trace_windowed(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
+                                       const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                                       const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_img* pending_mask,
+                                       const vkr_img* pending_data, const vkr_trace_window_push* push, void* stream) {
+  TraceArgs a;
+  VKR_TRY(make_windowed_args(a, depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, pending_mask, pending_data, push, "sssr_trace_windowed"));
   dim3 block(TRACE_THREADS, 1);
   dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 8 * TRACE_WY - 1) / (8 * TRACE_WY));
-  hipLaunchKernelGGL((k_sssr_trace<true, false>), grid, block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_sssr_trace<true, false, false>), grid, block, 0, (hipStream_t)stream, a);
   return launch_status("sssr_trace_windowed");
+}
+
+// The windowed trace in two launches around the arrival of the whole-frame pyramid (include/vkr_postfx.h).
+extern "C" int vkr_sssr_trace_windowed_head(const vkr_img* local_depth, const vkr_img* frame_depth, const vkr_img* normal, const vkr_img* material,
+                                            const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                                            const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_img* pending_mask,
+                                            const vkr_img* pending_data, const vkr_trace_window_push* push, void* workspace,
+                                            uint64_t workspace_bytes, uint32_t park_after_rounds, void* stream) {
+  const char* P = "sssr_trace_windowed_head";
+  TraceArgs a;
+  VKR_TRY(make_windowed_args(a, frame_depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, pending_mask, pending_data, push, P));
+  VKR_TRY(bind_trace_queue(a, workspace, workspace_bytes, P));
+  if (park_after_rounds > 4) { set_error("%s: park_after_rounds %u (0..4)", P, park_after_rounds); return VKR_ERR_EXTENT; }
+  a.park_after = (int)park_after_rounds;
+  if (!local_depth || local_depth->mip_count < 1 || local_depth->mip_count > (uint32_t)a.depth.count) { set_error("%s: the local pyramid must have 1 .. %d levels", P, a.depth.count); return VKR_ERR_MIPS; }
+  a.local.count = (int)local_depth->mip_count;
+  for (int i = 0; i < a.local.count; i++) {
+    Tex& t = a.local.mip[i];
+    VKR_TRY(make_tex(local_depth, i, VKR_FMT_D24_UNORM_S8, "sssr_trace_windowed_head.local_depth", &t));
+    const Tex& f = a.depth.mip[i];
+    // a strip of the frame's level: full width, rows [oy, oy + h) — and the same texel grid as the frame's level
+    if (t.ox != 0 || t.w != t.fw || t.fw != f.fw || t.fh != f.fh) {
+      set_error("%s: level %d of the local pyramid (%dx%d of %dx%d at row %d) is not a strip of the frame's level (%dx%d)", P, i, t.w, t.h, t.fw, t.fh, t.oy, f.fw, f.fh);
+      return VKR_ERR_EXTENT;
+    }
+  }
+  for (int i = a.local.count; i < 16; i++) a.local.mip[i] = a.local.mip[0];
+  // the pixels of this launch sample level 0 at their own position: their rows must be among the local ones
+  if (a.out_ray.oy < a.local.mip[0].oy || a.out_ray.oy + a.out_ray.h > a.local.mip[0].oy + a.local.mip[0].h) {
+    set_error("%s: the rays' rows [%d, %d) are not inside the local rows of level 0 [%d, %d)", P, a.out_ray.oy, a.out_ray.oy + a.out_ray.h,
+              a.local.mip[0].oy, a.local.mip[0].oy + a.local.mip[0].h);
+    return VKR_ERR_EXTENT;
+  }
+  if (hipMemsetAsync(a.q.counters, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) { set_error("%s: memset failed", P); return VKR_ERR_LAYOUT; }
+  dim3 block(TRACE_THREADS, 1);
+  dim3 grid((a.out_ray.w + 31) / 32, (a.out_ray.h + 8 * TRACE_WY - 1) / (8 * TRACE_WY));
+  hipLaunchKernelGGL((k_sssr_trace<true, true, true>), grid, block, 0, (hipStream_t)stream, a);
+  return launch_status(P);
+}
+
+extern "C" int vkr_sssr_trace_windowed_resume(const vkr_img* frame_depth, const vkr_img* normal, const vkr_img* material,
+                                              const vkr_trace_params* params, const float* halton_vec4, const vkr_img* out_ray,
+                                              const vkr_img* out_occlusion, const vkr_img* pdf_tex, const vkr_img* pending_mask,
+                                              const vkr_img* pending_data, const vkr_trace_window_push* push, void* workspace,
+                                              uint64_t workspace_bytes, void* stream) {
+  const char* P = "sssr_trace_windowed_resume";
+  TraceArgs a;
+  VKR_TRY(make_windowed_args(a, frame_depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, pending_mask, pending_data, push, P));
+  VKR_TRY(bind_trace_queue(a, workspace, workspace_bytes, P));
+  hipLaunchKernelGGL((k_sssr_trace_resume<true>), resume_grid(a), dim3(TRACE_THREADS, 1), 0, (hipStream_t)stream, a);
+  return launch_status(P);
 }
 
 extern "C" int vkr_sssr_validate(const vkr_img* rays, const vkr_img* pending_mask, const vkr_img* pending_data, const vkr_img* frame_normals,

@@ -122,6 +122,8 @@ struct PostFxFrame {
       ssr.get_settings().use_tile_classification = (mask & VKRH_STAGE_SSR_CLASSIFIED) != 0;
       ssr.run(graph, assr_params, draw_params, gbuffer, gtao.raw);
     }
+    if (mask & VKRH_STAGE_SSR_TRACE_HEAD) ssr.run_trace_head(graph, assr_params, gbuffer, gtao.raw, hiz_gathered_mips);
+    if (mask & VKRH_STAGE_SSR_TRACE_RESUME) ssr.run_trace_resume(graph, gbuffer, gtao.raw);
     if (mask & VKRH_STAGE_SSR_TRACE) ssr.run_trace(graph, assr_params, gbuffer, gtao.raw);
     if (mask & VKRH_STAGE_SSR_RESOLVE) ssr.run_resolve(graph, assr_params, draw_params, gbuffer);
     if (mask & VKRH_STAGE_GTAO_MAIN_ONLY)
@@ -443,6 +445,9 @@ struct TiledFrame {
     uint64_t wire_bytes = 0;
     bool counted = false;
   } hit;
+  // the trace in two stages around the gather (needs the pending-ray images of the request / reply mode); VKR_TILED_LOCAL_FIRST=0: one stage
+  bool local_first() const { return normals_by_request() && local_first_enabled; }
+  bool local_first_enabled = getenv("VKR_TILED_LOCAL_FIRST") == nullptr || std::string {getenv("VKR_TILED_LOCAL_FIRST")} != "0";
   bool by_request() const { return tiled && cfg.world > 1 && cfg.albedo_by_gather != 1; }          // hit colours
   bool normals_by_request() const { return tiled && cfg.world > 1 && cfg.albedo_by_gather == 0; }   // ... and hit normals
   vkr_img dn_img() { return frame->graph.get_image(frame->gbuffer.downsampled_normals)->describe(0, 1); }
@@ -630,10 +635,13 @@ struct TiledFrame {
         f.run(VKRH_STAGE_TAA);
         copy_halo(VKRH_HALO_TAA, true);
         start_halo(VKRH_HALO_TAA);
+        // local rows first: prologue, pinned steps and as much of every march as this rank's own pyramid rows allow run while
+        // the depth all-gather is still on the wire; a ray that needs more is parked (csrc/ssr.hip, k_sssr_trace<.., LOCAL>)
+        if (local_first()) f.run(VKRH_STAGE_SSR_TRACE_HEAD);
         break;
       case 2:
         wait(VKRH_GATHER_HIZ);
-        f.run(VKRH_STAGE_HIZ_TAIL | VKRH_STAGE_SSR_TRACE);
+        f.run(VKRH_STAGE_HIZ_TAIL | (local_first() ? VKRH_STAGE_SSR_TRACE_RESUME : VKRH_STAGE_SSR_TRACE));
         if (by_request()) {
           if (cfg.comm) hit_exchange_native();  // count -> all-gather of the counts -> host copy, all on the exchange stream
           else hit_count(compute);

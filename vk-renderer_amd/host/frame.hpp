@@ -45,6 +45,11 @@ enum {
   VKRH_STAGE_SSR_TRACE          = 1u << 15, /* first half of ssr.run: the trace (needs the Hi-Z pyramid)                    */
   VKRH_STAGE_SSR_RESOLVE        = 1u << 16, /* second half of ssr.run: filter + blur (needs albedo at the hit positions)      */
   VKRH_STAGE_RASTER             = 1u << 17, /* scene_renderer.draw_taa on the loaded scene (main.cpp:345) instead of the generator */
+  /* tiled, hit normals by request: the trace as two stages around the arrival of the gathered pyramid — the head marches on the
+   * window's own levels 1..gathered_mips and parks what needs more, the resume finishes the parked rays on the whole-frame
+   * pyramid (after VKRH_STAGE_HIZ_TAIL).  HEAD + RESUME leave what VKRH_STAGE_SSR_TRACE leaves.                          */
+  VKRH_STAGE_SSR_TRACE_HEAD     = 1u << 18,
+  VKRH_STAGE_SSR_TRACE_RESUME   = 1u << 19,
   VKRH_STAGE_CHAIN      = (1u << 3) | (1u << 5) | (1u << 6) | (1u << 7)
 };
 

@@ -335,6 +335,29 @@ void register_hot_path_programs() {
       return vkr_sssr_trace_windowed(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), halton_table(h.buffer.get(), st.stream),
                                      &rays, &occ, &pdf, &mask, &data, push<vkr_trace_window_push>(st, P), st.stream);
     });
+    // the windowed trace in two tasks (include/vkr_postfx.h): bindings of sssr_trace_windowed, the head with the window's own
+    // pyramid levels at 0 and the whole-frame pyramid (extents only) at 10; both use the context's workspace
+    create_program("sssr_trace_windowed_head", [=](LaunchState& st) {
+      const char* P = "sssr_trace_windowed_head";
+      vkr_img local = tex(st, 0, T, P), frame = tex(st, 10, T, P), normal = tex(st, 1, T, P), material = tex(st, 2, T, P);
+      vkr_img rays = tex(st, 5, S, P), occ = tex(st, 6, S, P), pdf = tex(st, 7, T, P), mask = tex(st, 8, S, P), data = tex(st, 9, S, P);
+      const SetSlot& h = st.set->slots[4];
+      if (h.kind != SetSlot::Ubo || !h.buffer) throw std::runtime_error{"sssr_trace_windowed_head: Halton buffer (binding 4) is not bound"};
+      const uint64_t bytes = vkr_sssr_trace_workspace_bytes(rays.width, rays.height);
+      return vkr_sssr_trace_windowed_head(&local, &frame, &normal, &material, ubo<vkr_trace_params>(st, 3, P), halton_table(h.buffer.get(), st.stream),
+                                          &rays, &occ, &pdf, &mask, &data, push<vkr_trace_window_push>(st, P), st.require_workspace(bytes), bytes, 2u, st.stream);
+    });
+    create_program("sssr_trace_windowed_resume", [=](LaunchState& st) {
+      const char* P = "sssr_trace_windowed_resume";
+      vkr_img depth = tex(st, 0, T, P), normal = tex(st, 1, T, P), material = tex(st, 2, T, P);
+      vkr_img rays = tex(st, 5, S, P), occ = tex(st, 6, S, P), pdf = tex(st, 7, T, P), mask = tex(st, 8, S, P), data = tex(st, 9, S, P);
+      const SetSlot& h = st.set->slots[4];
+      if (h.kind != SetSlot::Ubo || !h.buffer) throw std::runtime_error{"sssr_trace_windowed_resume: Halton buffer (binding 4) is not bound"};
+      const uint64_t bytes = vkr_sssr_trace_workspace_bytes(rays.width, rays.height);
+      if (st.workspace_bytes < bytes) throw std::runtime_error{"sssr_trace_windowed_resume: no head launch has filled the workspace"};
+      return vkr_sssr_trace_windowed_resume(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), halton_table(h.buffer.get(), st.stream),
+                                            &rays, &occ, &pdf, &mask, &data, push<vkr_trace_window_push>(st, P), st.workspace, bytes, st.stream);
+    });
     create_program("sssr_filter", [=](LaunchState& st) {
       const char* P = "sssr_filter";
       vkr_img rays = tex(st, 0, T, P), depth = tex(st, 1, T, P), albedo = tex(st, 2, T, P), normal = tex(st, 3, T, P);

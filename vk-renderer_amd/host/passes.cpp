@@ -535,6 +535,33 @@ void AdvancedSSR::run_trace(RenderGraph &graph, const AdvancedSSRParams &params,
   }
 }
 
+void AdvancedSSR::run_trace_head(RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff, ImageResourceId ssr_occlusion, uint32_t local_levels) {
+  if (!gbuff.tiled || !gbuff.normals_by_request) throw std::runtime_error {"run_trace_head: only the tiled frame with hit normals by request traces in two tasks"};
+  if (settings.use_tile_classification) throw std::runtime_error {"run_trace_head: not with tile classification"};
+  head_config = trace_params(params, counter);
+  advance_counter();
+  if (!trace_head_pass.has_program()) trace_head_pass = gpu::create_compute_pipeline("sssr_trace_windowed_head");
+  const uint32_t mips = graph.get_descriptor(gbuff.frame_hiz).mip_levels;
+  const vkr_trace_window_push wpc {settings.max_rougness, gbuff.normal_row0, gbuff.normal_row1};
+  rec::compute(graph, "SSSR_trace", trace_head_pass,
+    {rec::sampled_mips(0, gbuff.depth, sampler, DEPTH, 1, local_levels), rec::sampled(1, gbuff.frame_normals, sampler), rec::sampled(2, gbuff.material, sampler),
+     rec::uniform(3, head_config), rec::uniform_buffer(4, halton_buffer), rec::storage(5, rays), rec::storage(6, ssr_occlusion),
+     rec::sampled(7, preintegrated_pdf, sampler), rec::storage(8, gbuff.pend_mask), rec::storage(9, gbuff.pend_data),
+     rec::sampled_mips(10, gbuff.frame_hiz, sampler, DEPTH, 0, mips)},  // extents and level count only: its rows are still arriving
+    rec::push(wpc), rec::Grid {rays, 8, 8, rec::Ceil});
+}
+
+void AdvancedSSR::run_trace_resume(RenderGraph &graph, const Gbuffer &gbuff, ImageResourceId ssr_occlusion) {
+  if (!trace_resume_pass.has_program()) trace_resume_pass = gpu::create_compute_pipeline("sssr_trace_windowed_resume");
+  const uint32_t mips = graph.get_descriptor(gbuff.frame_hiz).mip_levels;
+  const vkr_trace_window_push wpc {settings.max_rougness, gbuff.normal_row0, gbuff.normal_row1};
+  rec::compute(graph, "SSSR_trace_resume", trace_resume_pass,
+    {rec::sampled_mips(0, gbuff.frame_hiz, sampler, DEPTH, 0, mips), rec::sampled(1, gbuff.frame_normals, sampler), rec::sampled(2, gbuff.material, sampler),
+     rec::uniform(3, head_config), rec::uniform_buffer(4, halton_buffer), rec::storage(5, rays), rec::storage(6, ssr_occlusion),
+     rec::sampled(7, preintegrated_pdf, sampler), rec::storage(8, gbuff.pend_mask), rec::storage(9, gbuff.pend_data)},
+    rec::push(wpc), rec::Grid {rays, 8, 8, rec::Ceil});
+}
+
 void AdvancedSSR::run_resolve(RenderGraph &graph, const AdvancedSSRParams &params, const DrawTAAParams &taa_params, const Gbuffer &gbuff) {
   run_filter_pass(graph, params, gbuff);
   run_blur_pass(graph, params, taa_params, gbuff);

@@ -421,6 +421,11 @@ struct AdvancedSSR {
   // trace needs the gathered Hi-Z pyramid, the filter the gathered albedo)
   void run_trace(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion);
   void run_resolve(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const DrawTAAParams &taa_params, const Gbuffer &gbuff);
+  // multi-GPU (hit normals by request): the trace as two tasks AROUND the arrival of the gathered pyramid.  run_trace_head marches
+  // on the window image's own levels 1..local_levels of gbuff.depth and parks what needs more (vkr_sssr_trace_windowed_head);
+  // run_trace_resume finishes the parked rays on gbuff.frame_hiz once it is complete.  Together: run_trace's images.
+  void run_trace_head(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion, uint32_t local_levels);
+  void run_trace_resume(rendergraph::RenderGraph &graph, const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion);
 
   // advanced_ssr.cpp:440-495,216-302 (private in the reference; public here so drivers can record them one by one)
   void clear_indirect_params(rendergraph::RenderGraph &graph);
@@ -442,6 +447,7 @@ private:
 
   gpu::ComputePipeline trace_pass;
   gpu::ComputePipeline trace_windowed_pass;  // multi-GPU: hit normals by request (not in the reference)
+  gpu::ComputePipeline trace_head_pass, trace_resume_pass;  // ... in two tasks around the arrival of the gathered pyramid
   gpu::ComputePipeline filter_pass;
   gpu::ComputePipeline blur_pass;
   gpu::ComputePipeline preintegrate_pass;
@@ -466,6 +472,7 @@ private:
 
   uint32_t counter {0u};
   Settings settings;
+  vkr_trace_params head_config {};  // what run_trace_head handed to its launch: run_trace_resume continues the same rays
 
   void advance_counter();
   void run_trace_pass(rendergraph::RenderGraph &graph, const AdvancedSSRParams &params, const Gbuffer &gbuff, rendergraph::ImageResourceId ssr_occlusion);
