@@ -305,6 +305,10 @@ int vkr_sssr_trace_windowed_resume(const vkr_img* frame_depth, const vkr_img* no
                                    uint64_t workspace_bytes, void* stream);
 int vkr_sssr_validate(const vkr_img* rays, const vkr_img* pending_mask, const vkr_img* pending_data, const vkr_img* frame_normals,
                       const vkr_trace_params* params, void* stream);
+/* the same, unless *skip_if_set (a device word, read by the launch) is non-zero: a round of requests that dropped some (see
+ * vkr_hit_requests_bounded) has not delivered every hit normal, and the test must wait for the exact round               */
+int vkr_sssr_validate_unless(const vkr_img* rays, const vkr_img* pending_mask, const vkr_img* pending_data, const vkr_img* frame_normals,
+                             const vkr_trace_params* params, const uint32_t* skip_if_set, void* stream);
 
 /* program "sssr_filter": advanced_ssr.cpp:308-369 + filter.comp (bindings 0..6)          */
 int vkr_sssr_filter(const vkr_img* rays, const vkr_img* depth, const vkr_img* albedo,
@@ -521,9 +525,18 @@ typedef struct vkr_hit_sources {
 #define VKR_HIT_WORKSPACE_WORDS 4096u
 int vkr_hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* workspace,
                      const uint32_t* segments, vkr_hit_request* out, void* stream);
+/* Pass 2 into segments of FIXED capacity (sized from the previous frame's counts, so that both ends of the exchange know the
+ * message sizes without waiting for this frame's): owner o's requests from out[segments[o]] on, at most capacities[o] of them —
+ * what does not fit is dropped (the caller compares this frame's counts with the capacities afterwards and repeats the round
+ * exactly if any segment overflowed).  Slots a segment does not use must hold VKR_HIT_NO_REQUEST (fill `out` with 0xFF bytes
+ * first): vkr_hit_reply answers such a slot with zeros and counts no error, vkr_hit_scatter skips it.                      */
+#define VKR_HIT_NO_REQUEST 0xFFFFFFFFu
+int vkr_hit_requests_bounded(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* workspace,
+                             const uint32_t* segments, const uint32_t* capacities, vkr_hit_request* out,
+                             uint32_t* dropped_flag /* device word, zeroed by the caller: set to 1 when a request was dropped */, void* stream);
 /* replies (device, 16 bytes each, 16-byte aligned): the texel pair(s) of requests[i] from this rank's albedo / downsampled-
  * normal window (normals may be NULL when no normal request can arrive); a request for texels the window does not hold
- * answers 0 and increments *error_counter                                                                              */
+ * answers 0, increments error_counter[0] and leaves one such request and its index in error_counter[1], [2] (3 words)                                                                              */
 #define VKR_HIT_REPLY_BYTES 16u
 int vkr_hit_reply(const vkr_img* albedo, const vkr_img* normals, const vkr_hit_request* requests, uint32_t count, void* replies,
                   uint32_t* error_counter, void* stream);

@@ -23,8 +23,14 @@ MAX_WAVES_PER_SIMD = 8
 HOT = {
     "k_downsample_gbuffer": ("hiz.hip", 256, 32, 0, 0, 8),
     "k_depth_mips_fused": ("hiz.hip", 256, 32, 0, 2048, 8),
-    "k_sssr_trace<false>": ("ssr.hip", 256, 72, 0, 23 * 1024, 7),
-    "k_sssr_trace<true>": ("ssr.hip", 256, 72, 0, 23 * 1024, 7),
+    # <WINDOWED, PARK, LOCAL>: one launch / head of the split (single GPU) / windowed one launch / multi-GPU head on local rows
+    "k_sssr_trace<false, false, false>": ("ssr.hip", 256, 72, 0, 23 * 1024, 7),
+    "k_sssr_trace<false, true, false>": ("ssr.hip", 256, 72, 0, 23 * 1024, 7),
+    "k_sssr_trace<true, false, false>": ("ssr.hip", 256, 72, 0, 23 * 1024, 7),
+    "k_sssr_trace<true, true, true>": ("ssr.hip", 256, 80, 0, 23 * 1024, 6),
+    # the resume launch is latency-bound (a tenth of the rays, 3 blocks per CU): registers are not what limits it
+    "k_sssr_trace_resume<false>": ("ssr.hip", 256, 96, 0, 23 * 1024, 5),
+    "k_sssr_trace_resume<true>": ("ssr.hip", 256, 96, 0, 23 * 1024, 5),
     "k_sssr_filter": ("ssr.hip", 256, 64, 0, 12 * 1024 + 256, 8),
     "k_sssr_blur": ("ssr.hip", 512, 128, 16, 48 * 1024, 4),
     "k_gtao_main<true, true>": ("gtao.hip", 1024, 64, 0, 21 * 1024, 8),   # 16-wave blocks: > 64 VGPRs means ONE block per CU

@@ -112,6 +112,15 @@ WORKER = textwrap.dedent("""
             if n:
                 print(f'rank {rank} {name} halo rows {lo}..{hi}: {n} texels differ from the neighbour interior')
             bad += n
+    # the hit-colour rounds: the first frame waits for the counts on the host, every later one goes out on the previous frame's
+    # capacities; VKR_HIT_CAP_PERCENT=30 (a test case) makes segments too small, and the overflowing frames repeat their round exactly
+    spec, exact, repeated = t.frame.tiled_hit_rounds()
+    print(f'[rounds] rank {rank}: speculative {spec} exact {exact} repeated {repeated}')
+    if t.frame.gather_mode != 1:
+        want_repeat = os.environ.get('VKR_HIT_CAP_PERCENT') is not None
+        if exact != 1 or spec != FRAMES - 1 or (repeated > 0) != want_repeat:
+            print(f'rank {rank}: unexpected hit rounds (frames {FRAMES}, forced overflow {want_repeat})')
+            bad += 1
     dist.barrier()
     torch.cuda.synchronize()
     t.frame.close(); plain.frame.close()
@@ -181,6 +190,7 @@ def _wire_log(path, world):
     # five-rank case of round 3 stood AT the box's limit of six processes on the card (five ranks + this process) and a run
     # of round 4 was killed by the guard with seven counted; no case here needs more than four ranks.
     ([0, 160, 368, 592], True, 3, False),
+    ([0, 160, 320, 480], True, 4, "overflow"),     # segments sized at 30 % of the previous frame's counts: every later frame overflows and repeats its round exactly
 ])
 def test_native_tiled_frame_between_real_processes(bounds, moving, frames, by_broadcast, tmp_path):
     world = len(bounds) - 1
@@ -190,6 +200,10 @@ def test_native_tiled_frame_between_real_processes(bounds, moving, frames, by_br
     env = dict(os.environ, VKR_RCCL_LIBRARY=_stub(), VKR_STUB_RCCL_LOG=str(log), VKR_STUB_RCCL_TIMEOUT_S="120", VKR_BOUNDS=json.dumps(bounds),
                VKR_MOVING="1" if moving else "0", VKR_FRAMES=str(frames), HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("VKR_GATHER_V_BROADCAST", None)
+    env.pop("VKR_HIT_CAP_PERCENT", None)
+    if by_broadcast == "overflow":
+        env["VKR_HIT_CAP_PERCENT"] = "30"
+        by_broadcast = False
     if by_broadcast:
         env["VKR_GATHER_V_BROADCAST"] = "1"
     rc, out, err = _launch(world, [str(script)], env, timeout=420)

@@ -34,7 +34,9 @@ struct HitReqArgs {
   uint32_t* counts;         // pass 1: per owner
   uint32_t* workspace;      // [block][HIT_MAX_WORLD]: what each block of pass 1 counted per owner; pass 2 turns it into the blocks' bases
   uint32_t seg[HIT_MAX_WORLD];  // pass 2: first request of owner o's segment
+  uint32_t cap[HIT_MAX_WORLD];  // pass 2: room in owner o's segment (requests beyond it are dropped: vkr_hit_requests_bounded)
   vkr_hit_request* out;     // NULL: pass 1
+  uint32_t* dropped;        // bounded pass 2: set to 1 when a request did not fit its segment (or NULL)
 };
 
 // One thread per ray texel of a 64 x 16 tile.  A launch has at most HIT_BLOCKS blocks of 1024 threads; a block walks tiles
@@ -105,10 +107,10 @@ VKR_DEV int hit_emit(const HitReqArgs& a, const HitRay& r, uint32_t* code, uint3
 }
 
 __global__ __launch_bounds__(1024) void k_hit_requests(HitReqArgs a, HitTile g) {
-  __shared__ uint32_t s_n[HIT_MAX_WORLD], s_base[HIT_MAX_WORLD];
+  __shared__ uint32_t s_n[HIT_MAX_WORLD], s_base[HIT_MAX_WORLD], s_end[HIT_MAX_WORLD];  // s_end: one past the last slot of the owner's segment
   const int tid = threadIdx.x;
   const int tiles = g.tiles_x * g.tiles_y;
-  if (tid < HIT_MAX_WORLD) { s_n[tid] = 0u; s_base[tid] = a.seg[tid]; }
+  if (tid < HIT_MAX_WORLD) { s_n[tid] = 0u; s_base[tid] = a.seg[tid]; s_end[tid] = a.cap[tid] == 0xFFFFFFFFu ? 0xFFFFFFFFu : a.seg[tid] + a.cap[tid]; }
   __syncthreads();
   if (a.out) {  // pass 2: my base per owner = the segment's start + everything the blocks before me counted in pass 1
     const uint32_t o = (uint32_t)tid & (HIT_MAX_WORLD - 1);
@@ -127,7 +129,11 @@ __global__ __launch_bounds__(1024) void k_hit_requests(HitReqArgs a, HitTile g) 
       const int n = hit_emit(a, r[j], code, owner);
       for (int k = 0; k < n; k++) {
         const uint32_t slot = atomicAdd(&s_n[owner[k]], 1u);
-        if (a.out) a.out[s_base[owner[k]] + slot] = code[k];
+        if (a.out) {
+          const uint32_t at = s_base[owner[k]] + slot;
+          if (at < s_end[owner[k]]) a.out[at] = code[k];
+          else if (a.dropped) *a.dropped = 1u;  // a bounded segment drops what does not fit, and says so
+        }
       }
     }
   }
@@ -146,11 +152,13 @@ __global__ __launch_bounds__(256) void k_hit_reply(Tex albedo, Tex normals, uint
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= count) return;
   const uint32_t r = req[i];
+  if (r == VKR_HIT_NO_REQUEST) { replies[i] = make_uint4(0u, 0u, 0u, 0u); return; }  // an unused slot of a fixed-capacity segment
   const bool nrm = (r & VKR_HIT_NORMAL) != 0u, both = (r & VKR_HIT_BOTH_ROWS) != 0u;
   const Tex& t = nrm ? normals : albedo;
   const int ly = (int)(r & 0x3FFFu) - t.oy, lx = (int)((r >> 14) & 0x3FFFu) - t.ox;
   if ((nrm && !has_normals) || ly < 0 || ly + (both ? 1 : 0) >= t.h || lx < 0 || lx + 1 >= t.w) {  // not mine: the ranks' strips disagree
     atomicAdd(errors, 1u);
+    errors[1] = r; errors[2] = i;  // (diagnostics: one of the offending requests and its slot)
     replies[i] = make_uint4(0u, 0u, 0u, 0u);
     return;
   }
@@ -163,6 +171,7 @@ __global__ __launch_bounds__(256) void k_hit_scatter(Tex frame_albedo, Tex frame
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= count) return;
   const uint32_t r = req[i];
+  if (r == VKR_HIT_NO_REQUEST) return;
   const uint4 v = replies[i];
   const Tex& t = (r & VKR_HIT_NORMAL) ? frame_normals : frame_albedo;
   const int row = (int)(r & 0x3FFFu), x = (int)((r >> 14) & 0x3FFFu);
@@ -178,8 +187,8 @@ __global__ __launch_bounds__(256) void k_hit_scatter(Tex frame_albedo, Tex frame
 
 using namespace vkr;
 
-extern "C" int vkr_hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* workspace,
-                                const uint32_t* segments, vkr_hit_request* out, void* stream) {
+static int hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* workspace,
+                        const uint32_t* segments, const uint32_t* capacities, vkr_hit_request* out, uint32_t* dropped, void* stream) {
   if (!src || !row_bounds || (!out && !counts) || (out && (!workspace || !segments))) { set_error("hit_requests: NULL argument"); return VKR_ERR_NULL; }
   if (world < 1 || world > HIT_MAX_WORLD) { set_error("hit_requests: world %u (1..%d)", world, HIT_MAX_WORLD); return VKR_ERR_EXTENT; }
   if (src->albedo_width > 16384 || src->albedo_height > 16384) { set_error("hit_requests: a request packs row and column into 14 bits each (frame <= 16384)"); return VKR_ERR_EXTENT; }
@@ -211,14 +220,29 @@ extern "C" int vkr_hit_requests(const vkr_hit_sources* src, const uint32_t* row_
     }
     a.nw = (int)src->normal_width; a.nh = (int)src->normal_height; a.nrow0 = src->normal_row0; a.nrow1 = src->normal_row1;
   }
-  a.counts = counts; a.workspace = workspace; a.out = out;
-  for (uint32_t r = 0; r < HIT_MAX_WORLD; r++) a.seg[r] = (out && r < world) ? segments[r] : 0u;
+  a.counts = counts; a.workspace = workspace; a.out = out; a.dropped = dropped;
+  for (uint32_t r = 0; r < HIT_MAX_WORLD; r++) {
+    a.seg[r] = (out && r < world) ? segments[r] : 0u;
+    a.cap[r] = (out && capacities && r < world) ? capacities[r] : 0xFFFFFFFFu;
+  }
   HitTile g;
   g.tiles_x = (a.rays.w + 63) / 64;
   g.tiles_y = (a.rays.h + HIT_TILE_H - 1) / HIT_TILE_H + 1;  // one more row of tiles: see hit_load
   const int tiles = g.tiles_x * g.tiles_y;
   hipLaunchKernelGGL(k_hit_requests, dim3((uint32_t)(tiles < HIT_BLOCKS ? tiles : HIT_BLOCKS)), dim3(1024), 0, (hipStream_t)stream, a, g);
   return launch_status("hit_requests");
+}
+
+extern "C" int vkr_hit_requests(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* counts, uint32_t* workspace,
+                                const uint32_t* segments, vkr_hit_request* out, void* stream) {
+  return hit_requests(src, row_bounds, world, counts, workspace, segments, nullptr, out, nullptr, stream);
+}
+
+extern "C" int vkr_hit_requests_bounded(const vkr_hit_sources* src, const uint32_t* row_bounds, uint32_t world, uint32_t* workspace,
+                                        const uint32_t* segments, const uint32_t* capacities, vkr_hit_request* out, uint32_t* dropped_flag,
+                                        void* stream) {
+  if (!out || !capacities || !dropped_flag) { set_error("hit_requests_bounded: NULL argument"); return VKR_ERR_NULL; }
+  return hit_requests(src, row_bounds, world, nullptr, workspace, segments, capacities, out, dropped_flag, stream);
 }
 
 extern "C" int vkr_hit_reply(const vkr_img* albedo, const vkr_img* normals, const vkr_hit_request* requests, uint32_t count, void* replies,

@@ -530,7 +530,8 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace_resume(TraceArgs a
 // ---- sssr_validate: the deferred hit-normal test of the windowed trace (trace.comp:103-109) -----------------------
 // For every pixel the windowed trace left pending (its hit-normal footprint was not in memory yet): the same sample, the
 // same dot product; a ray that fails becomes invalid (w = 1.0), exactly what the one-GPU trace would have stored.
-__global__ __launch_bounds__(256) void k_sssr_validate(Tex rays, Tex pend_mask, Tex pend_data, Tex normal, Mat4 normal_mat) {
+__global__ __launch_bounds__(256) void k_sssr_validate(Tex rays, Tex pend_mask, Tex pend_data, Tex normal, Mat4 normal_mat, const uint32_t* skip_if_set) {
+  if (skip_if_set && *skip_if_set != 0u) return;  // the hit normals are not all here (vkr_sssr_validate_unless)
   const int lx = blockIdx.x * 64 + threadIdx.x, ly = blockIdx.y * 4 + threadIdx.y;
   if (lx >= rays.w || ly >= rays.h) return;
   if (*texel_ptr<uint8_t>(pend_mask, lx, ly) == 0u) return;
@@ -1273,6 +1274,11 @@ extern "C" int vkr_sssr_trace_windowed_resume(const vkr_img* frame_depth, const 
 
 extern "C" int vkr_sssr_validate(const vkr_img* rays, const vkr_img* pending_mask, const vkr_img* pending_data, const vkr_img* frame_normals,
                                  const vkr_trace_params* params, void* stream) {
+  return vkr_sssr_validate_unless(rays, pending_mask, pending_data, frame_normals, params, nullptr, stream);
+}
+
+extern "C" int vkr_sssr_validate_unless(const vkr_img* rays, const vkr_img* pending_mask, const vkr_img* pending_data, const vkr_img* frame_normals,
+                                        const vkr_trace_params* params, const uint32_t* skip_if_set, void* stream) {
   if (!params) { set_error("sssr_validate: NULL argument"); return VKR_ERR_NULL; }
   Tex r, m, pd, n;
   VKR_TRY(make_tex(rays, 0, VKR_FMT_RGBA16_UNORM, "sssr_validate.rays", &r));
@@ -1283,7 +1289,7 @@ extern "C" int vkr_sssr_validate(const vkr_img* rays, const vkr_img* pending_mas
   Mat4 nm;
   load_mat(nm, params->normal_mat);
   const dim3 block(64, 4);
-  hipLaunchKernelGGL(k_sssr_validate, grid2d(r.w, r.h, block), block, 0, (hipStream_t)stream, r, m, pd, n, nm);
+  hipLaunchKernelGGL(k_sssr_validate, grid2d(r.w, r.h, block), block, 0, (hipStream_t)stream, r, m, pd, n, nm, skip_if_set);
   return launch_status("sssr_validate");
 }
 

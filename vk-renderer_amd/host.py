@@ -105,6 +105,8 @@ def lib():
         l.vkrh_tiled_hit_replies.argtypes = [C.c_void_p, C.POINTER(HaloPeer), C.c_uint32, C.POINTER(C.c_uint32)]
         l.vkrh_tiled_hit_finish.argtypes = [C.c_void_p]
         l.vkrh_tiled_hit_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        l.vkrh_tiled_hit_rounds.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        l.vkrh_tiled_local_first.argtypes = [C.c_void_p]
         l.vkrh_tiled_hit_errors.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         l.vkrh_tiled_time_waits.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_tiled_wait_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -393,6 +395,15 @@ class HostFrame:
         e = C.c_uint32(0)
         self._check(lib().vkrh_tiled_hit_errors(self.tiled_handle, C.byref(e)))
         return int(e.value)
+
+    def tiled_hit_rounds(self):
+        """(rounds enqueued on the previous frame's capacities, exact rounds after a host round trip, rounds repeated after an overflow)"""
+        r = (C.c_uint64 * 3)()
+        self._check(lib().vkrh_tiled_hit_rounds(self.tiled_handle, r))
+        return int(r[0]), int(r[1]), int(r[2])
+
+    def tiled_local_first(self):
+        return bool(lib().vkrh_tiled_local_first(self.tiled_handle))
 
     def tiled_hit_bytes(self):
         b = C.c_uint64(0)

@@ -444,6 +444,16 @@ struct TiledFrame {
     std::vector<uint32_t> out_seg, in_seg;  // [world + 1]: my requests for owner o / the requests of rank r for me, as runs
     uint64_t wire_bytes = 0;
     bool counted = false;
+    // Native wire without a host round trip: the room of every rank-to-owner segment THIS frame, derived on every rank from
+    // LAST frame's world x world counts (identical everywhere: the counts are all-gathered).  With it the whole round — requests,
+    // both exchanges, replies, scatter — is enqueued behind the trace at once; the host only looks at this frame's counts
+    // afterwards (phase 4) and repeats the round exactly if a segment was too small.  Empty: no previous frame yet.
+    std::vector<uint32_t> cap_matrix;
+    std::vector<uint32_t> caps_out;     // [world]: row `rank` of cap_matrix (what vkr_hit_requests_bounded takes)
+    hipEvent_t ev_counts = nullptr;     // this frame's counts (and last frame's reply errors) have reached host_counts
+    bool speculative = false;           // this frame's round went out on capacities
+    uint32_t cap_percent = 125;         // room = this share of last frame's count (+ 64, rounded up to 64); VKR_HIT_CAP_PERCENT
+    uint64_t rounds_speculative = 0, rounds_exact = 0, rounds_repeated = 0;
   } hit;
   // the trace in two stages around the gather (needs the pending-ray images of the request / reply mode); VKR_TILED_LOCAL_FIRST=0: one stage
   bool local_first() const { return normals_by_request() && local_first_enabled; }
@@ -472,12 +482,15 @@ struct TiledFrame {
     const uint32_t w = cfg.world;
     if (w > 16) throw std::runtime_error {"tiled frame: the request / reply exchange is laid out for at most 16 ranks"};
     hit.counts = (uint32_t*)gpu::device_alloc(sizeof(uint32_t) * HIT_WORDS);
+    check(hipMemset(hit.counts, 0, sizeof(uint32_t) * HIT_WORDS), "memset");  // (the error word is read before the first count clears it)
     hit.workspace = (uint32_t*)gpu::device_alloc(sizeof(uint32_t) * VKR_HIT_WORKSPACE_WORDS);
-    check(hipHostMalloc((void**)&hit.host_counts, sizeof(uint32_t) * (w * w + 1), hipHostMallocDefault), "pinned counts");
+    check(hipHostMalloc((void**)&hit.host_counts, sizeof(uint32_t) * (w * w + 4), hipHostMallocDefault), "pinned counts");
     hit.out_seg.assign(w + 1, 0); hit.in_seg.assign(w + 1, 0);
     // room for what this rank can ask for — every ray of its window ending on another strip — and the same for what it
     // may be asked (anything beyond grows, see grow())
-    const uint64_t worst = (normals_by_request() ? 2ull : 1ull) * (W / 2) * (wh / 2) + 1024;  // one request per ray and surface (two only where a footprint straddles two strips)
+    // (the worst case — every ray of the window ending on another strip, (4 + 16) B x 2 directions x 2 surfaces — was
+    // 370 MB per rank at c4 for an exchange that moves 10 - 30 MB; a quarter of the rays is still 4x what the frames ask, and grow() covers the rest)
+    const uint64_t worst = ((normals_by_request() ? 2ull : 1ull) * (W / 2) * (wh / 2)) / 4 + 4096;
     uint64_t cap = 0;
     grow((void**)&hit.req_out, &cap, worst, sizeof(vkr_hit_request));
     grow((void**)&hit.reply_in, &hit.cap_out, worst, VKR_HIT_REPLY_BYTES);
@@ -485,11 +498,14 @@ struct TiledFrame {
     grow((void**)&hit.req_in, &cap, worst, sizeof(vkr_hit_request));
     grow((void**)&hit.reply_out, &hit.cap_in, worst, VKR_HIT_REPLY_BYTES);
     grew = false;  // before the first frame: the caller synchronises after set-up (prepare), nothing is in flight
+    check(hipEventCreateWithFlags(&hit.ev_counts, hipEventDisableTiming), "event");
+    if (const char* e = getenv("VKR_HIT_CAP_PERCENT")) hit.cap_percent = (uint32_t)std::max(1, atoi(e));
   }
   void hit_release() {
     gpu::device_free(hit.counts);
     gpu::device_free(hit.workspace);
     if (hit.host_counts) (void)hipHostFree(hit.host_counts);
+    if (hit.ev_counts) (void)hipEventDestroy(hit.ev_counts);
     gpu::device_free(hit.req_out); gpu::device_free(hit.reply_in); gpu::device_free(hit.req_in); gpu::device_free(hit.reply_out);
   }
   // own rows of the whole-frame albedo: the window's rows are copied where the all-gather would have put the tile's
@@ -522,6 +538,9 @@ struct TiledFrame {
   bool grew = false;
   void grow(void** p, uint64_t* cap, uint64_t need, uint64_t elem) {
     if (need <= *cap) return;
+    // a round that went out on capacities may still be in flight on the exchange stream (the host no longer waits for it): what
+    // it reads and writes must not go back to the allocator under it.  Rare: a buffer grows by a quarter more than it needs.
+    if (*p && xchg) check(hipStreamSynchronize(xchg), "synchronize");
     gpu::device_free(*p);
     *cap = need + need / 4 + 1024;
     *p = gpu::device_alloc(*cap * elem);
@@ -533,8 +552,9 @@ struct TiledFrame {
     check(hipEventRecord(ev_ready[VKRH_GATHER_ALBEDO], compute), "event record");
     check(hipStreamWaitEvent(s, ev_ready[VKRH_GATHER_ALBEDO], 0), "stream wait");
   }
-  // pass 2 on stream s, given everybody's counts: fills req_out and returns the peer list of the request exchange
-  uint32_t hit_write(const uint32_t* matrix, hipStream_t s, vkr_halo_peer* peers) {
+  // pass 2 on stream s, given everybody's counts — or, bounded, everybody's segment capacities: fills req_out and returns the
+  // peer list of the request exchange
+  uint32_t hit_write(const uint32_t* matrix, hipStream_t s, vkr_halo_peer* peers, bool bounded = false) {
     const uint32_t w = cfg.world, me = cfg.rank;
     for (uint32_t o = 0; o < w; o++) hit.out_seg[o + 1] = hit.out_seg[o] + matrix[me * w + o];
     for (uint32_t r = 0; r < w; r++) hit.in_seg[r + 1] = hit.in_seg[r] + matrix[r * w + me];
@@ -549,8 +569,18 @@ struct TiledFrame {
     if (hit.out_seg[w]) {
       HitSources h;
       hit_sources(h);
-      if (vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, hit.workspace, hit.out_seg.data(), hit.req_out, s) != 0)
-        throw std::runtime_error {std::string {"hit_requests: "} + vkr_last_error()};
+      int rc;
+      // Every slot starts as "no request".  Bounded segments have unused room by construction; an exact round that REPEATS a
+      // bounded one may write fewer requests than it counted, because the deferred normal test of the first round has
+      // meanwhile turned some provisional hits into misses (their albedo texels are no longer asked for).
+      check(hipMemsetAsync(hit.req_out, 0xFF, uint64_t(hit.out_seg[w]) * sizeof(vkr_hit_request), s), "memset");
+      if (bounded) {
+        hit.caps_out.assign(matrix + me * w, matrix + me * w + w);
+        rc = vkr_hit_requests_bounded(&h.src, bounds.data(), w, hit.workspace, hit.out_seg.data(), hit.caps_out.data(), hit.req_out, hit.counts + HIT_DROPPED, s);
+      } else {
+        rc = vkr_hit_requests(&h.src, bounds.data(), w, hit.counts, hit.workspace, hit.out_seg.data(), hit.req_out, s);
+      }
+      if (rc != 0) throw std::runtime_error {std::string {"hit_requests: "} + vkr_last_error()};
     }
     uint32_t n = 0;
     hit.wire_bytes = 0;
@@ -577,45 +607,81 @@ struct TiledFrame {
     }
     return n;
   }
-  void hit_scatter(hipStream_t s) {
+  void hit_scatter(hipStream_t s, bool bounded = false) {
     const vkr_img f = frame_albedo_img(), fn = frame_normals_img();
     if (vkr_hit_scatter(&f, normals_by_request() ? &fn : nullptr, hit.req_out, hit.reply_in, hit.out_seg[cfg.world], s) != 0)
       throw std::runtime_error {std::string {"hit_scatter: "} + vkr_last_error()};
     if (normals_by_request()) {  // the hit-normal test the windowed trace deferred: the footprints are complete now
       const vkr_img r = rays_img(), m = pend_mask_img(), d = pend_data_img();
       const vkr_trace_params tp = frame->trace_params();
-      if (vkr_sssr_validate(&r, &m, &d, &fn, &tp, s) != 0) throw std::runtime_error {std::string {"sssr_validate: "} + vkr_last_error()};
+      // (a bounded round that dropped requests of THIS rank has not brought every hit normal: the test waits for the exact round)
+      if (vkr_sssr_validate_unless(&r, &m, &d, &fn, &tp, bounded ? hit.counts + HIT_DROPPED : nullptr, s) != 0) throw std::runtime_error {std::string {"sssr_validate: "} + vkr_last_error()};
     }
     hit.counted = false;
   }
-  // The native exchange: the counts of every rank cross the host once (the compute stream has GTAO queued meanwhile), the
-  // rest is enqueued on the exchange stream and ends in ev_done[VKRH_GATHER_ALBEDO], which the filter waits for.
+  // The native exchange.  Behind the trace, on the exchange stream: count, all-gather of the counts, their copy to the host
+  // (with the reply errors of the previous frame) and an event.  With capacities from the previous frame the whole round
+  // follows at once (hit_round: requests into fixed-room segments, the two point-to-point exchanges at those sizes, replies,
+  // scatter, the deferred normal test) and ends in ev_done[VKRH_GATHER_ALBEDO], which the filter waits for: no host round trip
+  // between the trace and the filter.  hit_exchange_complete() is where the host looks at the counts: in the first frame it
+  // is the round trip (called with GTAO queued, before anything else goes on the exchange stream: ADVICE r03 — the old
+  // whole-stream synchronise also waited for GTAO and its halo exchange); later it only checks that no segment overflowed
+  // and otherwise repeats the round exactly (every rank sees the same matrix and takes the same branch).
   void hit_exchange_native() {
     const uint32_t w = cfg.world;
     check(hipEventRecord(ev_ready[VKRH_GATHER_ALBEDO], compute), "event record");  // the trace (and its pending images) are complete
     check(hipStreamWaitEvent(xchg, ev_ready[VKRH_GATHER_ALBEDO], 0), "stream wait");
+    // the error word of the previous frame's replies, before the memset of hit_count() clears it
+    check(hipMemcpyAsync(hit.host_counts + w * w, hit.counts + HIT_ERRORS, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, xchg), "errors to host");
     hit_count(xchg);
     const vkr_gather_part part {hit.counts, hit.counts + HIT_MATRIX, uint64_t(w) * sizeof(uint32_t)};
     if (vkr_all_gather(cfg.comm, &part, 1, xchg) != 0) throw std::runtime_error {std::string {"exchange: "} + vkr_last_error()};
     check(hipMemcpyAsync(hit.host_counts, hit.counts + HIT_MATRIX, sizeof(uint32_t) * w * w, hipMemcpyDeviceToHost, xchg), "counts to host");
+    check(hipEventRecord(hit.ev_counts, xchg), "event record");
     hit_pending = true;
+    hit.speculative = !hit.cap_matrix.empty();
+    if (hit.speculative) { hit_round(hit.cap_matrix.data(), true); hit.rounds_speculative++; }
   }
-  bool hit_pending = false;
-  void hit_exchange_complete() {  // host-blocking: call with the next compute work already queued
-    if (!hit_pending) return;
-    gpu::TraceRange range {"hit colours: counts -> requests -> replies -> scatter"};
-    hit_pending = false;
-    check(hipStreamSynchronize(xchg), "synchronize");
+  // requests -> exchange -> replies -> exchange -> scatter (+ deferred normal test), all on the exchange stream
+  void hit_round(const uint32_t* matrix, bool bounded) {
     vkr_halo_peer peers[HIT_PEERS];
-    uint32_t n = hit_write(hit.host_counts, xchg, peers);
+    uint32_t n = hit_write(matrix, xchg, peers, bounded);
     if (vkr_halo_exchange(cfg.comm, peers, n, xchg) != 0) throw std::runtime_error {std::string {"exchange: "} + vkr_last_error()};
     n = hit_reply(xchg, peers);
     if (vkr_halo_exchange(cfg.comm, peers, n, xchg) != 0) throw std::runtime_error {std::string {"exchange: "} + vkr_last_error()};
-    hit_scatter(xchg);
+    hit_scatter(xchg, bounded);
     check(hipEventRecord(ev_done[VKRH_GATHER_ALBEDO], xchg), "event record");
   }
+  bool hit_pending = false;
+  void hit_exchange_complete() {  // host-blocking on the counts only
+    if (!hit_pending) return;
+    gpu::TraceRange range {hit.speculative ? "hit colours: check the counts" : "hit colours: counts -> requests -> replies -> scatter"};
+    hit_pending = false;
+    const uint32_t w = cfg.world;
+    check(hipEventSynchronize(hit.ev_counts), "event synchronize");
+    if (hit.host_counts[w * w] != 0)
+      throw std::runtime_error {"tiled frame: " + std::to_string(hit.host_counts[w * w]) + " hit-colour requests of the previous frame named texels their owner does not hold (the ranks' strips disagree); one of them: request " +
+                                std::to_string(hit.host_counts[w * w + 1]) + " in slot " + std::to_string(hit.host_counts[w * w + 2]) + " of " + std::to_string(hit.in_seg[w])};
+    bool overflow = false;
+    for (uint32_t i = 0; hit.speculative && i < w * w; i++) overflow = overflow || hit.host_counts[i] > hit.cap_matrix[i];
+    if (!hit.speculative || overflow) {
+      hit_round(hit.host_counts, false);
+      (overflow ? hit.rounds_repeated : hit.rounds_exact)++;
+    }
+    // room for the next frame: last count + a quarter, in steps of 64; neighbours always keep a segment, a pair that asked for
+    // nothing and is not adjacent keeps none (if it ever asks, that frame repeats its round)
+    hit.cap_matrix.assign(w * w, 0u);
+    for (uint32_t r = 0; r < w; r++)
+      for (uint32_t o = 0; o < w; o++) {
+        const uint32_t c = hit.host_counts[r * w + o];
+        const bool adjacent = r + 1 == o || o + 1 == r;
+        if (r == o || (c == 0 && !adjacent)) continue;
+        hit.cap_matrix[r * w + o] = uint32_t((uint64_t(c) * hit.cap_percent / 100 + 63) / 64 * 64 + 64);
+      }
+    hit.speculative = false;
+  }
   static constexpr uint32_t HIT_PEERS = 16;
-  static constexpr uint32_t HIT_ERRORS = 32, HIT_MATRIX = 64, HIT_WORDS = 64 + 256;  // world <= 16
+  static constexpr uint32_t HIT_ERRORS = 32, HIT_DROPPED = 40, HIT_MATRIX = 64, HIT_WORDS = 64 + 256;  // world <= 16; [0, HIT_MATRIX) is cleared by every count
 
   // ---- the frame, in phases (an exchange may only start / must be complete at a phase boundary) ------------------------
   void phase(uint32_t p) {
@@ -631,13 +697,14 @@ struct TiledFrame {
         else hit_local_rows(compute);
         break;
       case 1:
-        finish_halo(VKRH_HALO_TAA);
-        f.run(VKRH_STAGE_TAA);
-        copy_halo(VKRH_HALO_TAA, true);
-        start_halo(VKRH_HALO_TAA);
-        // local rows first: prologue, pinned steps and as much of every march as this rank's own pyramid rows allow run while
-        // the depth all-gather is still on the wire; a ray that needs more is parked (csrc/ssr.hip, k_sssr_trace<.., LOCAL>)
-        if (local_first()) f.run(VKRH_STAGE_SSR_TRACE_HEAD);
+        if (local_first()) {
+          // local rows first: prologue, pinned steps and as much of every march as this rank's own pyramid rows allow run while
+          // the depth all-gather is still on the wire; a ray that needs more is parked (csrc/ssr.hip, k_sssr_trace<.., LOCAL>).
+          // The TAA, which used to be what ran ahead of the gather, moves behind GTAO: there it covers the hit-colour round.
+          f.run(VKRH_STAGE_SSR_TRACE_HEAD);
+          break;
+        }
+        taa_and_halo();
         break;
       case 2:
         wait(VKRH_GATHER_HIZ);
@@ -650,12 +717,15 @@ struct TiledFrame {
       case 3:  // GTAO needs the trace's (occlusion, pdf) but not the albedo: it runs ahead of the reference's order to hide the second gather
         finish_halo(VKRH_HALO_AO);
         f.run(VKRH_STAGE_GTAO);
+        // first frame (no capacities yet): the host waits for the counts here — GTAO is queued on the device, nothing else yet on the exchange stream
+        if (by_request() && cfg.comm && !hit.speculative) hit_exchange_complete();
         copy_halo(VKRH_HALO_AO, true);
         start_halo(VKRH_HALO_AO);
-        if (by_request() && cfg.comm) hit_exchange_complete();  // the host waits for the counts here, with GTAO queued on the device
+        if (local_first()) taa_and_halo();
         break;
       case 4:
         if (by_request() && !cfg.comm && hit.counted) throw std::runtime_error {"vkrh_tiled_phase: the harness must complete the hit-colour exchange before phase 4"};
+        if (by_request() && cfg.comm) hit_exchange_complete();  // the round went out on capacities: the counts arrived long ago, look at them
         wait(VKRH_GATHER_ALBEDO);
         finish_halo(VKRH_HALO_SSR);
         f.run(VKRH_STAGE_SSR_RESOLVE);
@@ -665,6 +735,12 @@ struct TiledFrame {
         break;
       default: throw std::runtime_error {"vkrh_tiled_phase: phases are 0..4"};
     }
+  }
+  void taa_and_halo() {
+    finish_halo(VKRH_HALO_TAA);
+    frame->run(VKRH_STAGE_TAA);
+    copy_halo(VKRH_HALO_TAA, true);
+    start_halo(VKRH_HALO_TAA);
   }
   void step() {
     if (!tiled) { frame->run(VKRH_STAGE_CHAIN); frame->end_frame(false); return; }
@@ -1020,6 +1096,14 @@ int vkrh_tiled_hit_bytes(void* tiled, uint64_t* bytes) {
     *bytes = ((TiledFrame*)tiled)->hit.wire_bytes;
   });
 }
+int vkrh_tiled_hit_rounds(void* tiled, uint64_t* rounds3) {
+  return guarded([&] {
+    if (!tiled || !rounds3) throw std::runtime_error{"vkrh_tiled_hit_rounds: NULL argument"};
+    const auto& h = ((TiledFrame*)tiled)->hit;
+    rounds3[0] = h.rounds_speculative; rounds3[1] = h.rounds_exact; rounds3[2] = h.rounds_repeated;
+  });
+}
+int vkrh_tiled_local_first(void* tiled) { return tiled && ((TiledFrame*)tiled)->local_first() ? 1 : 0; }
 int vkrh_tiled_time_waits(void* tiled, uint32_t on) {
   return guarded([&] {
     auto* t = (TiledFrame*)tiled;

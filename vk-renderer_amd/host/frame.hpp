@@ -182,6 +182,11 @@ int   vkrh_tiled_hit_replies(void* tiled, vkr_halo_peer* peers, uint32_t capacit
 int   vkrh_tiled_hit_finish(void* tiled);
 /* bytes this rank received over the wire for the hit colours in the last frame (requests in + replies in)              */
 int   vkrh_tiled_hit_bytes(void* tiled, uint64_t* bytes);
+/* native wire: how the hit-colour rounds of the frames so far went — [0] enqueued on the previous frame's capacities (no host
+ * round trip), [1] exact rounds after the host had the counts (first frame), [2] rounds repeated because a segment overflowed */
+int   vkrh_tiled_hit_rounds(void* tiled, uint64_t* rounds3);
+/* 1: the trace runs in two stages around the depth all-gather (VKRH_STAGE_SSR_TRACE_HEAD / _RESUME) and the TAA after GTAO */
+int   vkrh_tiled_local_first(void* tiled);
 /* requests of the last frame that this rank could not answer from its window (0 unless the ranks' strips disagree); synchronises */
 int   vkrh_tiled_hit_errors(void* tiled, uint32_t* errors);
 /* Diagnostics: how long the compute stream stood still for each exchange.  vkrh_tiled_time_waits(on) brackets every wait

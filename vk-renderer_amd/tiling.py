@@ -629,6 +629,7 @@ def native_lockstep_frame(ranks):
     """One frame of every in-process rank of a strip grid (C++ tiled frames made with native=True, comm=None), advanced
     phase by phase; between phases the harness copies exactly the buffers the RCCL calls would move."""
     by_gather = ranks[0].frame.albedo_by_gather or len(ranks) == 1
+    taa_after_gtao = ranks[0].frame.tiled_local_first()  # the C++ frame then resolves the TAA in phase 3 (frame.cpp: local rows first)
     for p in range(5):
         for t in ranks:
             t.frame.tiled_phase(p)
@@ -636,9 +637,11 @@ def native_lockstep_frame(ranks):
             _move_gather(ranks, 0)
             if by_gather:
                 _move_gather(ranks, 1)
-        elif p == 1:
+        elif p == 1 and not taa_after_gtao:
             _move_halo(ranks, 0)
         elif p == 3:
+            if taa_after_gtao:
+                _move_halo(ranks, 0)
             _move_halo(ranks, 1)
             if not by_gather:
                 ranks[0].hit_matrix = _hit_exchange(ranks)
