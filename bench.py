@@ -387,7 +387,7 @@ def main():
                 "halo": sum(p[3] for s_ in range(3) for p in frame.tiled_halo_peers(s_)), "hit": 0 if by_gather else frame.tiled_hit_bytes()}
         every = [None] * world
         dist.all_gather_object(every, mine)
-        # hit colours: by request / reply (8-byte requests in + 8-byte replies in, last frame's count) or the all-gathered albedo
+        # hit colours: by request / reply (4-byte requests in + 16-byte replies in, last frame's segments) or the all-gathered albedo
         exchange_bytes_per_rank = [{"hiz_gather_in": sum(e["hiz"] for e in every) - every[r]["hiz"],
                                     "hit_colours_in": (sum(e["albedo"] for e in every) - every[r]["albedo"]) if by_gather else every[r]["hit"],
                                     "hit_colours": "all-gather of the albedo" if by_gather else "request / reply",
@@ -538,6 +538,10 @@ def main():
             # calibration run: ms per frame every rank's compute stream stood still for each exchange (None: no wire)
             "exchange_wait_ms": exchange_wait_ms,
             "exchange_bytes_per_rank": exchange_bytes_per_rank,
+            # native wire, rank 0: hit-colour rounds (enqueued on the previous frame's capacities, exact after a host round trip, repeated after an overflow)
+            "hit_rounds": list(frame.tiled_hit_rounds()) if (tiled.native and frame.tiled_handle is not None and comm is not None and not frame.albedo_by_gather) else None,
+            "tiled_options": {"gather_mode": frame.gather_mode, "all_gather_v": "broadcast" if os.environ.get("VKR_GATHER_V_BROADCAST") == "1" else "point-to-point",
+                              "trace_local_rows_first": frame.tiled_local_first()} if (tiled.native and frame.tiled_handle is not None) else None,
             "measured_read_gbps": measured_read,
         }
         if noskip_ms is not None:
@@ -551,12 +555,15 @@ def main():
                                    "the time of a frame whose content helps nowhere")
         if world > 1 and (W, H) == (C4_W, C4_H):
             # the denominator of the scaling curve: the SAME 15360x8640 frame on one GPU (python bench.py --config c4 --gpus 1)
-            ref_path = os.path.join(ROOT, "profiles", "r03_bench_c4_n1.json")
+            # (a committed measurement of another run, another box and possibly another build: its git head travels with it, and
+            # the driver's own N = 1 ... 8 runs of one invocation are the scaling curve that counts)
+            ref_path = os.path.join(ROOT, "profiles", "r04_bench_c4_n1.json")
             if os.path.exists(ref_path):
                 with open(ref_path) as f:
                     ref = json.load(f)
                 out["single_gpu_same_frame_ms"] = ref["ms_per_step"]
-                out["single_gpu_same_frame_source"] = "profiles/r03_bench_c4_n1.json (python bench.py --config c4 --gpus 1 on one MI355X)"
+                out["single_gpu_same_frame_source"] = ("profiles/r04_bench_c4_n1.json (python bench.py --config c4 --gpus 1 on one MI355X, build "
+                                                       + str(ref.get("git_head", "?"))[:12] + ")")
                 out["speedup_vs_single_gpu_same_frame"] = ref["ms_per_step"] / (elapsed / args.steps * 1e3)
         if step_ms:  # median of >= 50 hipEvent-timed frames, beside the contract's wall-clock mean
             med = statistics.median(step_ms)

@@ -201,6 +201,7 @@ def test_native_tiled_frame_between_real_processes(bounds, moving, frames, by_br
                VKR_MOVING="1" if moving else "0", VKR_FRAMES=str(frames), HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("VKR_GATHER_V_BROADCAST", None)
     env.pop("VKR_HIT_CAP_PERCENT", None)
+    env["VKR_TILED_LOCAL_FIRST"] = "1" if (world == 4 and moving) else "0"  # one case runs the trace in two stages around the gather
     if by_broadcast == "overflow":
         env["VKR_HIT_CAP_PERCENT"] = "30"
         by_broadcast = False

@@ -48,14 +48,18 @@ def _interiors_differ(t, want, tw, th):
     return bad
 
 
-@pytest.mark.parametrize("world,tile_h,gather,mode", [(2, 160, 4, 0), (4, 160, 4, 0), (3, 136, 3, 0), (4, 160, 4, 1), (4, 160, 4, 2)])  # 136 = 8 * 17: only depth mips 1..3 travel
-def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather, mode, monkeypatch):
+@pytest.mark.parametrize("world,tile_h,gather,mode,local_first", [(2, 160, 4, 0, False), (4, 160, 4, 0, False), (3, 136, 3, 0, False), (4, 160, 4, 1, False), (4, 160, 4, 2, False),
+                                                                    (4, 160, 4, 0, True), (3, 136, 3, 0, True)])  # 136 = 8 * 17: only depth mips 1..3 travel
+def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather, mode, local_first, monkeypatch):
     """mode 0 (the default): hit colours AND hit normals by request / reply (vkr_sssr_trace_windowed, vkr_hit_requests /
     _reply / _scatter, vkr_sssr_validate); 1: the albedo and the downsampled normals of the whole frame all-gathered into
-    every rank (round 2); 2: albedo by request, normals gathered.  All must equal the plain frame on every tile interior."""
+    every rank (round 2); 2: albedo by request, normals gathered.  All must equal the plain frame on every tile interior.
+    local_first (VKR_TILED_LOCAL_FIRST=1, off by default): the trace in two stages around the depth gather — head on the
+    rank's own pyramid rows, resume on the whole-frame pyramid — and the TAA behind GTAO."""
     import torch
 
     monkeypatch.setenv("VKR_TILED_GATHER_MODE", str(mode))
+    monkeypatch.setenv("VKR_TILED_LOCAL_FIRST", "1" if local_first else "0")
     by_gather = mode == 1
 
     from vk_renderer_amd.camera import FrameSetup
@@ -68,6 +72,7 @@ def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather, 
     ranks = [TiledFrame(FrameSetup(W, H), r, world, 1, world, device, native=True, comm=None) for r in range(world)]
     for t in ranks:
         assert t.native and t.gather_mips == gather and t.frame.tiled_handle
+        assert t.frame.tiled_local_first() == local_first
         t.prepare()
     for _ in range(3):
         lockstep_frame(ranks)

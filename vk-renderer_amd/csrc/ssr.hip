@@ -1235,6 +1235,13 @@ extern "C" int vkr_sssr_trace_windowed_head(const vkr_img* local_depth, const vk
   a.park_after = (int)park_after_rounds;
   if (!local_depth || local_depth->mip_count < 1 || local_depth->mip_count > (uint32_t)a.depth.count) { set_error("%s: the local pyramid must have 1 .. %d levels", P, a.depth.count); return VKR_ERR_MIPS; }
   a.local.count = (int)local_depth->mip_count;
+  // every local level must be made of whole texels of the frame's level: make_tex() halves origin and extent per level, which
+  // is only the frame's texel grid when both divide (a strip cut at a multiple of 16 full-res rows has four such levels)
+  if (((uint32_t)local_depth->origin_y | local_depth->height) & ((1u << (a.local.count - 1)) - 1u)) {
+    set_error("%s: local rows [%d, +%u) do not divide into %d levels (origin and height must be multiples of %u)", P, local_depth->origin_y,
+              local_depth->height, a.local.count, 1u << (a.local.count - 1));
+    return VKR_ERR_EXTENT;
+  }
   for (int i = 0; i < a.local.count; i++) {
     Tex& t = a.local.mip[i];
     VKR_TRY(make_tex(local_depth, i, VKR_FMT_D24_UNORM_S8, "sssr_trace_windowed_head.local_depth", &t));

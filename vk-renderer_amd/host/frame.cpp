@@ -455,9 +455,13 @@ struct TiledFrame {
     uint32_t cap_percent = 125;         // room = this share of last frame's count (+ 64, rounded up to 64); VKR_HIT_CAP_PERCENT
     uint64_t rounds_speculative = 0, rounds_exact = 0, rounds_repeated = 0;
   } hit;
-  // the trace in two stages around the gather (needs the pending-ray images of the request / reply mode); VKR_TILED_LOCAL_FIRST=0: one stage
+  // The trace in two stages around the gather (needs the pending-ray images of the request / reply mode): VKR_TILED_LOCAL_FIRST=1.
+  // OFF by default: measured on a 15360 x 1080 strip of config 4 (tools/trace_local_probe.py) the head parks 70 - 76 % of the
+  // rays — a march climbs past the gathered levels after four skipped tiles — so the resume launch repeats most of the work
+  // through 80-byte records: head 0.42 + resume 0.67 ms against 0.70 ms for the one launch, more than the 0.16 - 0.28 ms of
+  // exposed gather it can hide.
   bool local_first() const { return normals_by_request() && local_first_enabled; }
-  bool local_first_enabled = getenv("VKR_TILED_LOCAL_FIRST") == nullptr || std::string {getenv("VKR_TILED_LOCAL_FIRST")} != "0";
+  bool local_first_enabled = getenv("VKR_TILED_LOCAL_FIRST") != nullptr && std::string {getenv("VKR_TILED_LOCAL_FIRST")} == "1";
   bool by_request() const { return tiled && cfg.world > 1 && cfg.albedo_by_gather != 1; }          // hit colours
   bool normals_by_request() const { return tiled && cfg.world > 1 && cfg.albedo_by_gather == 0; }   // ... and hit normals
   vkr_img dn_img() { return frame->graph.get_image(frame->gbuffer.downsampled_normals)->describe(0, 1); }
