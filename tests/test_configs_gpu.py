@@ -4,7 +4,8 @@ c3, c4 and c5):
   c3  7680x4320, full chain: per-pass parity against the oracle on the same bytes, once on the synthetic G-buffer and
       once on the rasterised procedural scene drawn through SceneRenderer (Sponza.bin is absent from the reference
       mount and the reference's assets do not travel to the GPU box, SURVEY.md 8(d));
-  c4  15360x8640 cut into the eight 15360x1080 strips bench.py --gpus 8 renders: every rank an in-process TiledFrame
+  c4  15360x8640 on one GPU, every pass against the oracle on the same bytes; and the same frame
+      cut into the eight 15360x1080 strips bench.py --gpus 8 renders: every rank an in-process TiledFrame
       on the one GPU (tests/test_tiled_lockstep_gpu.py plays the wire), tile interiors against the plain one-GPU
       frame of the same size — the count of differing texels is the deviation mask of SURVEY.md 8(e);
   c5  3840x2160, the host frame's [DOWNSAMPLE] + [SSR] x 8 + [TAA] plan of bench.py --config c5 against the oracle's
@@ -105,6 +106,28 @@ def test_c3_8k_rasterised_through_scene_renderer(oracle_lib, parity_table):
         n, _ = report(hname, rimg.format, frame.download(hname).decode(), rimg.decode())
         assert n <= 8, f"{hname}: {n} texels outside tolerance (measured: 0 - 1, profiles/parity_c3.json / parity_c5.json)"
     frame.close()
+
+
+def test_c4_full_frame_stagewise_against_the_oracle(oracle_lib, parity_table):
+    """BASELINE configs[3]'s frame, 15360x8640, against the ORACLE (VERDICT r03 missing #6: the tiled test above compares
+    HIP with HIP): every pass of the chain on one GPU with the oracle's bytes as its inputs, Hi-Z / dn / dv bit-exact (14
+    mips), everything else with a budget of zero texels outside tolerance.  With the test above — eight strips bit-identical
+    to this one-GPU frame — the tiled frame is tied to the oracle at its full size.  Inputs are made identical once and after
+    every pass only that pass's outputs are replaced by the oracle's (19 surfaces of 0.13 - 1.1 GB each: not re-uploaded per pass)."""
+    W, H = 15360, 8640
+    ref, gpu = _pair(W, H, oracle_lib)
+    ref.synth()
+    ref.build_prev_hiz()
+    ref.init_histories()
+    ref.preintegrate_pdf()
+    assert ref.depth.mips == 14  # floor(log2(15360)) + 1, scene_renderer.cpp:13
+    _sync_inputs(ref, gpu)
+    for stage, outs in STAGES:
+        getattr(ref, stage)()
+        getattr(gpu, stage)()
+        _compare(ref, gpu, outs, budget=0)
+        for name in outs:
+            getattr(gpu, name).copy_from(getattr(ref, name))
 
 
 def test_c5_eight_rays_per_pixel_loop(oracle_lib, parity_table):

@@ -74,6 +74,36 @@ def main():
         print(f"  {x:6.1f} us: {int(((t[:, 0] <= x) & (t[:, 4] > x)).sum())}")
     xcc = (st[:, 6] >> np.uint64(32)).astype(np.int64)
     print("blocks per XCC:", np.bincount(xcc & 15)[:8].tolist())
+    # Per CU (XCC, shader engine, array, CU of HW_ID): how much of the kernel's time the CU holds 0 / 1 / 2+ blocks, and how
+    # much of it EVERY block it holds is still staging its tile (phase 0 -> 1: global loads, decode, LDS stores, barrier) —
+    # time in which the CU issues next to no VALU work.  This is what VALU-busy 0.69 is made of.
+    hw = st[:, 6] & np.uint64(0xFFFFFFFF)
+    cu_key = ((xcc & 15) << 16) | (((hw >> np.uint64(13)) & np.uint64(7)).astype(np.int64) << 8) | (((hw >> np.uint64(12)) & np.uint64(1)).astype(np.int64) << 4) | ((hw >> np.uint64(8)) & np.uint64(15)).astype(np.int64)
+    cus = np.unique(cu_key)
+    grid = np.arange(0.0, total, 0.25)  # 0.25 us resolution
+    empty = one = two = staging_only = 0.0
+    for k in cus:
+        m = cu_key == k
+        res = np.zeros(grid.size, dtype=np.int32)
+        tapping = np.zeros(grid.size, dtype=np.int32)
+        for b in np.flatnonzero(m):
+            res += (grid >= t[b, 0]) & (grid < t[b, 4])
+            tapping += (grid >= t[b, 1]) & (grid < t[b, 3])
+        empty += (res == 0).mean(); one += (res == 1).mean(); two += (res >= 2).mean()
+        staging_only += ((res > 0) & (tapping == 0)).mean()
+    n = float(len(cus))
+    summary = {"kernel_us": total, "blocks": int(tiles), "cus_seen": int(n), "cu_time_share": {"no_block": empty / n, "one_block": one / n, "two_or_more": two / n,
+               "every_resident_block_staging_or_storing": staging_only / n},
+               "sum_block_time_over_512_slots_us": dur.sum() / 512, "phase_us_by_radius": {}}
+    for rr in sorted(set(r.tolist())):
+        mm = r == rr
+        summary["phase_us_by_radius"][int(rr)] = {"blocks": int(mm.sum()), "stage": float((t[mm, 1] - t[mm, 0]).mean()), "setup": float((t[mm, 2] - t[mm, 1]).mean()),
+                                                   "taps": float((t[mm, 3] - t[mm, 2]).mean()), "store": float((t[mm, 4] - t[mm, 3]).mean())}
+    print(f"per CU ({int(n)} CUs seen): no block {empty / n:.3f}, one block {one / n:.3f}, two or more {two / n:.3f} of the kernel's time; "
+          f"every resident block outside its tap loop {staging_only / n:.3f}")
+    import json
+    with open(os.path.join(ROOT, "gpurun_out", "blur_timeline.json"), "w") as f:
+        json.dump(summary, f, indent=1)
     # start time of blocks by launch order: how far the dispatcher is ahead
     order = np.arange(tiles)
     late = t[:, 0] > 0.6 * total

@@ -316,24 +316,19 @@ void register_hot_path_programs() {
       vkr_img rays = tex(st, 5, S, P), occ = tex(st, 6, S, P), pdf = tex(st, 7, T, P);
       const SetSlot& h = st.set->slots[4];
       if (h.kind != SetSlot::Ubo || !h.buffer) throw std::runtime_error{"sssr_trace: Halton buffer (binding 4) is not bound"};
-      if (vkr_get_switches() & VKR_SWITCH_TRACE_ONE_LAUNCH)
+      // Two launches where they pay: the rays still marching after step 48 (two of the four compacted rounds: a tenth of them) are
+      // parked in the context's workspace and finished by the resume launch, 256 rays of many tiles per block.  Same images bit
+      // for bit.  Measured on one MI355X (tools/trace_split_probe.py): 3840x2160 0.259 against 0.272 ms (park after one round
+      // 0.280, after three 0.268); 1920x1080 0.105 against 0.094 (a second launch and a memset on a 0.1 ms pass);
+      // 7680x4320 1.008 against 1.004; 15360x8640 4.196 against 4.007 — the 80-byte records of the parked rays (17 MB at 4K,
+      // 270 MB at 15360x8640) must stay in the caches between the two launches for the resume launch to be cheap.
+      const uint64_t n_rays = uint64_t(rays.width) * rays.height;
+      if ((vkr_get_switches() & VKR_SWITCH_TRACE_ONE_LAUNCH) || n_rays < (1ull << 20) || n_rays > (6ull << 20))
         return vkr_sssr_trace(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), halton_table(h.buffer.get(), st.stream),
                               &rays, &occ, &pdf, push<vkr_trace_push>(st, P), st.stream);
-      // two launches: the rays still marching after step 48 (two of the four compacted rounds: a tenth of them) are parked in
-      // the context's workspace and finished by the resume launch, 256 rays of many tiles per block (measured at 3840x2160:
-      // 0.259 against 0.272 ms; park after one round 0.280, after three 0.268).  Same images bit for bit.
       const uint64_t bytes = vkr_sssr_trace_workspace_bytes(rays.width, rays.height);
       return vkr_sssr_trace_split(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), halton_table(h.buffer.get(), st.stream),
                                   &rays, &occ, &pdf, push<vkr_trace_push>(st, P), st.require_workspace(bytes), bytes, 2u, st.stream);
-    });
-    create_program("sssr_trace_windowed", [=](LaunchState& st) {  // multi-GPU variant (include/vkr_postfx.h), bindings 0..9
-      const char* P = "sssr_trace_windowed";
-      vkr_img depth = tex(st, 0, T, P), normal = tex(st, 1, T, P), material = tex(st, 2, T, P);
-      vkr_img rays = tex(st, 5, S, P), occ = tex(st, 6, S, P), pdf = tex(st, 7, T, P), mask = tex(st, 8, S, P), data = tex(st, 9, S, P);
-      const SetSlot& h = st.set->slots[4];
-      if (h.kind != SetSlot::Ubo || !h.buffer) throw std::runtime_error{"sssr_trace_windowed: Halton buffer (binding 4) is not bound"};
-      return vkr_sssr_trace_windowed(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), halton_table(h.buffer.get(), st.stream),
-                                     &rays, &occ, &pdf, &mask, &data, push<vkr_trace_window_push>(st, P), st.stream);
     });
     // the windowed trace in two tasks (include/vkr_postfx.h): bindings of sssr_trace_windowed, the head with the window's own
     // pyramid levels at 0 and the whole-frame pyramid (extents only) at 10; both use the context's workspace
