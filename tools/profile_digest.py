@@ -132,12 +132,14 @@ def main():
         merged = defaultdict(dict)
         for d in a.sq:
             for k, cs in counters(d).items():
+                if "SQ_THREAD_CYCLES_VALU" in cs and "SQ_ACTIVE_INST_VALU" in cs:  # both from ONE pass: the ratio is the lane use
+                    merged[k]["_lanes"] = cs["SQ_THREAD_CYCLES_VALU"][0] / cs["SQ_ACTIVE_INST_VALU"][0]
                 for c, (v, _) in cs.items():
                     merged[k][c] = v
-        names = sorted({c for cs in merged.values() for c in cs})
+        names = sorted({c for cs in merged.values() for c in cs if c != "_lanes"})
         with open(f"profiles/{a.tag}_sq_counters.md", "w") as g:
             g.write(f"# SQ counters per kernel launch (means), rocprofv3 --pmc passes; {a.note}\n\n")
-            g.write("| kernel | " + " | ".join(names) + " | VALU busy (4·ACTIVE_INST_VALU / 1024 SIMD / (duration·2.4 GHz)) |\n|---|" + "---|" * (len(names) + 1) + "\n")
+            g.write("| kernel | " + " | ".join(names) + " | VALU busy (4·ACTIVE_INST_VALU / 1024 SIMD / (duration·2.4 GHz)) | active lanes per VALU instruction (THREAD_CYCLES_VALU / ACTIVE_INST_VALU, same pass) |\n|---|" + "---|" * (len(names) + 2) + "\n")
             for k in TASK_OF:
                 if k not in merged:
                     continue
@@ -146,7 +148,8 @@ def main():
                 if "SQ_ACTIVE_INST_VALU" in cs and cs.get("_duration_ns"):
                     # gfx94x VALUBusy formula: 4 * SQ_ACTIVE_INST_VALU / SIMD_NUM / cycles, 1024 SIMDs, 2.4 GHz
                     ratio = f"{4.0 * cs['SQ_ACTIVE_INST_VALU'] / 1024.0 / (cs['_duration_ns'] * 2.4):.2f}"
-                g.write(f"| {k} | " + " | ".join(f"{cs.get(c, float('nan')):.4g}" for c in names) + f" | {ratio} |\n")
+                lanes = f"{cs['_lanes']:.1f}" if "_lanes" in cs else ""
+                g.write(f"| {k} | " + " | ".join(f"{cs.get(c, float('nan')):.4g}" for c in names) + f" | {ratio} | {lanes} |\n")
         print("wrote", f"profiles/{a.tag}_sq_counters.md")
         busy, weight = {}, {}
         for k, (task, _) in TASK_OF.items():
