@@ -68,6 +68,7 @@ def lib():
         l.vkrh_last_error.restype = C.c_char_p
         l.vkrh_set_camera.argtypes = [C.c_void_p, C.POINTER(HostCamera)]
         l.vkrh_pin_randoms.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32]
+        l.vkrh_has_program.argtypes = [C.c_char_p]
         l.vkrh_set_gtao_mode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         l.vkrh_set_synth_flags.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_set_gathered_mips.argtypes = [C.c_void_p, C.c_uint32]

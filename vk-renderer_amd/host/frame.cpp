@@ -794,6 +794,10 @@ void* vkrh_create(const vkrh_config* cfg) {
 }
 void vkrh_destroy(void* frame) { delete (PostFxFrame*)frame; }
 const char* vkrh_last_error(void) { return g_error.c_str(); }
+int vkrh_has_program(const char* name) {
+  gpu::register_hot_path_programs();
+  return name && gpu::has_program(name) ? 1 : 0;
+}
 
 int vkrh_set_camera(void* frame, const vkrh_camera* cam) {
   return guarded([&] { if (!frame || !cam) throw std::runtime_error{"NULL argument"}; ((PostFxFrame*)frame)->set_camera(*cam); });

@@ -82,6 +82,8 @@ int vkrh_load_scene(void* frame, const vkr_raster_vertex* vertices, uint32_t ver
                     const vkrh_scene_draw* draws, uint32_t draw_count, const vkrh_scene_texture* textures, uint32_t texture_count);
 /* pin ScreenSpaceTrace's per-frame randoms (screen_trace.cpp:49-53) */
 int vkrh_pin_screen_trace(void* frame, float angle_jitter, float random_offset, uint32_t frame_count);
+/* 1 when the program table of the host layer knows `name` (a name of src/shaders/config.json or one of this path's own) */
+int vkrh_has_program(const char* name);
 int vkrh_set_gtao_mode(void* frame, uint32_t use_mis, uint32_t two_directions);
 /* material mode of the synthetic G-buffer (VKRH_STAGE_GBUFFER): 0, or VKR_SYNTH_TEXTURED_ROUGHNESS (include/vkr_postfx.h) */
 int vkrh_set_synth_flags(void* frame, uint32_t flags);

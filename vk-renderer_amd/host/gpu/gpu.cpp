@@ -330,6 +330,15 @@ void register_hot_path_programs() {
       return vkr_sssr_trace_split(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), halton_table(h.buffer.get(), st.stream),
                                   &rays, &occ, &pdf, push<vkr_trace_push>(st, P), st.require_workspace(bytes), bytes, 2u, st.stream);
     });
+    create_program("sssr_trace_windowed", [=](LaunchState& st) {  // multi-GPU variant (include/vkr_postfx.h), bindings 0..9
+      const char* P = "sssr_trace_windowed";
+      vkr_img depth = tex(st, 0, T, P), normal = tex(st, 1, T, P), material = tex(st, 2, T, P);
+      vkr_img rays = tex(st, 5, S, P), occ = tex(st, 6, S, P), pdf = tex(st, 7, T, P), mask = tex(st, 8, S, P), data = tex(st, 9, S, P);
+      const SetSlot& h = st.set->slots[4];
+      if (h.kind != SetSlot::Ubo || !h.buffer) throw std::runtime_error{"sssr_trace_windowed: Halton buffer (binding 4) is not bound"};
+      return vkr_sssr_trace_windowed(&depth, &normal, &material, ubo<vkr_trace_params>(st, 3, P), halton_table(h.buffer.get(), st.stream),
+                                     &rays, &occ, &pdf, &mask, &data, push<vkr_trace_window_push>(st, P), st.stream);
+    });
     // the windowed trace in two tasks (include/vkr_postfx.h): bindings of sssr_trace_windowed, the head with the window's own
     // pyramid levels at 0 and the whole-frame pyramid (extents only) at 10; both use the context's workspace
     create_program("sssr_trace_windowed_head", [=](LaunchState& st) {
