@@ -130,15 +130,19 @@ int vkrh_set_async(void* frame, uint32_t on);
  *
  *   downsample | all-gather(depth mips 1..k) starts on the exchange stream; own albedo / normal rows go into the frame images
  *   TAA (needs neither)            | its halo refresh starts
- *   Hi-Z tail + SSR trace          (after the gather; rays that end on another rank's rows stay pending) | requests are counted
- *   GTAO main, filter, accumulate  | its halo refresh starts | request / reply for hit colours + hit normals, then the
- *                                    deferred hit-normal test (vkr_sssr_validate), on the exchange stream
+ *   Hi-Z tail + SSR trace          (after the gather; rays that end on another rank's rows stay pending) | the requests are
+ *                                    counted, the counts all-gathered, and — from the second frame on — the whole request /
+ *                                    reply round for hit colours + hit normals and the deferred hit-normal test
+ *                                    (vkr_sssr_validate) are enqueued on the exchange stream at once
+ *   GTAO main, filter, accumulate  | its halo refresh starts
  *   SSR filter + blur              (after the replies are in place) | its halo refresh starts; history remaps
  *
  * Hit colours: the filter reads the albedo at the hit position of every valid ray, anywhere in the frame.  Each rank asks
- * the owners for the footprint rows outside its window (vkr_hit_requests / _reply / _scatter, 8-byte requests and
- * replies moved with vkr_halo_exchange) instead of receiving the albedo of the whole frame; the counts cross the host
- * once per frame, while GTAO keeps the device busy.  albedo_by_gather = 1 restores the all-gather.
+ * the owners for the footprint rows outside its window (vkr_hit_requests / _reply / _scatter, 4-byte requests and 16-byte
+ * replies moved with vkr_halo_exchange) instead of receiving the albedo of the whole frame.  The message sizes of a frame
+ * come from the PREVIOUS frame's counts (segments of fixed room, identical on every rank), so the host is not in the path:
+ * it looks at this frame's counts before it queues the filter and repeats the round exactly if a segment overflowed; only
+ * the first frame waits for its counts (with GTAO queued).  albedo_by_gather = 1 restores the all-gather.
  *
  * Every exchange is one grouped RCCL launch (vkr_all_gather / vkr_halo_exchange) on the frame's own exchange stream,
  * ordered against the compute stream with events only: the host never blocks, and a halo refresh issued after the
