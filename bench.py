@@ -401,7 +401,7 @@ def main():
     frame.enable_task_timing(True, only=dominant)
     # one event per step boundary on the frame's stream (= torch's current stream): the median step time of SURVEY 8(d)
     stream = torch.cuda.current_stream(device)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if args.steps >= 50 else []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if args.steps >= 10 else []
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -466,7 +466,14 @@ def main():
                 d = json.load(f).get(args.config)  # one digest per BASELINE config
             if not d:
                 return None, None
-            return d.get(dominant), f"profiles/{fname}[{args.config}]" + (f" ({d['_source']})" if "_source" in d else "")
+            note = ""
+            if d.get("_library_sha16"):  # was the digest taken with the kernel library this run has loaded?
+                import hashlib
+
+                with open(abi.PRODUCT_LIB, "rb") as lf:
+                    mine = hashlib.sha256(lf.read()).hexdigest()[:16]
+                note = "; SAME kernel library as this run" if mine == d["_library_sha16"] else f"; digest of ANOTHER build of the kernel library ({d['_library_sha16']}, this run {mine})"
+            return d.get(dominant), f"profiles/{fname}[{args.config}]" + (f" ({d['_source']}{note})" if "_source" in d else "")
 
         # HBM bytes / VALU-busy of the dominant kernel are NOT measured in this run: they are the committed rocprofv3
         # --pmc digests of the same command (tools/profile_run.sh + tools/profile_digest.py --config), kept per BASELINE
@@ -565,7 +572,7 @@ def main():
                 out["single_gpu_same_frame_source"] = ("profiles/r04_bench_c4_n1.json (python bench.py --config c4 --gpus 1 on one MI355X, build "
                                                        + str(ref.get("git_head", "?"))[:12] + ")")
                 out["speedup_vs_single_gpu_same_frame"] = ref["ms_per_step"] / (elapsed / args.steps * 1e3)
-        if step_ms:  # median of >= 50 hipEvent-timed frames, beside the contract's wall-clock mean
+        if step_ms:  # median of the hipEvent-timed frames (>= 10 steps), beside the contract's wall-clock mean
             med = statistics.median(step_ms)
             out["ms_per_step_median"] = med
             out["value_median"] = px / (med * 1e-3) / 1e6  # rank 0's stream only: meaningful at N = 1

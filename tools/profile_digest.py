@@ -70,6 +70,18 @@ def counters(d, skip_first=2):
     return out
 
 
+def library_sha16():
+    """which build of the kernels the profiled command ran: sha256 of csrc/libvkr_postfx.so (the file travels to the GPU box as it
+    is), so that bench.py can say whether a committed digest belongs to the library it has loaded"""
+    import hashlib
+
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vk-renderer_amd", "csrc", "libvkr_postfx.so")
+    if not os.path.exists(lib):
+        return None
+    with open(lib, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def merge_by_config(path, config, digest):
     """profiles/traffic.json / valu_busy.json: {config: {task: value, "_source": ...}} — one digest per BASELINE config"""
     table = {}
@@ -78,6 +90,7 @@ def merge_by_config(path, config, digest):
             table = json.load(f)
         if "_source" in table:  # the round-3 layout: one flat digest, of c2
             table = {"c2": table}
+    digest["_library_sha16"] = library_sha16()
     table[config] = digest
     with open(path, "w") as g:
         json.dump(table, g, indent=1, sort_keys=True)
