@@ -150,3 +150,34 @@ def test_windowed_trace_local_rows_first(rank, levels, park_after, oracle_lib):
     rows_g = d[: data.pitch[0] * data.height].reshape(data.height, data.pitch[0])[:, : data.width * 16].view(np.float32).reshape(data.height, data.width // 2, 8)
     rows_w = want_data.reshape(-1)[: data.pitch[0] * data.height].reshape(data.height, data.pitch[0])[:, : data.width * 16].view(np.float32).reshape(data.height, data.width // 2, 8)
     assert np.array_equal(rows_g[pend][:, [0, 1, 2, 4, 5]], rows_w[pend][:, [0, 1, 2, 4, 5]]), "pending R / hit uv differ"
+
+
+def test_requests_into_segments_of_fixed_room(oracle_lib):
+    """vkr_hit_requests_bounded (the native wire sizes its messages from the PREVIOUS frame's counts): with room for every request
+    the segments hold exactly the exact pass's sets and nothing is flagged; with too little room every segment is full, holds a
+    subset of the exact set, the overflow is flagged, and the unused slots of a roomy segment say VKR_HIT_NO_REQUEST — which the
+    reply answers with zeros without counting an error."""
+    _, gr = _chains("product", "cuda")
+    lower, upper = gr[1], gr[0]
+    lower.ssr_trace_windowed(frame_random=0)
+    counts = lower.hit_count(BOUNDS)
+    exact, seg = lower.hit_write(BOUNDS, counts)
+    exact_h = lower.buffer_to_host(exact).view(np.uint32)[: seg[-1]]
+    n0 = counts[0]
+    assert n0 > 200 and counts[1] == 0
+    # roomy: 100 slots more than needed for owner 0, 64 for owner 1 (which gets nothing)
+    out, s2, dropped = lower.hit_write_bounded(BOUNDS, [n0 + 100, 64])
+    h = lower.buffer_to_host(out).view(np.uint32)
+    assert dropped == 0
+    assert np.array_equal(np.sort(h[: n0]), np.sort(exact_h[: n0])), "a roomy segment holds the exact set"
+    assert (h[n0: s2[-1]] == 0xFFFFFFFF).all(), "unused slots say: no request"
+    rep, err = upper.hit_reply(out, s2[1])
+    rep_h = upper.buffer_to_host(rep).view(np.uint32)[: 4 * s2[1]].reshape(-1, 4)
+    assert err == 0 and (rep_h[n0:] == 0).all() and rep_h[:n0].any()
+    # tight: half the room
+    cap = n0 // 2
+    out, s3, dropped = lower.hit_write_bounded(BOUNDS, [cap, 64])
+    h = lower.buffer_to_host(out).view(np.uint32)
+    assert dropped == 1
+    kept = h[:cap]
+    assert (kept != 0xFFFFFFFF).all() and np.isin(kept, exact_h[: n0]).all() and (h[cap: s3[-1]] == 0xFFFFFFFF).all()

@@ -243,13 +243,18 @@ ENTRY_ARGS = {
     "sssr_trace_windowed_resume": [_IMG, _IMG, _IMG, P(TraceParams), C.c_void_p, _IMG, _IMG, _IMG, _IMG, _IMG, P(TraceWindowPush), C.c_void_p, C.c_uint64],
     "sssr_validate": [_IMG, _IMG, _IMG, _IMG, P(TraceParams)],
     "hit_requests": [P(HitSources), P(C.c_uint32), C.c_uint32, C.c_void_p, C.c_void_p, P(C.c_uint32), C.c_void_p],
+    # pass 2 into segments of fixed room (workspace, segments, capacities, out, dropped flag); which requests an overflowing
+    # segment keeps is the order of the device's atomics: checked by its properties, not against a twin
+    "hit_requests_bounded": [P(HitSources), P(C.c_uint32), C.c_uint32, C.c_void_p, P(C.c_uint32), P(C.c_uint32), C.c_void_p, C.c_void_p],
     "hit_reply": [_IMG, _IMG, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p],
     "hit_scatter": [_IMG, _IMG, C.c_void_p, C.c_void_p, C.c_uint32],
 }
 
 
-# entries that are a different SCHEDULE of another entry (same images bit for bit): no twin in a checker library
-SCHEDULE_VARIANTS = {"sssr_trace_split": "sssr_trace", "sssr_trace_windowed_head": "sssr_trace_windowed", "sssr_trace_windowed_resume": "sssr_trace_windowed"}
+# entries without a twin in a checker library: a different SCHEDULE of another entry (same images bit for bit), or a variant
+# whose result is only defined up to the order of the device's atomics (checked against the exact entry by its properties)
+SCHEDULE_VARIANTS = {"sssr_trace_split": "sssr_trace", "sssr_trace_windowed_head": "sssr_trace_windowed", "sssr_trace_windowed_resume": "sssr_trace_windowed",
+                     "hit_requests_bounded": "hit_requests"}
 
 
 class RectCopy(C.Structure):  # vkr_rect_copy

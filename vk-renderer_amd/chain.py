@@ -357,6 +357,25 @@ class PostFxChain:
         self.call("hit_requests", C.byref(self._hit_sources(normals)), b, world, None, self._buf_ptr(self._hit_workspace), seg, self._buf_ptr(out))
         return out, segments
 
+    def hit_write_bounded(self, row_bounds, capacities, normals=True):
+        """vkr_hit_requests_bounded after hit_count(): segments of fixed room (capacities per owner), unused slots VKR_HIT_NO_REQUEST
+        -> (uint32 buffer, segments, dropped flag).  Product backend only."""
+        import torch
+
+        assert self.backend == "product"
+        world = len(row_bounds) - 1
+        segments = [0]
+        for c in capacities:
+            segments.append(segments[-1] + c)
+        out = torch.full((max(segments[-1], 1),), -1, dtype=torch.int32, device=self.device)  # 0xFFFFFFFF: no request
+        dropped = self._u32_buffer(1)
+        b = (C.c_uint32 * (world + 1))(*row_bounds)
+        seg = (C.c_uint32 * (world + 1))(*segments)
+        cap = (C.c_uint32 * world)(*capacities)
+        self.call("hit_requests_bounded", C.byref(self._hit_sources(normals)), b, world, self._buf_ptr(self._hit_workspace), seg, cap, self._buf_ptr(out),
+                  self._buf_ptr(dropped))
+        return out, segments, int(self.buffer_to_host(dropped)[0])
+
     def hit_reply(self, requests, count, normals=True):
         """16 bytes per request from this window's albedo / downsampled normals -> (uint32 buffer [4 * count], errors)"""
         replies, errors = self._u32_buffer(4 * count), self._u32_buffer(1)
