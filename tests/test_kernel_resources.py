@@ -29,8 +29,8 @@ HOT = {
     "k_sssr_trace<true, false, false>": ("ssr.hip", 256, 72, 0, 23 * 1024, 7),
     "k_sssr_trace<true, true, true>": ("ssr.hip", 256, 80, 0, 23 * 1024, 6),
     # the resume launch is latency-bound (a tenth of the rays, 3 blocks per CU): registers are not what limits it
-    "k_sssr_trace_resume<false>": ("ssr.hip", 256, 96, 0, 23 * 1024, 5),
-    "k_sssr_trace_resume<true>": ("ssr.hip", 256, 96, 0, 23 * 1024, 5),
+    "k_sssr_trace_resume<false, false>": ("ssr.hip", 256, 96, 0, 1024, 5),      # <WINDOWED, COMPACT>: single GPU, every lane its own ray
+    "k_sssr_trace_resume<true, true>": ("ssr.hip", 256, 96, 0, 23 * 1024, 5),   # multi-GPU resume: compacted rounds
     "k_sssr_filter": ("ssr.hip", 256, 64, 0, 12 * 1024 + 256, 8),
     "k_sssr_blur": ("ssr.hip", 512, 128, 16, 48 * 1024, 4),
     "k_gtao_main<true, true>": ("gtao.hip", 1024, 64, 0, 21 * 1024, 8),   # 16-wave blocks: > 64 VGPRs means ONE block per CU

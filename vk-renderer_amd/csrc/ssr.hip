@@ -472,10 +472,16 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
 // The resume launch: every block takes 256 consecutive records of the queue (the rays of many tiles), marches them to their
 // end in the same compacted rounds and runs the epilogue for their pixels.  The record stays in the queue while its ray
 // marches, so a thread holds nothing across the rounds but its record's index.
-template <bool WINDOWED>
-__global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace_resume(TraceArgs a) {
+// COMPACT: the block's rays march in the compacted rounds of the head launch (the multi-GPU resume: most rays of the strip, long
+// marches — throughput counts).  Without it every lane marches its own ray to the end: the single-GPU resume is a tenth of the
+// rays with at most 32 steps left, 3 blocks per CU, bound by the latency of its dependent fetches — there the rounds' barriers
+// and list bookkeeping cost what their better lane use saves (measured: 0.704 against 0.707 ms per frame, and 5 KB instead of 22 KB of LDS).
+#define RESUME_BLOCK TRACE_THREADS
+template <bool WINDOWED, bool COMPACT>
+__global__ __launch_bounds__(RESUME_BLOCK) void k_sssr_trace_resume(TraceArgs a) {
   __shared__ uint4 s_mip[16];
-  __shared__ TracePool pool;
+  __shared__ uint4 pool_storage[COMPACT ? (sizeof(TracePool) + 15) / 16 : 1];  // (no pool without the rounds)
+  TracePool& pool = *(TracePool*)pool_storage;
   __shared__ uint32_t s_total;
   const int tid = threadIdx.x, lane = tid & 63;
   stage_mip_tables<false>(a, tid, s_mip, nullptr);
@@ -488,9 +494,11 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace_resume(TraceArgs a
   const MarchEnv env = trace_env(a, s_mip);
   const Proj pr = a.pr;
   const f2 tex_size = mk2((float)a.out_ray.fw, (float)a.out_ray.fh);
-  for (uint32_t first = blockIdx.x * TRACE_THREADS; first < total; first += gridDim.x * TRACE_THREADS) {
-    if (tid < 2) pool.count[tid] = 0;
-    __syncthreads();
+  for (uint32_t first = blockIdx.x * RESUME_BLOCK; first < total; first += gridDim.x * RESUME_BLOCK) {
+    if (COMPACT) {
+      if (tid < 2) pool.count[tid] = 0;
+      __syncthreads();
+    }
     const uint32_t idx = first + (uint32_t)tid;
     const bool have = idx < total;
     const uint4* rec = a.q.records + (uint64_t)idx * TQ_VEC;
@@ -515,15 +523,23 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace_resume(TraceArgs a
     };
     if (have) load_ray();
     const bool marching = have && !finished;
-    pool_park(pool, marching, tid, lane, rc, st);
-    trace_rounds<false>(env, pool, tid, lane, 1 << 30);
+    if (COMPACT) {
+      pool_park(pool, marching, tid, lane, rc, st);
+      trace_rounds<false>(env, pool, tid, lane, 1 << 30);
+    } else if (marching) {
+      bool more = true;
+#pragma unroll 1
+      while (more) more = march_step<true, 15>(env, rc, st, 80);
+    }
     if (have) {
-      load_ray();  // (again: cheaper than five more live vectors across the rounds)
-      if (marching) pool_load_result(pool.ray + tid * TP_VEC, st);
+      if (COMPACT) {
+        load_ray();  // (again: cheaper than five more live vectors across the rounds)
+        if (marching) pool_load_result(pool.ray + tid * TP_VEC, st);
+      }
       const uint4 r3 = rec[3];
       trace_epilogue<WINDOWED>(a, a.depth.mip[0], rc, st, mk3(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z)), __uint_as_float(r3.w), pixel_depth, lx, ly);
     }
-    __syncthreads();  // the pool is reused by the next chunk
+    if (COMPACT) __syncthreads();  // the pool is reused by the next chunk
   }
 }
 
@@ -1161,8 +1177,9 @@ static int bind_trace_queue(TraceArgs& a, void* workspace, uint64_t workspace_by
 
 // blocks of the resume launch: they loop over the queue, so the grid only has to fill the machine
 static dim3 resume_grid(const TraceArgs& a) {
-  const uint32_t chunks = (a.q.capacity + TRACE_THREADS - 1) / TRACE_THREADS;
-  return dim3(chunks < 2048u ? chunks : 2048u);
+  const uint32_t chunks = (a.q.capacity + RESUME_BLOCK - 1) / RESUME_BLOCK;
+  const uint32_t most = 2048u * (TRACE_THREADS / RESUME_BLOCK);
+  return dim3(chunks < most ? chunks : most);
 }
 
 extern "C" int vkr_sssr_trace_split(const vkr_img* depth, const vkr_img* normal, const vkr_img* material,
@@ -1181,7 +1198,7 @@ extern "C" int vkr_sssr_trace_split(const vkr_img* depth, const vkr_img* normal,
   if (hipMemsetAsync(a.q.counters, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) { set_error("sssr_trace_split: memset failed"); return VKR_ERR_LAYOUT; }
   hipLaunchKernelGGL((k_sssr_trace<false, true, false>), grid, block, 0, (hipStream_t)stream, a);
   VKR_TRY(launch_status("sssr_trace_split (head)"));
-  hipLaunchKernelGGL((k_sssr_trace_resume<false>), resume_grid(a), block, 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_sssr_trace_resume<false, false>), resume_grid(a), dim3(RESUME_BLOCK), 0, (hipStream_t)stream, a);
   return launch_status("sssr_trace_split (resume)");
 }
 
@@ -1275,7 +1292,7 @@ extern "C" int vkr_sssr_trace_windowed_resume(const vkr_img* frame_depth, const 
   TraceArgs a;
   VKR_TRY(make_windowed_args(a, frame_depth, normal, material, params, halton_vec4, out_ray, out_occlusion, pdf_tex, pending_mask, pending_data, push, P));
   VKR_TRY(bind_trace_queue(a, workspace, workspace_bytes, P));
-  hipLaunchKernelGGL((k_sssr_trace_resume<true>), resume_grid(a), dim3(TRACE_THREADS, 1), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_sssr_trace_resume<true, true>), resume_grid(a), dim3(RESUME_BLOCK), 0, (hipStream_t)stream, a);
   return launch_status(P);
 }
 
