@@ -263,8 +263,8 @@ int vkr_sssr_trace(const vkr_img* depth, const vkr_img* normal, const vkr_img* m
 /* "sssr_trace" in two launches, same images as vkr_sssr_trace bit for bit.  The head launch runs every ray's prologue, its 16
  * pinned steps and `park_after_rounds` (0..4) of the compacted 16-step rounds, and finishes the pixels whose rays have ended;
  * a ray that has not is PARKED: written, with what the rest of its march and its epilogue need (80 bytes), to a frame-wide
- * queue in `workspace`.  The resume launch takes 256 consecutive parked rays per block — the stragglers of many tiles in one
- * pool — marches them to their end and writes their pixels.  workspace: device memory of at least
+ * queue in `workspace`.  The resume launch gives every parked ray a lane of its own — the stragglers of many tiles side by side
+ * in full waves — marches them to their end and writes their pixels.  workspace: device memory of at least
  * vkr_sssr_trace_workspace_bytes(rays width, rays height) bytes, 16-byte aligned, no initialisation needed; a workspace
  * belongs to one stream at a time.                                                                                      */
 uint64_t vkr_sssr_trace_workspace_bytes(uint32_t rays_width, uint32_t rays_height);

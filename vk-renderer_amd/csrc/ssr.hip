@@ -181,8 +181,8 @@ VKR_DEV int trace_rounds(const MarchEnv& env, TracePool& pool, int tid, int lane
 // ---- frame-wide queue of parked rays (vkr_sssr_trace_split: head launch -> resume launch) -----------------------------------
 // A ray the head launch does not finish is written here with everything the rest of its march and its epilogue need —
 // 80 bytes: {origin, t} {direction, h} {pixel normal, mip | i << 8} {R, roughness} {pixel depth, lx | ly << 16, -, -} —
-// and the resume launch loads 256 consecutive records per block: rays of many tiles in one pool, so its rounds run on full
-// waves where a tile's own stragglers would leave one nearly empty wave per round.  inv_direction and view_vec are
+// and the resume launch loads 256 consecutive records per block: rays of many tiles side by side, so its waves start full
+// where a tile's own stragglers would leave one nearly empty wave of their block alive for two more rounds.  inv_direction and view_vec are
 // recomputed from the record by the very operations that made them (safe_inverse, reconstruct_view_vec: bit-identical).
 #define TQ_VEC 5
 #define TQ_FINISHED 0x80000000u  // in the mip | i << 8 word: the march has ended, only the epilogue is owed (its hit depth lies on rows not held)
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void k_sssr_trace(TraceArgs a) {
 }
 
 // The resume launch: every block takes 256 consecutive records of the queue (the rays of many tiles), marches them to their
-// end in the same compacted rounds and runs the epilogue for their pixels.  The record stays in the queue while its ray
+// end and runs the epilogue for their pixels.  The record stays in the queue while its ray
 // marches, so a thread holds nothing across the rounds but its record's index.
 // COMPACT: the block's rays march in the compacted rounds of the head launch (the multi-GPU resume: most rays of the strip, long
 // marches — throughput counts).  Without it every lane marches its own ray to the end: the single-GPU resume is a tenth of the
