@@ -544,7 +544,7 @@ int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_img* frame_normals, c
                     uint32_t count, void* stream);
 
 /* Measurement switches — the library's only process-wide state.  The environment (VKR_BLUR_NO_SKIP, VKR_FILTER_NO_SKIP,
- * VKR_TAA_GENERIC, VKR_SHADING_GENERIC, VKR_BLUR_GENERIC, VKR_TRACE_ONE_LAUNCH) is read once, at the first launch that asks; afterwards only vkr_set_switches
+ * VKR_TAA_GENERIC, VKR_SHADING_GENERIC, VKR_BLUR_GENERIC, VKR_BLUR_LANE_LOOPS, VKR_TRACE_ONE_LAUNCH) is read once, at the first launch that asks; afterwards only vkr_set_switches
  * changes them.  NO_SKIP: evaluate every tap of the blur / filter even in tiles without a reflection / hit (a
  * content-independent time; the stored texels are the same wherever every weight is finite).  GENERIC: the TAA /
  * shading instantiations that do not assume equal window layouts.                                                  */
@@ -553,6 +553,7 @@ int vkr_hit_scatter(const vkr_img* frame_albedo, const vkr_img* frame_normals, c
 #define VKR_SWITCH_TAA_GENERIC     4u
 #define VKR_SWITCH_SHADING_GENERIC 8u
 #define VKR_SWITCH_BLUR_GENERIC    16u /* every wave of the blur on the per-lane Gaussian loop (no wave-uniform-sigma path) */
+#define VKR_SWITCH_BLUR_LANE_LOOPS 64u /* waves that do not share one sigma on the per-lane tap loops of rounds 1-3 instead of the transposed packed rows (blur_rows) */
 #define VKR_SWITCH_TRACE_ONE_LAUNCH 32u /* read by the HOST layer (host/gpu): program "sssr_trace" as one launch (vkr_sssr_trace) instead of
                                           * head + resume (vkr_sssr_trace_split); the library's entries do what their names say either way */
 uint32_t vkr_get_switches(void);

@@ -219,10 +219,11 @@ def test_taa_generic_footprints(size, oracle_lib, monkeypatch):
 @pytest.mark.parametrize("size", [(640, 360), (1282, 722), (3840, 2160)])
 def test_blur_uniform_sigma_and_general_paths(size, oracle_lib):
     """ssr.hip resolves a wave whose pixels share one sigma (constant roughness over a surface) on blur_uniform_sigma — Gaussian
-    factors evaluated once, rows unrolled, column sums — and every other wave on the per-lane loop; VKR_SWITCH_BLUR_GENERIC
-    sends all waves through the latter.  Both must give the oracle's image (zero texels outside tolerance), and the frame
-    must exercise both: the two runs differ in the last bit of some texels (different summation order), never by more than
-    one UNORM8 code."""
+    factors evaluated once, rows unrolled, column sums — and every other wave on blur_rows (per-pixel factor tables, columns
+    unrolled, row sums; round 4) or, with VKR_SWITCH_BLUR_LANE_LOOPS, on the per-lane loops of rounds 1-3;
+    VKR_SWITCH_BLUR_GENERIC sends ALL waves through the non-uniform path.  All three must give the oracle's image (zero texels
+    outside tolerance), and the frame must exercise them: the runs differ in the last bit of some texels (different summation
+    order), never by more than one UNORM8 code."""
     import numpy as np
 
     lib = abi.product()
@@ -237,8 +238,9 @@ def test_blur_uniform_sigma_and_general_paths(size, oracle_lib):
     ref.ssr_blur()
     images = {}
     try:
-        for general in (False, True):
-            lib.vkr_set_switches((before | abi.SWITCH_BLUR_GENERIC) if general else (before & ~abi.SWITCH_BLUR_GENERIC))
+        clear = before & ~(abi.SWITCH_BLUR_GENERIC | abi.SWITCH_BLUR_LANE_LOOPS)
+        for general in (False, True, "lane loops"):
+            lib.vkr_set_switches(clear | (abi.SWITCH_BLUR_GENERIC if general else 0) | (abi.SWITCH_BLUR_LANE_LOOPS if general == "lane loops" else 0))
             gpu.ssr_blur()
             gpu.sync()
             _compare(ref, gpu, ("blurred",), budget=0)
@@ -247,8 +249,10 @@ def test_blur_uniform_sigma_and_general_paths(size, oracle_lib):
         lib.vkr_set_switches(before)
     d = np.abs(images[False] - images[True])
     differing = int((d != 0).any(axis=-1).sum())
-    print(f"[parity] blur paths at {size}: {differing} texels differ between the uniform-sigma and the general path, max {int(d.max())} code")
-    assert int(d.max()) <= 1
+    d2 = np.abs(images["lane loops"] - images[True])
+    print(f"[parity] blur paths at {size}: {differing} texels differ between the uniform-sigma and the rows path, max {int(d.max())} code; "
+          f"{int((d2 != 0).any(axis=-1).sum())} between the rows path and the per-lane loops, max {int(d2.max())} code")
+    assert int(d.max()) <= 1 and int(d2.max()) <= 1
     if size[0] >= 3840:  # (a few flipped roundings per 1e5 texels: a small frame can have none)
         assert differing > 0, "no wave took the uniform-sigma path (or the switch is dead): the test frame does not exercise it"
 

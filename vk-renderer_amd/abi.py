@@ -327,7 +327,7 @@ def check(rc, lib=None):
 
 COMM_ID_BYTES = 128
 # measurement switches (include/vkr_postfx.h VKR_SWITCH_*): vkr_get_switches / vkr_set_switches
-SWITCH_BLUR_NO_SKIP, SWITCH_FILTER_NO_SKIP, SWITCH_TAA_GENERIC, SWITCH_SHADING_GENERIC, SWITCH_BLUR_GENERIC, SWITCH_TRACE_ONE_LAUNCH = 1, 2, 4, 8, 16, 32
+SWITCH_BLUR_NO_SKIP, SWITCH_FILTER_NO_SKIP, SWITCH_TAA_GENERIC, SWITCH_SHADING_GENERIC, SWITCH_BLUR_GENERIC, SWITCH_TRACE_ONE_LAUNCH, SWITCH_BLUR_LANE_LOOPS = 1, 2, 4, 8, 16, 32, 64
 
 
 class Comm:

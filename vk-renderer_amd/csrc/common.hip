@@ -27,6 +27,7 @@ uint32_t switches() {
     if (getenv("VKR_SHADING_GENERIC")) v |= VKR_SWITCH_SHADING_GENERIC;
     if (getenv("VKR_BLUR_GENERIC")) v |= VKR_SWITCH_BLUR_GENERIC;
     if (getenv("VKR_TRACE_ONE_LAUNCH")) v |= VKR_SWITCH_TRACE_ONE_LAUNCH;
+    if (getenv("VKR_BLUR_LANE_LOOPS")) v |= VKR_SWITCH_BLUR_LANE_LOOPS;
     uint32_t expected = 0x80000000u;
     if (!g_switches.compare_exchange_strong(expected, v)) v = expected;
   }

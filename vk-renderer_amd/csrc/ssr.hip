@@ -681,6 +681,7 @@ struct BlurArgs {
   uint32_t accumulate, disable_blur;
   uint32_t skip_empty_tiles;  // 1: a tile whose staged reflections are all black skips its taps (the sums are exactly 0)
   uint32_t uniform_sigma_path;  // 1: waves whose pixels share one sigma take blur_uniform_sigma
+  uint32_t rows_path;           // 1: every other wave takes blur_rows (0: the per-lane loops, VKR_SWITCH_BLUR_LANE_LOOPS)
 };
 
 // Tile geometry of the blur: a block resolves BLUR_BX x BLUR_BY pixels and stages the pixels within
@@ -843,6 +844,69 @@ template <int R> VKR_DEV void blur_uniform_sigma(const uint4* s_px, const BlurCe
   accB = mk4(acc_r.y * g, acc_g.y * g, acc_b.y * g, acc_w.y * g);
 }
 
+// Per-lane sigma (a material texture: roughness, hence sigma and radius, differ from pixel to pixel): the same packed tap as
+// blur_uniform_sigma, with the loop nest TRANSPOSED so that per-pixel Gaussian factors still fit a small register table.  Pixels
+// A and B of a thread are vertically adjacent, so in one staged ROW they share the column index i: the column factors of a row
+// are the pairs C[k] = {E_A(k), E_B(k)}, k = |i| — R + 1 register pairs, evaluated once per thread from its two sigmas — and the
+// 2R + 1 columns of a row are unrolled (consecutive LDS records, immediate offsets, reads running ahead); the row factor
+// {E_A(|s|), E_B(|s - 1|)} is applied once per row to the row's sums.  R is the largest radius in the WAVE: a pixel with a smaller
+// radius has zeros in its table entries beyond it (and in its row factors), so its extra taps add exactly 0 and no lane
+// diverges.  Replaces the per-lane loops of rounds 1-3 (11 VALU instructions per pixel-tap on divergent trip counts, pairs of
+// different radius resolved one pixel at a time) where a wave does not share one sigma: 7 per pixel-tap.  Per pixel the taps and
+// weights are the shader's; the sums are formed row by row.
+template <int R> VKR_DEV void blur_rows(const uint4* s_px, const BlurCentre* c, bool has_b, f4& accA, f4& accB) {
+  const int rA = c[0].r, rB = has_b ? c[1].r : -1;
+  const v2f nie = {c[0].neg_inv_e_log2, c[1].neg_inv_e_log2};
+  v2f C[R + 1];
+#pragma unroll
+  for (int k = 0; k <= R; k++) {
+    const v2f e = exp2_2((float)(k * k) * nie);
+    C[k] = (v2f){k <= rA ? e.x : 0.0f, k <= rB ? e.y : 0.0f};
+  }
+  const v2f cnx = {c[0].normal.x, c[1].normal.x}, cny = {c[0].normal.y, c[1].normal.y}, cnz = {c[0].normal.z, c[1].normal.z};
+  const v2f kb = {c[0].k_bilateral, c[1].k_bilateral};
+  const v2f kcd = kb * (v2f){c[0].depth, c[1].depth};
+  v2f acc_r = {0.0f, 0.0f}, acc_g = {0.0f, 0.0f}, acc_b = {0.0f, 0.0f}, acc_w = {0.0f, 0.0f};
+  const uint4* row = s_px + (c[0].tc - R - R * BLUR_TW);  // row -R of pixel A, column -R
+#pragma unroll 1
+  for (int s = -R; s <= R + 1; s++, row += BLUR_TW) {
+    // row s of A is row s - 1 of B
+    const int ja = s < 0 ? -s : s, jb = s < 1 ? 1 - s : s - 1;
+    v2f f = exp2_2((v2f){(float)(ja * ja), (float)(jb * jb)} * nie);
+    f = (v2f){ja <= rA ? f.x : 0.0f, jb <= rB ? f.y : 0.0f};
+    v2f row_r = {0.0f, 0.0f}, row_g = {0.0f, 0.0f}, row_b = {0.0f, 0.0f}, row_w = {0.0f, 0.0f};
+    uint4 ahead[BLUR_AHEAD];
+#pragma unroll
+    for (int k = 0; k < BLUR_AHEAD; k++) ahead[k] = lds_load4(row + k);
+#pragma unroll
+    for (int i = -R; i <= R; i++) {
+      const uint4 p = ahead[(i + R) % BLUR_AHEAD];
+      if (i + R + BLUR_AHEAD <= 2 * R) ahead[(i + R) % BLUR_AHEAD] = lds_load4(row + (i + R + BLUR_AHEAD));
+      const v2f nzw = {__uint_as_float(p.z), __uint_as_float(p.w)};
+      const v2f nxy = __builtin_elementwise_fma(cny, splat2(__uint_as_float(p.y)), cnx * splat2(__uint_as_float(p.x)));
+      v2f nw, kdz;
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] clamp" : "=v"(nw) : "v"(cnz), "v"(nzw), "v"(nxy));
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+          : "=v"(kdz) : "v"(kb), "v"(nzw), "v"(kcd));
+      const v2f tw = nw * C[i < 0 ? -i : i];
+      v2f w;
+      w.x = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(kdz.x), tw.x, tw.x), 0.0f), 1.0f);
+      w.y = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(-__builtin_fabsf(kdz.y), tw.y, tw.y), 0.0f), 1.0f);
+      row_r = __builtin_elementwise_fma(w, splat2((float)(p.x & 0xFFu)), row_r);
+      row_g = __builtin_elementwise_fma(w, splat2((float)(p.y & 0xFFu)), row_g);
+      row_b = __builtin_elementwise_fma(w, splat2((float)(p.z & 0xFFu)), row_b);
+      row_w += w;
+    }
+    acc_r = __builtin_elementwise_fma(f, row_r, acc_r);
+    acc_g = __builtin_elementwise_fma(f, row_g, acc_g);
+    acc_b = __builtin_elementwise_fma(f, row_b, acc_b);
+    acc_w = __builtin_elementwise_fma(f, row_w, acc_w);
+  }
+  const float gA = c[0].g, gB = c[1].g;
+  accA = mk4(acc_r.x * gA, acc_g.x * gA, acc_b.x * gA, acc_w.x * gA);
+  accB = mk4(acc_r.y * gB, acc_g.y * gB, acc_b.y * gB, acc_w.y * gB);
+}
+
 // one BLUR_BX x BLUR_BY tile of the output; s_px: the staged tile, one 16-byte record per pixel (blur_pack); s_lut: the sRGB
 // decode table (storage; staged inside, visible after the first barrier)
 VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, uint4* s_px, float* s_lut, const int tid) {
@@ -994,7 +1058,29 @@ VKR_DEV void blur_tile(const BlurArgs& a, const i2 blk, uint4* s_px, float* s_lu
       }
     }
   }
-  if (empty_tile || uniform_sigma) {
+  bool by_rows = false;
+  if (!empty_tile && !uniform_sigma && a.rows_path != 0) {
+    // the largest radius of the wave (lanes past the window's bottom row have no pixel B: its radius does not count)
+    int rmax = max(c[0].r, has_b ? c[1].r : 0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rmax = max(rmax, __shfl_xor(rmax, off));
+    by_rows = true;
+    switch (__builtin_amdgcn_readfirstlane(rmax)) {
+      case 0: case 1: blur_rows<1>(s_px, c, has_b, accA, accB); break;
+      case 2: blur_rows<2>(s_px, c, has_b, accA, accB); break;
+      case 3: blur_rows<3>(s_px, c, has_b, accA, accB); break;
+      case 4: blur_rows<4>(s_px, c, has_b, accA, accB); break;
+      case 5: blur_rows<5>(s_px, c, has_b, accA, accB); break;
+      case 6: blur_rows<6>(s_px, c, has_b, accA, accB); break;
+      case 7: blur_rows<7>(s_px, c, has_b, accA, accB); break;
+      case 8: blur_rows<8>(s_px, c, has_b, accA, accB); break;
+      case 9: blur_rows<9>(s_px, c, has_b, accA, accB); break;
+      case 10: blur_rows<10>(s_px, c, has_b, accA, accB); break;
+      case 11: blur_rows<11>(s_px, c, has_b, accA, accB); break;
+      default: by_rows = false; break;
+    }
+  }
+  if (empty_tile || uniform_sigma || by_rows) {
     // empty: nothing to add up, both sums stay 0 and the epilogue turns them into colour 0 (then the history mix)
   } else if (!has_b || c[0].r != c[1].r) {
     accA = blur_single(s_px, c[0]);
@@ -1358,6 +1444,7 @@ static int make_blur_args(BlurArgs& a, const vkr_img* depth, const vkr_img* norm
   a.disable_blur = push->disable_blur;
   a.skip_empty_tiles = (switches() & VKR_SWITCH_BLUR_NO_SKIP) ? 0u : 1u;  // measurement switch: identical output for finite weights
   a.uniform_sigma_path = (switches() & VKR_SWITCH_BLUR_GENERIC) ? 0u : 1u;
+  a.rows_path = (switches() & VKR_SWITCH_BLUR_LANE_LOOPS) ? 0u : 1u;
   if (a.max_roughness > 1.0f || a.max_roughness < 0.0f) {  // sigma <= 4 bounds the staged radius (blur.comp:45)
     set_error("sssr_blur: max_roughness must be in [0,1] (reference slider range, advanced_ssr.cpp:558)");
     return VKR_ERR_EXTENT;
