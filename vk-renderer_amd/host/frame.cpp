@@ -265,6 +265,7 @@ struct TiledFrame {
     frame.reset(new PostFxFrame(fc));
     frame->hiz_gathered_mips = tiled ? k : 4;
     if (normals_by_request()) frame->gbuffer.enable_normal_requests(frame->graph, wy0 / 2, (wy0 + wh) / 2);
+    if (tiled && c.world > 1 && !env_set("VKR_TILED_WHOLE_WINDOW")) clip_outputs();
     if (tiled) {
       // the exchanges' kernels (a few workgroups each) must not queue behind a frame's worth of compute waves
       int prio_low = 0, prio_high = 0;
@@ -282,6 +283,27 @@ struct TiledFrame {
           halo[s][n].recv = gpu::device_alloc(halo[s][n].bytes);
         }
     }
+  }
+  static bool env_set(const char* name) { const char* v = getenv(name); return v && *v && *v != '0'; }
+  // Which rows of its window a rank has to COMPUTE (gpu::Image::set_store_rows; VKR_TILED_WHOLE_WINDOW=1 keeps round 3's "every
+  // pass on the whole window").  The three history surfaces and the filtered AO: the strip itself — the halo rows of a history
+  // arrive from the neighbours before the next frame reads them (copy_halo overwrote what the pass had computed there anyway),
+  // and the accumulation reads the filtered AO at its own pixel only.  The resolved reflections: the strip and the blur's apron
+  // (blur.comp: taps up to 11 texels away; ssr.hip BLUR_R).  The trace, GTAO main and the downsample stay whole-window: the
+  // request / reply round walks every ray of the window, and GTAO main's LDS path wants output and depth windows to coincide.
+  void clip_outputs() {
+    auto& g = frame->graph;
+    const uint32_t top = y0 - wy0;  // rows of halo above the strip inside the window
+    const auto rows = [&](rendergraph::ImageResourceId id, uint32_t shift, uint32_t apron) {
+      gpu::Image& img = *g.get_image(id);
+      const uint32_t first = top >> shift, last = (top + th) >> shift, h = img.get_info().height;
+      const uint32_t lo = first > apron ? first - apron : 0, hi = std::min(h, last + apron);
+      img.set_store_rows(lo, hi - lo);
+    };
+    rows(frame->taa_pass.get_output(), 0, 0); rows(frame->taa_pass.get_history(), 0, 0);
+    rows(frame->gtao.accumulated_ao, 1, 0); rows(frame->gtao.accumulated_history, 1, 0); rows(frame->gtao.filtered, 1, 0);
+    rows(frame->ssr.get_blurred(), 1, 0); rows(frame->ssr.get_blurred_history(), 1, 0);
+    rows(frame->ssr.get_ouput(), 1, 12);
   }
   void drop_wait_marks() {
     for (auto& v : wait_marks) { for (auto& m : v) { (void)hipEventDestroy(m.first); (void)hipEventDestroy(m.second); } v.clear(); }

@@ -119,6 +119,22 @@ vkr_img Image::describe(uint32_t base_mip, uint32_t count) const {
   return d;
 }
 
+void Image::set_store_rows(uint32_t row0, uint32_t rows) {
+  if (rows && (info.mip_levels != 1 || get_array_layers() != 1 || uint64_t(row0) + rows > info.height))
+    throw std::runtime_error{"Image::set_store_rows: rows outside the window, or not a single-mip image"};
+  store_row0 = rows ? row0 : 0;
+  store_rows = rows;
+}
+vkr_img Image::describe_store(uint32_t base_mip, uint32_t count) const {
+  vkr_img d = describe(base_mip, count);
+  if (store_rows) {  // (single-mip image: base_mip = 0, count = 1)
+    d.base = (uint8_t*)d.base + uint64_t(store_row0) * d.pitch_bytes[0];
+    d.origin_y += (int32_t)store_row0;
+    d.height = store_rows;
+  }
+  return d;
+}
+
 vkr_img Image::describe_layer(uint32_t layer) const {
   if (layer >= get_array_layers() || info.mip_levels != 1) throw std::runtime_error{"Image layer view outside the array"};
   vkr_img d = describe(0, 1);
@@ -230,6 +246,7 @@ vkr_img tex(const LaunchState& st, uint32_t slot, SetSlot::Kind kind, const char
     if (nearest_border ? !is_nearest_border : !is_default)
       throw std::runtime_error{std::string{prog} + ": binding " + std::to_string(slot) + ": sampler not implemented on this path"};
   }
+  if (kind == SetSlot::StorageTexture) return s.view.image->describe_store(s.view.range.base_mip, s.view.range.mips_count);
   return s.view.image->describe(s.view.range.base_mip, s.view.range.mips_count);
 }
 // The Halton(2,3) UBO of AdvancedSSR (advanced_ssr.cpp:54-58: 128 x vec4, xy filled, zw = 0).  The HIP programs want

@@ -79,6 +79,12 @@ struct Image {
   vkr_img describe(uint32_t base_mip, uint32_t count) const;
   // one layer of a (single-mip) array image
   vkr_img describe_layer(uint32_t layer) const;
+  // Multi-GPU strips (host/frame.cpp): of a window image that a pass writes, only rows [row0, row0 + rows) of mip 0 are ever
+  // read — by the passes downstream in the same frame, or as the rank's own share of a history whose halo rows arrive from the
+  // neighbours.  A program that binds the image as its storage OUTPUT gets the view describe_store() returns: the same memory,
+  // window origin and height narrowed to those rows, so its launch covers nothing else.  rows = 0: the whole window (default).
+  void set_store_rows(uint32_t row0, uint32_t rows);
+  vkr_img describe_store(uint32_t base_mip, uint32_t count) const;
   // tightly packed rows of one mip -> device (asset upload; synchronous)
   void upload_mip(uint32_t mip, const void* rows);
   // asset knowledge the raster stage can use: no texel of any mip level has alpha 0 (set by the scene loader, which
@@ -92,6 +98,7 @@ struct Image {
   size_t bytes = 0;
   std::array<uint32_t, VKR_MAX_MIPS> pitch{};
   std::array<uint64_t, VKR_MAX_MIPS> offset{};
+  uint32_t store_row0 = 0, store_rows = 0;
 };
 using ImagePtr = std::shared_ptr<Image>;
 
