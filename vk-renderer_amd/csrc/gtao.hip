@@ -333,7 +333,9 @@ extern "C" int vkr_gtao_main(const vkr_img* depth, const vkr_gtao_params* params
     }
   }
   dim3 block(GT_BX, GT_BY);
-  const bool tiled = a.tex_w == a.out.fw && a.tex_h == a.out.fh && same_window(a.depth, a.out);
+  // (the LDS tile is staged from frame coordinates clamped to the depth window, as sample<>() clamps: the output window may be
+  // any part of the frame — a strip's own rows of a window image, host/frame.cpp — as long as both describe the same frame)
+  const bool tiled = a.tex_w == a.out.fw && a.tex_h == a.out.fh && a.depth.fw == a.out.fw && a.depth.fh == a.out.fh;
   void (*kernel)(GtaoArgs) = tiled ? (a.use_mis ? k_gtao_main<true, true> : k_gtao_main<true, false>)
                                    : (a.use_mis ? k_gtao_main<false, true> : k_gtao_main<false, false>);
   hipLaunchKernelGGL(kernel, grid2d(a.out.w, a.out.h, block), block, 0, (hipStream_t)stream, a);

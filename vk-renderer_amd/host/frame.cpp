@@ -289,8 +289,10 @@ struct TiledFrame {
   // pass on the whole window").  The three history surfaces and the filtered AO: the strip itself — the halo rows of a history
   // arrive from the neighbours before the next frame reads them (copy_halo overwrote what the pass had computed there anyway),
   // and the accumulation reads the filtered AO at its own pixel only.  The resolved reflections: the strip and the blur's apron
-  // (blur.comp: taps up to 11 texels away; ssr.hip BLUR_R).  The trace, GTAO main and the downsample stay whole-window: the
-  // request / reply round walks every ray of the window, and GTAO main's LDS path wants output and depth windows to coincide.
+  // (blur.comp: taps up to 11 texels away; ssr.hip BLUR_R).  The rays — with their pending mask / data and the (occlusion, pdf)
+  // image the trace shares with GTAO main — two rows more: the resolve reads its four neighbours (filter.comp:112-134), GTAO's
+  // filter taps reach two rows (filter.comp:17-51); the request / reply round and the deferred normal test walk the same rows
+  // (rays_img() etc. describe the store rows).  The downsample stays whole-window: everything above reads its halo.
   void clip_outputs() {
     auto& g = frame->graph;
     const uint32_t top = y0 - wy0;  // rows of halo above the strip inside the window
@@ -304,6 +306,8 @@ struct TiledFrame {
     rows(frame->gtao.accumulated_ao, 1, 0); rows(frame->gtao.accumulated_history, 1, 0); rows(frame->gtao.filtered, 1, 0);
     rows(frame->ssr.get_blurred(), 1, 0); rows(frame->ssr.get_blurred_history(), 1, 0);
     rows(frame->ssr.get_ouput(), 1, 12);
+    rows(frame->ssr.get_rays(), 1, 14); rows(frame->gtao.raw, 1, 14);
+    if (normals_by_request()) { rows(frame->gbuffer.pend_mask, 1, 14); rows(frame->gbuffer.pend_data, 1, 14); }
   }
   void drop_wait_marks() {
     for (auto& v : wait_marks) { for (auto& m : v) { (void)hipEventDestroy(m.first); (void)hipEventDestroy(m.second); } v.clear(); }
@@ -488,8 +492,8 @@ struct TiledFrame {
   bool normals_by_request() const { return tiled && cfg.world > 1 && cfg.albedo_by_gather == 0; }   // ... and hit normals
   vkr_img dn_img() { return frame->graph.get_image(frame->gbuffer.downsampled_normals)->describe(0, 1); }
   vkr_img frame_normals_img() { return frame->graph.get_image(frame->gbuffer.frame_normals)->describe(0, 1); }
-  vkr_img pend_mask_img() { return frame->graph.get_image(frame->gbuffer.pend_mask)->describe(0, 1); }
-  vkr_img pend_data_img() { return frame->graph.get_image(frame->gbuffer.pend_data)->describe(0, 1); }
+  vkr_img pend_mask_img() { return frame->graph.get_image(frame->gbuffer.pend_mask)->describe_store(0, 1); }
+  vkr_img pend_data_img() { return frame->graph.get_image(frame->gbuffer.pend_data)->describe_store(0, 1); }
   // what vkr_hit_requests walks: the rays for the albedo rows, the pending rays of the windowed trace for the normal rows
   struct HitSources { vkr_img rays, mask, data; vkr_hit_sources src; };
   void hit_sources(HitSources& h) {
@@ -501,7 +505,7 @@ struct TiledFrame {
       h.src.normal_width = W / 2; h.src.normal_height = H / 2; h.src.normal_row0 = wy0 / 2; h.src.normal_row1 = (wy0 + wh) / 2;
     }
   }
-  vkr_img rays_img() { return frame->graph.get_image(frame->ssr.get_rays())->describe(0, 1); }
+  vkr_img rays_img() { return frame->graph.get_image(frame->ssr.get_rays())->describe_store(0, 1); }
   vkr_img albedo_img() { return frame->graph.get_image(frame->gbuffer.albedo)->describe(0, 1); }
   vkr_img frame_albedo_img() { return frame->graph.get_image(frame->gbuffer.frame_albedo)->describe(0, 1); }
   void hit_init() {
