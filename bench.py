@@ -553,7 +553,8 @@ def main():
             # native wire, rank 0: hit-colour rounds (enqueued on the previous frame's capacities, exact after a host round trip, repeated after an overflow)
             "hit_rounds": list(frame.tiled_hit_rounds()) if (tiled.native and frame.tiled_handle is not None and comm is not None and not frame.albedo_by_gather) else None,
             "tiled_options": {"gather_mode": frame.gather_mode, "all_gather_v": "broadcast" if os.environ.get("VKR_GATHER_V_BROADCAST") == "1" else "point-to-point",
-                              "trace_local_rows_first": frame.tiled_local_first()} if (tiled.native and frame.tiled_handle is not None) else None,
+                              "trace_local_rows_first": frame.tiled_local_first(),
+                              "rows_computed": "whole window" if os.environ.get("VKR_TILED_WHOLE_WINDOW", "0") not in ("", "0") else "the rows that are read"} if (tiled.native and frame.tiled_handle is not None) else None,
             "measured_read_gbps": measured_read,
         }
         if noskip_ms is not None:

@@ -48,16 +48,21 @@ def _interiors_differ(t, want, tw, th):
     return bad
 
 
-@pytest.mark.parametrize("world,tile_h,gather,mode,local_first", [(2, 160, 4, 0, False), (4, 160, 4, 0, False), (3, 136, 3, 0, False), (4, 160, 4, 1, False), (4, 160, 4, 2, False),
-                                                                    (4, 160, 4, 0, True), (3, 136, 3, 0, True)])  # 136 = 8 * 17: only depth mips 1..3 travel
-def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather, mode, local_first, monkeypatch):
+@pytest.mark.parametrize("world,tile_h,gather,mode,local_first,whole", [(2, 160, 4, 0, False, False), (4, 160, 4, 0, False, False), (3, 136, 3, 0, False, False),
+                                                                          (4, 160, 4, 1, False, False), (4, 160, 4, 2, False, False), (4, 160, 4, 0, True, False),
+                                                                          (3, 136, 3, 0, True, False),  # 136 = 8 * 17: only depth mips 1..3 travel
+                                                                          (4, 160, 4, 0, False, True), (3, 136, 3, 0, True, True)])
+def test_native_ranks_in_lockstep_match_single_gpu_frame(world, tile_h, gather, mode, local_first, whole, monkeypatch):
     """mode 0 (the default): hit colours AND hit normals by request / reply (vkr_sssr_trace_windowed, vkr_hit_requests /
     _reply / _scatter, vkr_sssr_validate); 1: the albedo and the downsampled normals of the whole frame all-gathered into
     every rank (round 2); 2: albedo by request, normals gathered.  All must equal the plain frame on every tile interior.
     local_first (VKR_TILED_LOCAL_FIRST=1, off by default): the trace in two stages around the depth gather — head on the
-    rank's own pyramid rows, resume on the whole-frame pyramid — and the TAA behind GTAO."""
+    rank's own pyramid rows, resume on the whole-frame pyramid — and the TAA behind GTAO.
+    whole (VKR_TILED_WHOLE_WINDOW=1): every pass on its whole window, as in round 3; by default a rank computes only the rows
+    of its window that something reads (host/frame.cpp: clip_outputs)."""
     import torch
 
+    monkeypatch.setenv("VKR_TILED_WHOLE_WINDOW", "1" if whole else "0")
     monkeypatch.setenv("VKR_TILED_GATHER_MODE", str(mode))
     monkeypatch.setenv("VKR_TILED_LOCAL_FIRST", "1" if local_first else "0")
     by_gather = mode == 1
