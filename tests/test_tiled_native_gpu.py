@@ -165,3 +165,35 @@ def test_native_tiled_frame_through_a_one_rank_rccl_communicator(gather_v, monke
     t.frame.close()
     comm.close()
     assert bad == 0
+
+
+def test_one_rank_without_force_tiled_has_no_phases():
+    """A one-rank frame that is not forced onto the multi-GPU path has no exchange stream and no events: vkrh_tiled_step runs
+    the plain chain, vkrh_tiled_phase refuses with a message.  The Python harness does not even make a native frame for it
+    (TiledFrame.native is False, its handle None): the vkrh_tiled_* entries must answer a NULL handle with an error, not a
+    crash (tools/lockstep_profile.py --world 1 ran into exactly that)."""
+    import torch
+
+    from vk_renderer_amd.camera import FrameSetup
+    from vk_renderer_amd.tiling import HostBackend, TiledFrame
+
+    W, H = 256, 128
+    device = torch.device("cuda", 0)
+    t = TiledFrame(FrameSetup(W, H), 0, 1, 1, 1, device, native=True, comm=None)
+    assert not t.tiled and not t.native and t.frame.tiled_handle is None
+    for call in (lambda: t.frame.tiled_phase(0), t.frame.tiled_step, t.frame.tiled_flush, lambda: t.frame.tiled_time_waits(True)):
+        with pytest.raises(RuntimeError, match="NULL tiled frame"):
+            call()
+    t.frame.close()
+    # the C++ tiled frame itself, one rank, not forced: step is the plain chain, phases do not exist
+    b = HostBackend(FrameSetup(W, H), (0, 0, W, H), False, device,
+                    native=dict(rank=0, world=1, halo=48, gathered_mips=4, force_tiled=False, comm=None, row_bounds=None))
+    b.prepare()
+    with pytest.raises(RuntimeError, match="not tiled"):
+        b.frame.tiled_phase(0)
+    for _ in range(2):
+        b.frame.tiled_step()
+    b.frame.tiled_flush()
+    torch.cuda.synchronize()
+    assert b.frame.download("taa_hist").raw(0).any()  # the chain ran
+    b.frame.close()

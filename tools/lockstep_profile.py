@@ -26,7 +26,7 @@ from vk_renderer_amd.tiling import TiledFrame, native_lockstep_frame  # noqa: E4
 
 
 def measure(W, H, world, bounds, frames, warmup, device):
-    ranks = [TiledFrame(FrameSetup(W, H), r, world, 1, world, device, native=True, comm=None, row_bounds=bounds) for r in range(world)]
+    ranks = [TiledFrame(FrameSetup(W, H), r, world, 1, world, device, native=True, comm=None, row_bounds=bounds, force_tiled=world == 1) for r in range(world)]
     for t in ranks:
         t.prepare()
     for _ in range(warmup):

@@ -715,6 +715,7 @@ struct TiledFrame {
 
   // ---- the frame, in phases (an exchange may only start / must be complete at a phase boundary) ------------------------
   void phase(uint32_t p) {
+    if (!tiled) throw std::runtime_error {"vkrh_tiled_phase: this frame is not tiled (one rank without force_tiled has no phases: use vkrh_tiled_step)"};
     PostFxFrame& f = *frame;
     static const char* const names[VKRH_TILED_PHASES] = {"tiled: downsample | start gathers", "tiled: TAA | halo", "tiled: Hi-Z tail + trace",
                                                         "tiled: GTAO | halo | hit colours", "tiled: SSR filter + blur | halo"};
@@ -1072,9 +1073,14 @@ void* vkrh_tiled_create(const vkrh_tiled_config* cfg) {
 }
 void vkrh_tiled_destroy(void* tiled) { delete (TiledFrame*)tiled; }
 void* vkrh_tiled_frame(void* tiled) { return tiled ? ((TiledFrame*)tiled)->frame.get() : nullptr; }
-int vkrh_tiled_step(void* tiled) { return guarded([&] { ((TiledFrame*)tiled)->step(); }); }
-int vkrh_tiled_flush(void* tiled) { return guarded([&] { ((TiledFrame*)tiled)->flush(); }); }
-int vkrh_tiled_phase(void* tiled, uint32_t phase) { return guarded([&] { ((TiledFrame*)tiled)->phase(phase); }); }
+// (a NULL handle is an error message, not a crash: the Python harness keeps None for frames that are not native)
+static TiledFrame& tiled_ref(void* tiled, const char* what) {
+  if (!tiled) throw std::runtime_error{std::string{what} + ": NULL tiled frame"};
+  return *(TiledFrame*)tiled;
+}
+int vkrh_tiled_step(void* tiled) { return guarded([&] { tiled_ref(tiled, "vkrh_tiled_step").step(); }); }
+int vkrh_tiled_flush(void* tiled) { return guarded([&] { tiled_ref(tiled, "vkrh_tiled_flush").flush(); }); }
+int vkrh_tiled_phase(void* tiled, uint32_t phase) { return guarded([&] { tiled_ref(tiled, "vkrh_tiled_phase").phase(phase); }); }
 int vkrh_tiled_gather_parts(void* tiled, uint32_t which, vkr_gather_part* out, uint32_t capacity, uint32_t* count) {
   return guarded([&] {
     if (!tiled || !out || !count || capacity < 8 || which > 1) throw std::runtime_error{"vkrh_tiled_gather_parts: bad arguments (capacity >= 8)"};
@@ -1140,7 +1146,7 @@ int vkrh_tiled_hit_rounds(void* tiled, uint64_t* rounds3) {
 int vkrh_tiled_local_first(void* tiled) { return tiled && ((TiledFrame*)tiled)->local_first() ? 1 : 0; }
 int vkrh_tiled_time_waits(void* tiled, uint32_t on) {
   return guarded([&] {
-    auto* t = (TiledFrame*)tiled;
+    auto* t = &tiled_ref(tiled, "vkrh_tiled_time_waits");
     t->time_waits = on != 0;
     if (!on) {  // marks nobody collected: their events must not pile up
       TiledFrame::check(hipStreamSynchronize(t->compute), "synchronize");
