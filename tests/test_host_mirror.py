@@ -115,3 +115,29 @@ def test_async_lanes_follow_declared_hazards():
         frame.close()
     for n in outs[False]:
         assert np.array_equal(outs[False][n], outs[True][n]), f"{n}: overlapped frame differs from the one-stream frame"
+
+
+def test_null_handles_are_messages_not_crashes():
+    """Every vkrh_* entry that takes a frame (or tiled-frame) handle answers NULL with a non-zero status and a message:
+    the Python harness keeps None for frames it did not create natively (tools/lockstep_profile.py --world 1 found the
+    crash this replaces).  No device call is reached, so this runs without a GPU."""
+    import ctypes as C
+
+    from vk_renderer_amd import host
+
+    l = host.lib()
+    l.vkrh_last_error.restype = C.c_char_p
+    for name, extra in (("vkrh_run", (C.c_uint32(1),)), ("vkrh_end_frame", (C.c_uint32(0),)), ("vkrh_set_async", (C.c_uint32(1),)),
+                        ("vkrh_enable_task_timing", (C.c_uint32(1),)), ("vkrh_tiled_step", ()), ("vkrh_tiled_flush", ()),
+                        ("vkrh_tiled_phase", (C.c_uint32(0),)), ("vkrh_tiled_time_waits", (C.c_uint32(1),))):
+        fn = getattr(l, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p] + [type(e) for e in extra]
+        assert fn(None, *extra) != 0, name
+        assert b"NULL" in l.vkrh_last_error(), (name, l.vkrh_last_error())
+    l.vkrh_collect_task_times.restype = C.c_char_p
+    l.vkrh_collect_task_times.argtypes = [C.c_void_p]
+    assert l.vkrh_collect_task_times(None) is None
+    l.vkrh_last_tasks.restype = C.c_char_p
+    l.vkrh_last_tasks.argtypes = [C.c_void_p]
+    assert l.vkrh_last_tasks(None) == b""

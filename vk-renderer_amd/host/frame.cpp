@@ -801,6 +801,12 @@ template <typename F> int guarded(F&& f) {
   catch (...) { g_error = "unknown exception"; return 2; }
 }
 
+// the frame behind a vkrh_* handle; a NULL handle is an error message, not a crash
+PostFxFrame& frame_ref(void* frame) {
+  if (!frame) throw std::runtime_error{"NULL frame"};
+  return *(PostFxFrame*)frame;
+}
+
 }  // namespace
 
 extern "C" {
@@ -827,11 +833,11 @@ int vkrh_has_program(const char* name) {
 }
 
 int vkrh_set_camera(void* frame, const vkrh_camera* cam) {
-  return guarded([&] { if (!frame || !cam) throw std::runtime_error{"NULL argument"}; ((PostFxFrame*)frame)->set_camera(*cam); });
+  return guarded([&] { if (!frame || !cam) throw std::runtime_error{"NULL argument"}; frame_ref(frame).set_camera(*cam); });
 }
 int vkrh_pin_randoms(void* frame, float jitter, uint32_t gtao_frame_count, uint32_t ssr_counter) {
   return guarded([&] {
-    auto* f = (PostFxFrame*)frame;
+    auto* f = &frame_ref(frame);
     f->gtao.pin_angle_jitter(jitter);
     f->gtao.set_frame_count(gtao_frame_count);
     f->ssr.set_counter(ssr_counter);
@@ -840,7 +846,7 @@ int vkrh_pin_randoms(void* frame, float jitter, uint32_t gtao_frame_count, uint3
 int vkrh_load_scene(void* frame, const vkr_raster_vertex* vertices, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
                     const vkrh_scene_draw* draws, uint32_t draw_count, const vkrh_scene_texture* textures, uint32_t texture_count) {
   return guarded([&] {
-    auto* f = (PostFxFrame*)frame;
+    auto* f = &frame_ref(frame);
     if (!f || !vertices || !indices || (!draws && draw_count) || (!textures && texture_count)) throw std::runtime_error{"NULL argument"};
     std::vector<scene::FlatDraw> flat(draw_count);
     for (uint32_t i = 0; i < draw_count; i++) {
@@ -865,32 +871,32 @@ int vkrh_load_scene(void* frame, const vkr_raster_vertex* vertices, uint32_t ver
 }
 int vkrh_pin_screen_trace(void* frame, float angle_jitter, float random_offset, uint32_t frame_count) {
   return guarded([&] {
-    auto* f = (PostFxFrame*)frame;
+    auto* f = &frame_ref(frame);
     f->screen_trace.pin_randoms(angle_jitter, random_offset);
     f->screen_trace.set_frame_count(frame_count);
   });
 }
 int vkrh_set_gtao_mode(void* frame, uint32_t use_mis, uint32_t two_directions) {
-  return guarded([&] { auto* f = (PostFxFrame*)frame; f->gtao.set_mis(use_mis != 0); f->gtao.set_two_directions(two_directions != 0); });
+  return guarded([&] { auto* f = &frame_ref(frame); f->gtao.set_mis(use_mis != 0); f->gtao.set_two_directions(two_directions != 0); });
 }
 int vkrh_set_synth_flags(void* frame, uint32_t flags) {
   return guarded([&] {
     if (!frame) throw std::runtime_error{"NULL argument"};
     if (flags & ~uint32_t(VKR_SYNTH_TEXTURED_ROUGHNESS)) throw std::runtime_error{"vkrh_set_synth_flags: unknown flag"};
-    ((PostFxFrame*)frame)->synth.set_material_flags(flags);
+    frame_ref(frame).synth.set_material_flags(flags);
   });
 }
 int vkrh_set_gathered_mips(void* frame, uint32_t mips) {
   return guarded([&] {
     if (mips < 1 || mips > 4) throw std::runtime_error{"vkrh_set_gathered_mips: 1..4"};
-    ((PostFxFrame*)frame)->hiz_gathered_mips = mips;
+    frame_ref(frame).hiz_gathered_mips = mips;
   });
 }
-int vkrh_run(void* frame, uint32_t stage_mask) { return guarded([&] { ((PostFxFrame*)frame)->run(stage_mask); }); }
-int vkrh_end_frame(void* frame, uint32_t swap_depth) { return guarded([&] { ((PostFxFrame*)frame)->end_frame(swap_depth != 0); }); }
+int vkrh_run(void* frame, uint32_t stage_mask) { return guarded([&] { frame_ref(frame).run(stage_mask); }); }
+int vkrh_end_frame(void* frame, uint32_t swap_depth) { return guarded([&] { frame_ref(frame).end_frame(swap_depth != 0); }); }
 int vkrh_image(void* frame, const char* name, uint32_t base_mip, uint32_t mip_count, vkr_img* out) {
   return guarded([&] {
-    auto* f = (PostFxFrame*)frame;
+    auto* f = &frame_ref(frame);
     if (!f || !name || !out) throw std::runtime_error{"NULL argument"};
     auto& img = f->graph.get_image(f->lookup(name));
     if (mip_count == 0) mip_count = img->get_mip_levels() - base_mip;
@@ -899,7 +905,7 @@ int vkrh_image(void* frame, const char* name, uint32_t base_mip, uint32_t mip_co
 }
 int vkrh_read_buffer(void* frame, const char* name, void* dst, uint64_t capacity, uint64_t* bytes) {
   return guarded([&] {
-    auto* f = (PostFxFrame*)frame;
+    auto* f = &frame_ref(frame);
     if (!f || !name || !dst) throw std::runtime_error{"NULL argument"};
     const std::string n{name};
     rendergraph::BufferResourceId id;
@@ -920,14 +926,14 @@ int vkrh_read_buffer(void* frame, const char* name, void* dst, uint64_t capacity
 }
 int vkrh_image_layer(void* frame, const char* name, uint32_t layer, vkr_img* out) {
   return guarded([&] {
-    auto* f = (PostFxFrame*)frame;
+    auto* f = &frame_ref(frame);
     if (!f || !name || !out) throw std::runtime_error{"NULL argument"};
     *out = f->graph.get_image(f->lookup(name))->describe_layer(layer);
   });
 }
 int vkrh_capture(void* frame, const char* name, uint32_t mip, uint32_t kind, const char* path) {
   return guarded([&] {
-    auto* f = (PostFxFrame*)frame;
+    auto* f = &frame_ref(frame);
     if (!f || !name || !path) throw std::runtime_error{"NULL argument"};
     const ReadBackID id = f->readback.read_image(f->graph, f->lookup(name), 0, mip, 0);
     // the request matures frames_count + 1 submits later, like the reference's fenced frames
@@ -976,9 +982,10 @@ int vkrh_selftest_writers(const char* dir, uint32_t width, uint32_t height) {
       throw std::runtime_error{"cannot write PNG files under " + base};
   });
 }
-int vkrh_enable_task_timing(void* frame, uint32_t on) { return guarded([&] { ((PostFxFrame*)frame)->graph.enable_task_timing(on != 0); }); }
-int vkrh_enable_task_timing_only(void* frame, const char* task) { return guarded([&] { ((PostFxFrame*)frame)->graph.enable_task_timing(true, task ? task : ""); }); }
+int vkrh_enable_task_timing(void* frame, uint32_t on) { return guarded([&] { frame_ref(frame).graph.enable_task_timing(on != 0); }); }
+int vkrh_enable_task_timing_only(void* frame, const char* task) { return guarded([&] { frame_ref(frame).graph.enable_task_timing(true, task ? task : ""); }); }
 const char* vkrh_collect_task_times(void* frame) {
+  if (!frame) { g_error = "NULL frame"; return nullptr; }
   auto* f = (PostFxFrame*)frame;
   f->task_names.clear();
   int rc = guarded([&] {
@@ -1192,8 +1199,8 @@ int vkrh_balance_rows(const float* ms, const uint32_t* bounds_in, uint32_t world
     }
   });
 }
-const char* vkrh_last_tasks(void* frame) { return ((PostFxFrame*)frame)->task_names.c_str(); }
-const char* vkrh_last_lanes(void* frame) { return ((PostFxFrame*)frame)->task_lanes.c_str(); }
-int vkrh_set_async(void* frame, uint32_t on) { return guarded([&] { ((PostFxFrame*)frame)->graph.set_async(on != 0); }); }
+const char* vkrh_last_tasks(void* frame) { return frame ? ((PostFxFrame*)frame)->task_names.c_str() : ""; }
+const char* vkrh_last_lanes(void* frame) { return frame ? ((PostFxFrame*)frame)->task_lanes.c_str() : ""; }
+int vkrh_set_async(void* frame, uint32_t on) { return guarded([&] { frame_ref(frame).graph.set_async(on != 0); }); }
 
 }  // extern "C"
