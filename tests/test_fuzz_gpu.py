@@ -36,6 +36,9 @@ def _case(seed):
                        weight_ratio=rng.uniform(0.5, 2.0), two_directions=rng.choice((0, 255)), reflections_only=rng.choice((0, 0, 255))),
         gtao_accumulate=dict(clear_history=rng.choice((0, 0, 1))),
     )
+    # (drawn last, so that the cases of earlier rounds keep their other values) half of the cases on the scene whose roughness
+    # varies per texel: blur sigma differs from lane to lane, the resolve and GTAO see per-texel materials
+    setup["material"] = rng.choice(("flat", "textured"))
     return w, h, setup, params
 
 
