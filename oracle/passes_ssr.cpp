@@ -87,6 +87,12 @@ thread_local uint32_t t_last_steps = 0;
 // instrumentation for kernel design (tools/trace_steps.py --gate): how often the horizon update of a step is evaluated, passes its
 // |v| < 0.3 gate, and could have been refused by |v.z| alone; [0..3] pinned steps, [4..7] later steps: {steps, mip <= 1, passed, |v.z| >= 0.3}
 uint64_t* g_gate_counters = nullptr;
+// instrumentation for the multi-GPU design (tools/trace_row_reach.py): per ray, the first and one-past-the-last row of pyramid
+// level 0 covered by the texels its march fetched inside the frame (a texel of level L in row ty covers rows [ty << L, (ty + 1) << L));
+// two uint16 per ray: {first, end}, 0xFFFF / 0 when it fetched nothing inside the frame
+uint16_t* g_reach_sink = nullptr;
+int g_reach_sink_pitch = 0;
+thread_local uint32_t t_reach_lo = 0xFFFFu, t_reach_hi = 0u;
 
 // trace.comp:206-268
 vec3 hierarchical_raymarch_find_hor(const TraceCtx& c, vec3 origin, vec3 direction, int most_detailed_mip,
@@ -103,9 +109,17 @@ vec3 hierarchical_raymarch_find_hor(const TraceCtx& c, vec3 origin, vec3 directi
                       s.floor_offset, s.uv_offset, position, current_t);
   h = 0.0f;
   uint32_t i = 0;
+  t_reach_lo = 0xFFFFu; t_reach_hi = 0u;
   while (i < max_traversal_intersections && current_mip >= most_detailed_mip) {
     vec2 current_mip_position = current_mip_resolution * position.xy();
     float surface_z = depth_tex.fetch(to_ivec2(current_mip_position), current_mip).x;
+    if (g_reach_sink) {
+      const ivec2 q = to_ivec2(current_mip_position);
+      if (current_mip >= 0 && current_mip < depth_tex.mips() && q.x >= 0 && q.y >= 0 && q.x < depth_tex.fw(current_mip) && q.y < depth_tex.fh(current_mip)) {
+        t_reach_lo = std::min(t_reach_lo, (uint32_t)q.y << current_mip);
+        t_reach_hi = std::max(t_reach_hi, std::min((uint32_t)(q.y + 1) << current_mip, 0xFFFFu));
+      }
+    }
     bool skipped_tile = advance_ray(origin, direction, s.inv_direction, current_mip_position,
                                     current_mip_resolution_inv, s.floor_offset, s.uv_offset, surface_z,
                                     position, current_t);
@@ -138,6 +152,7 @@ vec3 hierarchical_raymarch_find_hor(const TraceCtx& c, vec3 origin, vec3 directi
 
 extern "C" void vkr_ref_set_step_sink(uint8_t* sink, int pitch_bytes) { g_step_sink = sink; g_step_sink_pitch = pitch_bytes; }
 extern "C" void vkr_ref_set_gate_counters(uint64_t* counters8) { g_gate_counters = counters8; }
+extern "C" void vkr_ref_set_reach_sink(uint16_t* sink, int pitch_bytes) { g_reach_sink = sink; g_reach_sink_pitch = pitch_bytes; }
 
 // trace.comp:41-141.  window != NULL: the multi-GPU variant (include/vkr_postfx.h vkr_sssr_trace_windowed) — the same
 // conjunction of validity tests, with the hit-normal test of a ray whose footprint rows are not all inside
@@ -199,6 +214,10 @@ static int trace_impl(const vkr_img* depth, const vkr_img* normal, const vkr_img
 
       vec3 out_r = hierarchical_raymarch_find_hor(c, ray_start, ray_dir, 0, 80, valid_hit, pixel_normal, view_vec, h);
       if (g_step_sink) g_step_sink[(size_t)ly * g_step_sink_pitch + lx] = (uint8_t)t_last_steps;
+      if (g_reach_sink) {
+        uint16_t* r = (uint16_t*)((uint8_t*)g_reach_sink + (size_t)ly * g_reach_sink_pitch) + 2 * lx;
+        r[0] = (uint16_t)t_reach_lo; r[1] = (uint16_t)t_reach_hi;
+      }
 
       if (valid_hit) {
         vec2 ray_step = abs(out_r.xy() - ray_start.xy()) * tex_size;
