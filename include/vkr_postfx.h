@@ -474,6 +474,15 @@ int vkr_comm_rank(const vkr_comm* comm, int* rank, int* world);
  * agrees on the result over its control plane before the collective vkr_comm_create, so that a rank without RCCL
  * cannot leave the others blocked inside ncclCommInitRank                                                          */
 int vkr_comm_available(void);
+/* A communicator that moves NOTHING and takes the time a fully connected xGMI node would (measurement facility, no RCCL
+ * needed): every exchange enqueues, on the caller's stream, a one-wave kernel that holds the stream for
+ * launch_us + (bytes on the busiest link) / link_gbps — each peer on a link of its own, full duplex: an all-gather costs
+ * the largest share any peer sends, a point-to-point group the largest per-peer total — and copies the rank's own share of
+ * an out-of-place all-gather into its slot.  What the peers would have sent is whatever the receive buffers already hold:
+ * with a static scene and buffers filled once by real peers (the in-process lockstep harness) every frame receives what it
+ * would have received, so the frame's stream / event schedule runs against realistic wire times on ONE GPU
+ * (tools/wire_emulation.py, vkrh_tiled_emulate_wire).                                                                   */
+int vkr_comm_create_emulated(int rank, int world, float link_gbps, float launch_us, vkr_comm** out);
 /* Start-up check of a fresh communicator, collective: every rank gathers a rank-tagged pattern through vkr_all_gather
  * and vkr_all_gather_v (shares of different sizes, in place) and trades one with each neighbour rank through
  * vkr_halo_exchange, on `stream`, then verifies every byte it received (synchronises the stream).  0 = the wire delivers

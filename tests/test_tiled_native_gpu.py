@@ -197,3 +197,66 @@ def test_one_rank_without_force_tiled_has_no_phases():
     torch.cuda.synchronize()
     assert b.frame.download("taa_hist").raw(0).any()  # the chain ran
     b.frame.close()
+
+
+def test_native_frame_on_an_emulated_wire_receives_what_its_peers_would_send():
+    """tools/wire_emulation.py in small: three ranks are driven in lockstep with real data (the SSR frame counter pinned, so every
+    frame asks for the same hit texels; the last frame's hit segments in the native layout, host.hit_capacities), then every rank
+    goes on NATIVELY — its own exchange stream, events, the hit round enqueued on the previous frame's counts — on an emulated
+    communicator that moves nothing and holds the stream for the wire's time (vkr_comm_create_emulated).  What the passes without
+    a history produce (rays, raw, reflections, filtered) must still be the plain frame's, bit for bit: the stale receive buffers
+    are what the peers would send — vkr_hit_requests hands out the slots of a segment in a fixed order, so this frame's requests
+    sit where the replies of the last lockstep frame answer them —, no request names a texel its owner does not hold, every
+    round goes out on the seeded capacities, and nothing runs ahead of the exchange it needs."""
+    import torch
+
+    from vk_renderer_amd import abi
+    from vk_renderer_amd.camera import FrameSetup
+    from vk_renderer_amd.tiling import TiledFrame
+
+    world, tw, th = 3, 256, 160
+    W, H = tw, th * world
+    device = torch.device("cuda", 0)
+    plain = TiledFrame(FrameSetup(W, H), 0, 1, 1, 1, device)
+    plain.prepare()
+    for _ in range(3):
+        plain.frame.pin_randoms(0.0, 0, 0)
+        plain.step()
+    plain.backend.sync()
+    names = ("rays", "raw", "reflections", "filtered")
+    want = {n: plain.frame.download(n) for n in names}
+    plain.frame.close()
+
+    ranks = [TiledFrame(FrameSetup(W, H), r, world, 1, world, device, native=True, comm=None) for r in range(world)]
+    for t in ranks:
+        t.prepare()
+    for k in range(3):
+        for t in ranks:
+            t.frame.pin_randoms(0.0, 0, 0)
+        lockstep_frame(ranks, hit_in_capacities=(k == 2))
+    counts = ranks[0].hit_matrix
+    assert sum(counts) > 0
+    bad = 0
+    for r, t in enumerate(ranks):
+        comm = abi.Comm.emulated(r, world, 60.0, 5.0)
+        t.frame.tiled_emulate_wire(comm.handle, counts)
+        for _ in range(3):
+            t.frame.pin_randoms(0.0, 0, 0)
+            t.frame.tiled_step()
+        t.frame.tiled_flush()
+        torch.cuda.synchronize()
+        assert t.frame.tiled_hit_errors() == 0
+        assert t.frame.tiled_hit_rounds() == (3, 0, 0), "every round must go out on the seeded capacities, none repeated"
+        x0, y0, _, _ = t.tile
+        for name in names:
+            got = t.frame.download(name)
+            ox, oy = got.origin
+            a = got.raw(0)[(y0 >> 1) - oy:(y0 >> 1) - oy + (th >> 1), (x0 >> 1) - ox:(x0 >> 1) - ox + (tw >> 1)]
+            b = want[name].raw(0)[(y0 >> 1):(y0 >> 1) + (th >> 1), (x0 >> 1):(x0 >> 1) + (tw >> 1)]
+            n = int((a != b).any(axis=-1).sum())
+            if n:
+                print(f"rank {r} {name}: {n} differing texels")
+            bad += n
+        t.frame.close()
+        comm.close()
+    assert bad == 0

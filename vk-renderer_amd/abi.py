@@ -296,6 +296,8 @@ def product():
         lib.vkr_comm_unique_id.argtypes = [C.c_void_p]
         lib.vkr_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, P(C.c_void_p)]
         lib.vkr_comm_destroy.argtypes = [C.c_void_p]
+        lib.vkr_comm_create_emulated.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, P(C.c_void_p)]
+        lib.vkr_comm_create_emulated.restype = C.c_int
         lib.vkr_comm_available.argtypes = []
         lib.vkr_get_switches.argtypes = []
         lib.vkr_get_switches.restype = C.c_uint32
@@ -364,6 +366,16 @@ class Comm:
         h = C.c_void_p(0)
         check(lib.vkr_comm_create((C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(ident), rank, world, C.byref(h)), lib)
         self.handle = h.value
+
+    @classmethod
+    def emulated(cls, rank, world, link_gbps=60.0, launch_us=15.0):
+        """vkr_comm_create_emulated: moves nothing, holds the stream for the wire's time (tools/wire_emulation.py)"""
+        self = cls.__new__(cls)
+        lib = product()
+        h = C.c_void_p(0)
+        check(lib.vkr_comm_create_emulated(rank, world, link_gbps, launch_us, C.byref(h)), lib)
+        self.handle = h.value
+        return self
 
     def self_check(self, device, agree=None):
         """Moves rank-tagged patterns through vkr_all_gather, vkr_all_gather_v and vkr_halo_exchange and verifies every

@@ -46,7 +46,8 @@ struct HitReqArgs {
 // line, a device-scope atomic on one line costs ~11 ns whoever issues it, and one reservation per 64 x 4 tile (16 k tiles of
 // a 7680 x 540 strip) made this byte-moving kernel take 0.16 ms — and leaves what it counted in the workspace.  Pass 2 has
 // the same blocks walk the same tiles: a block's requests for owner o start at segment[o] + what the blocks before it
-// counted, so it needs neither a second count nor a global atomic (within a block's range the order is that of its LDS atomics).
+// counted, so it needs neither a second count nor a global atomic; within a block's range the slots go out in a fixed order (tile,
+// wave, request of the ray, lane), so the same rays always put the same bytes on the wire.
 #define HIT_BLOCKS 256
 static_assert(HIT_BLOCKS * HIT_MAX_WORLD == VKR_HIT_WORKSPACE_WORDS, "the workspace holds one count per block and owner");
 #define HIT_BATCH 4
@@ -106,8 +107,13 @@ VKR_DEV int hit_emit(const HitReqArgs& a, const HitRay& r, uint32_t* code, uint3
   return n;
 }
 
+VKR_DEV int wave_rank_of(uint64_t mask) {  // set bits of `mask` below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 __global__ __launch_bounds__(1024) void k_hit_requests(HitReqArgs a, HitTile g) {
   __shared__ uint32_t s_n[HIT_MAX_WORLD], s_base[HIT_MAX_WORLD], s_end[HIT_MAX_WORLD];  // s_end: one past the last slot of the owner's segment
+  __shared__ uint32_t s_wcnt[16][HIT_MAX_WORLD];  // pass 2: requests per wave and owner of the tile in hand
   const int tid = threadIdx.x;
   const int tiles = g.tiles_x * g.tiles_y;
   if (tid < HIT_MAX_WORLD) { s_n[tid] = 0u; s_base[tid] = a.seg[tid]; s_end[tid] = a.cap[tid] == 0xFFFFFFFFu ? 0xFFFFFFFFu : a.seg[tid] + a.cap[tid]; }
@@ -120,6 +126,7 @@ __global__ __launch_bounds__(1024) void k_hit_requests(HitReqArgs a, HitTile g) 
     __syncthreads();
   }
   uint32_t code[4], owner[4];
+  const int wave = tid >> 6;
   for (int first = blockIdx.x; first < tiles; first += gridDim.x * HIT_BATCH) {
     HitRay r[HIT_BATCH];
 #pragma unroll
@@ -127,14 +134,40 @@ __global__ __launch_bounds__(1024) void k_hit_requests(HitReqArgs a, HitTile g) 
 #pragma unroll
     for (int j = 0; j < HIT_BATCH; j++) {
       const int n = hit_emit(a, r[j], code, owner);
-      for (int k = 0; k < n; k++) {
-        const uint32_t slot = atomicAdd(&s_n[owner[k]], 1u);
-        if (a.out) {
-          const uint32_t at = s_base[owner[k]] + slot;
-          if (at < s_end[owner[k]]) a.out[at] = code[k];
-          else if (a.dropped) *a.dropped = 1u;  // a bounded segment drops what does not fit, and says so
+      if (!a.out) {  // pass 1 counts: any order will do
+        for (int k = 0; k < n; k++) atomicAdd(&s_n[owner[k]], 1u);
+        continue;
+      }
+      // Pass 2 hands out the slots of a segment in a FIXED order — tile, wave, request k of the ray, lane — so that the same
+      // rays always produce the same bytes on the wire (a frame can be replayed; two runs can be compared request by request).
+      // Per tile: every wave counts its requests per owner (ballots), then takes its range behind the waves before it.
+      for (uint32_t o = 0; o < a.world; o++) {
+        uint32_t c = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) c += (uint32_t)__popcll(__ballot(k < n && owner[k] == o));
+        if ((tid & 63) == 0) s_wcnt[wave][o] = c;
+      }
+      __syncthreads();
+      uint32_t total = 0u;  // (thread o: what the whole block adds to owner o with this tile)
+      if (tid < (int)a.world)
+        for (int w = 0; w < 16; w++) total += s_wcnt[w][tid];
+      for (uint32_t o = 0; o < a.world; o++) {
+        uint32_t at = s_base[o] + s_n[o];
+        for (int w = 0; w < wave; w++) at += s_wcnt[w][o];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const bool mine = k < n && owner[k] == o;
+          const uint64_t m = __ballot(mine);
+          if (mine) {
+            const uint32_t slot = at + (uint32_t)wave_rank_of(m);
+            if (slot < s_end[o]) a.out[slot] = code[k];
+            else if (a.dropped) *a.dropped = 1u;  // a bounded segment drops what does not fit, and says so
+          }
+          at += (uint32_t)__popcll(m);
         }
       }
+      __syncthreads();
+      if (tid < (int)a.world) s_n[tid] += total;
     }
   }
   if (a.out) return;

@@ -78,7 +78,22 @@ int fail(const char* what, ncclResult_t r) {
 struct vkr_comm {
   ncclComm_t comm;
   int rank, world;
+  bool emulated = false;      // vkr_comm_create_emulated: no bytes move, the stream is held for the time the wire would take
+  float link_gbps = 0.0f, launch_us = 0.0f;
 };
+
+namespace {
+// one wave that holds its stream for `ticks` of the 100 MHz wall clock (the time passes whatever else happens: every wave exits)
+__global__ void k_wire_delay(uint64_t ticks) {
+  const uint64_t t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+int emulate_wire(const vkr_comm* comm, uint64_t busiest_link_bytes, void* stream, const char* what) {
+  const double us = (double)comm->launch_us + (double)busiest_link_bytes / ((double)comm->link_gbps * 1e3);
+  hipLaunchKernelGGL(k_wire_delay, dim3(1), dim3(64), 0, (hipStream_t)stream, (uint64_t)(us * 100.0));
+  return vkr::launch_status(what);
+}
+}  // namespace
 
 static_assert(sizeof(ncclUniqueId) == VKR_COMM_ID_BYTES, "VKR_COMM_ID_BYTES must hold an ncclUniqueId");
 
@@ -105,8 +120,21 @@ extern "C" int vkr_comm_create(const uint8_t* id_bytes, int rank, int world, vkr
   return vkr::VKR_OK;
 }
 
+extern "C" int vkr_comm_create_emulated(int rank, int world, float link_gbps, float launch_us, vkr_comm** out) {
+  if (!out) { vkr::set_error("comm_create_emulated: NULL argument"); return vkr::VKR_ERR_NULL; }
+  if (world < 1 || rank < 0 || rank >= world || !(link_gbps > 0.0f) || launch_us < 0.0f) {
+    vkr::set_error("comm_create_emulated: rank %d of %d, %g GB/s per link, %g us per launch", rank, world, (double)link_gbps, (double)launch_us);
+    return vkr::VKR_ERR_EXTENT;
+  }
+  vkr_comm* c = new vkr_comm{nullptr, rank, world};
+  c->emulated = true; c->link_gbps = link_gbps; c->launch_us = launch_us;
+  *out = c;
+  return vkr::VKR_OK;
+}
+
 extern "C" int vkr_comm_destroy(vkr_comm* comm) {
   if (!comm) return vkr::VKR_OK;
+  if (comm->emulated) { delete comm; return vkr::VKR_OK; }
   const ncclResult_t r = g_rccl.CommDestroy(comm->comm);
   delete comm;
   return r == ncclSuccess ? vkr::VKR_OK : fail("comm_destroy", r);
@@ -126,6 +154,17 @@ extern "C" int vkr_all_gather(vkr_comm* comm, const vkr_gather_part* parts, uint
   if (!comm || !parts) { vkr::set_error("all_gather: NULL argument"); return vkr::VKR_ERR_NULL; }
   for (uint32_t i = 0; i < count; i++)
     if (!parts[i].send || !parts[i].recv || parts[i].bytes == 0) { vkr::set_error("all_gather: part %u is empty", i); return vkr::VKR_ERR_NULL; }
+  if (comm->emulated) {  // every peer's share arrives on its own link, the parts one after the other
+    uint64_t link = 0;
+    for (uint32_t i = 0; i < count; i++) {
+      void* dst = (uint8_t*)parts[i].recv + uint64_t(comm->rank) * parts[i].bytes;
+      if (parts[i].send != dst && hipMemcpyAsync(dst, parts[i].send, (size_t)parts[i].bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+        vkr::set_error("all_gather (emulated): copy of the own share failed"); return vkr::VKR_ERR_LAYOUT;
+      }
+      link += parts[i].bytes;
+    }
+    return emulate_wire(comm, comm->world > 1 ? link : 0, stream, "all_gather (emulated)");
+  }
   ncclResult_t r = g_rccl.GroupStart();
   for (uint32_t i = 0; r == ncclSuccess && i < count; i++)
     r = g_rccl.AllGather(parts[i].send, parts[i].recv, (size_t)parts[i].bytes, ncclUint8, comm->comm, (hipStream_t)stream);
@@ -149,6 +188,25 @@ extern "C" int vkr_all_gather_v(vkr_comm* comm, const vkr_gather_v_part* parts, 
   // the point-to-point operations of a group into one launch (the same shape as an all-to-all-v).  VKR_GATHER_V_BROADCAST=1
   // selects the textbook form instead, one ncclBroadcast per surface and owner (world x surfaces collectives in the group).
   static const bool by_broadcast = getenv("VKR_GATHER_V_BROADCAST") != nullptr;
+  if (comm->emulated) {  // peer r's shares of all parts arrive on the link from r: the busiest link carries the tallest strip
+    uint64_t link = 0;
+    for (int peer = 0; peer < comm->world; peer++) {
+      uint64_t b = 0;
+      for (uint32_t i = 0; i < count; i++) b += parts[i].offsets[peer + 1] - parts[i].offsets[peer];
+      if (peer == comm->rank) {  // what this rank sends to every peer leaves on as many links, full duplex: its own share counts once
+        for (uint32_t i = 0; i < count; i++) {
+          const vkr_gather_v_part& p = parts[i];
+          const uint64_t n = p.offsets[peer + 1] - p.offsets[peer];
+          void* dst = (uint8_t*)p.recv + p.offsets[peer];
+          if (n && p.send != dst && hipMemcpyAsync(dst, p.send, (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+            vkr::set_error("all_gather_v (emulated): copy of the own share failed"); return vkr::VKR_ERR_LAYOUT;
+          }
+        }
+      }
+      if (comm->world > 1 && b > link) link = b;
+    }
+    return emulate_wire(comm, link, stream, "all_gather_v (emulated)");
+  }
   if (!by_broadcast) {
     for (uint32_t i = 0; i < count; i++) {  // my own share into place (what the root's broadcast would have copied)
       const vkr_gather_v_part& p = parts[i];
@@ -197,6 +255,17 @@ extern "C" int vkr_halo_exchange(vkr_comm* comm, const vkr_halo_peer* peers, uin
     if (p.peer < 0 || p.peer >= comm->world || p.peer == comm->rank) { vkr::set_error("halo_exchange: peer %d of rank %d / %d", p.peer, comm->rank, comm->world); return vkr::VKR_ERR_EXTENT; }
     if ((p.send_bytes && !p.send) || (p.recv_bytes && !p.recv)) { vkr::set_error("halo_exchange: peer %d has a NULL buffer", p.peer); return vkr::VKR_ERR_NULL; }
   }
+  if (comm->emulated) {  // one link per peer, full duplex: the busiest link carries max(send, recv) of that peer's messages
+    uint64_t link = 0;
+    for (int peer = 0; peer < comm->world; peer++) {
+      uint64_t out_b = 0, in_b = 0;
+      for (uint32_t i = 0; i < count; i++)
+        if (peers[i].peer == peer) { out_b += peers[i].send_bytes; in_b += peers[i].recv_bytes; }
+      const uint64_t b = out_b > in_b ? out_b : in_b;
+      if (b > link) link = b;
+    }
+    return emulate_wire(comm, link, stream, "halo_exchange (emulated)");
+  }
   // every send and receive of the surface in one group: RCCL fuses them into one launch and cannot deadlock on their order
   ncclResult_t r = g_rccl.GroupStart();
   for (uint32_t i = 0; r == ncclSuccess && i < count; i++) {
@@ -227,6 +296,7 @@ extern "C" uint64_t vkr_comm_selfcheck_bytes(int world) {
 extern "C" int vkr_comm_selfcheck(vkr_comm* comm, void* scratch, void* stream) {
   using vkr::VKR_OK;
   if (!comm || !scratch) { vkr::set_error("comm_selfcheck: NULL argument"); return vkr::VKR_ERR_NULL; }
+  if (comm->emulated) { vkr::set_error("comm_selfcheck: an emulated communicator moves no bytes"); return vkr::VKR_ERR_LAYOUT; }
   const int rank = comm->rank, world = comm->world;
   const uint64_t total = vkr_comm_selfcheck_bytes(world);
   std::vector<uint8_t> host(total, 0xEE);

@@ -108,6 +108,8 @@ def lib():
         l.vkrh_tiled_hit_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         l.vkrh_tiled_hit_rounds.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         l.vkrh_tiled_local_first.argtypes = [C.c_void_p]
+        l.vkrh_hit_capacities.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        l.vkrh_tiled_emulate_wire.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         l.vkrh_tiled_hit_errors.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         l.vkrh_tiled_time_waits.argtypes = [C.c_void_p, C.c_uint32]
         l.vkrh_tiled_wait_times.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -115,6 +117,15 @@ def lib():
         l.vkrh_balance_rows.restype = C.c_int
         _lib = l
     return _lib
+
+
+def hit_capacities(counts, world, percent=125):
+    """frame.hpp vkrh_hit_capacities: the segment room of the next frame's hit round from this frame's world x world counts"""
+    flat = (C.c_uint32 * len(counts))(*counts)
+    out = (C.c_uint32 * len(counts))()
+    if lib().vkrh_hit_capacities(flat, world, percent, out) != 0:
+        raise RuntimeError("host error: " + lib().vkrh_last_error().decode())
+    return list(out)
 
 
 def balance_rows(ms, bounds, align=16, min_rows=64):
@@ -405,6 +416,11 @@ class HostFrame:
 
     def tiled_local_first(self):
         return bool(lib().vkrh_tiled_local_first(self.tiled_handle))
+
+    def tiled_emulate_wire(self, comm_handle, counts):
+        """frame.hpp vkrh_tiled_emulate_wire: the harness-driven frame goes on natively on an emulated communicator"""
+        flat = (C.c_uint32 * len(counts))(*counts) if counts is not None else None
+        self._check(lib().vkrh_tiled_emulate_wire(self.tiled_handle, comm_handle, flat))
 
     def tiled_hit_bytes(self):
         b = C.c_uint64(0)

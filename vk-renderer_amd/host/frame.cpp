@@ -698,17 +698,36 @@ struct TiledFrame {
       hit_round(hit.host_counts, false);
       (overflow ? hit.rounds_repeated : hit.rounds_exact)++;
     }
-    // room for the next frame: last count + a quarter, in steps of 64; neighbours always keep a segment, a pair that asked for
-    // nothing and is not adjacent keeps none (if it ever asks, that frame repeats its round)
-    hit.cap_matrix.assign(w * w, 0u);
+    hit.cap_matrix.resize(w * w);
+    hit_capacities(hit.host_counts, w, hit.cap_percent, hit.cap_matrix.data());
+    hit.speculative = false;
+  }
+  // room for the next frame: last count + a quarter, in steps of 64; neighbours always keep a segment, a pair that asked for
+  // nothing and is not adjacent keeps none (if it ever asks, that frame repeats its round)
+  static void hit_capacities(const uint32_t* counts, uint32_t w, uint32_t percent, uint32_t* caps) {
     for (uint32_t r = 0; r < w; r++)
       for (uint32_t o = 0; o < w; o++) {
-        const uint32_t c = hit.host_counts[r * w + o];
+        const uint32_t c = counts[r * w + o];
         const bool adjacent = r + 1 == o || o + 1 == r;
-        if (r == o || (c == 0 && !adjacent)) continue;
-        hit.cap_matrix[r * w + o] = uint32_t((uint64_t(c) * hit.cap_percent / 100 + 63) / 64 * 64 + 64);
+        caps[r * w + o] = (r == o || (c == 0 && !adjacent)) ? 0u : uint32_t((uint64_t(c) * percent / 100 + 63) / 64 * 64 + 64);
       }
-    hit.speculative = false;
+  }
+  // Measurement (tools/wire_emulation.py): a frame that has so far been driven phase by phase by the in-process harness —
+  // which left in its receive buffers exactly what real peers send, in segments laid out by hit_capacities(counts) — goes on
+  // natively (vkrh_tiled_step) on `comm`, an emulated communicator (vkr_comm_create_emulated): the exchanges take their
+  // time on the exchange stream and deliver what is already there.  `counts` is the world x world matrix of that last frame.
+  void emulate_wire(void* comm, const uint32_t* counts) {
+    if (!tiled || cfg.world < 2 || !comm || cfg.comm) throw std::runtime_error {"vkrh_tiled_emulate_wire: needs a harness-driven frame of several ranks and a communicator"};
+    check(hipStreamSynchronize(compute), "synchronize");
+    cfg.comm = (vkr_comm*)comm;
+    if (by_request()) {
+      if (!counts) throw std::runtime_error {"vkrh_tiled_emulate_wire: the counts of the last frame are needed (hit colours by request)"};
+      const uint32_t w = cfg.world;
+      check(hipMemcpy(hit.counts + HIT_MATRIX, counts, sizeof(uint32_t) * w * w, hipMemcpyHostToDevice), "counts");
+      hit.cap_matrix.resize(w * w);
+      hit_capacities(counts, w, hit.cap_percent, hit.cap_matrix.data());
+      hit.speculative = false; hit_pending = false; hit.counted = false;
+    }
   }
   static constexpr uint32_t HIT_PEERS = 16;
   static constexpr uint32_t HIT_ERRORS = 32, HIT_DROPPED = 40, HIT_MATRIX = 64, HIT_WORDS = 64 + 256;  // world <= 16; [0, HIT_MATRIX) is cleared by every count
@@ -1149,6 +1168,15 @@ int vkrh_tiled_hit_rounds(void* tiled, uint64_t* rounds3) {
     const auto& h = ((TiledFrame*)tiled)->hit;
     rounds3[0] = h.rounds_speculative; rounds3[1] = h.rounds_exact; rounds3[2] = h.rounds_repeated;
   });
+}
+int vkrh_hit_capacities(const uint32_t* counts, uint32_t world, uint32_t percent, uint32_t* capacities) {
+  return guarded([&] {
+    if (!counts || !capacities || world == 0 || world > 16 || percent == 0) throw std::runtime_error{"vkrh_hit_capacities: bad arguments"};
+    TiledFrame::hit_capacities(counts, world, percent, capacities);
+  });
+}
+int vkrh_tiled_emulate_wire(void* tiled, void* comm, const uint32_t* counts) {
+  return guarded([&] { tiled_ref(tiled, "vkrh_tiled_emulate_wire").emulate_wire(comm, counts); });
 }
 int vkrh_tiled_local_first(void* tiled) { return tiled && ((TiledFrame*)tiled)->local_first() ? 1 : 0; }
 int vkrh_tiled_time_waits(void* tiled, uint32_t on) {

@@ -191,6 +191,15 @@ int   vkrh_tiled_hit_bytes(void* tiled, uint64_t* bytes);
 /* native wire: how the hit-colour rounds of the frames so far went — [0] enqueued on the previous frame's capacities (no host
  * round trip), [1] exact rounds after the host had the counts (first frame), [2] rounds repeated because a segment overflowed */
 int   vkrh_tiled_hit_rounds(void* tiled, uint64_t* rounds3);
+/* The room of every rank-to-owner segment of the NEXT frame's hit round, from this frame's world x world counts (what every
+ * rank derives for itself): count * percent / 100 + 64 in steps of 64; adjacent strips always keep a segment, a distant pair that
+ * asked for nothing keeps none.                                                                                          */
+int   vkrh_hit_capacities(const uint32_t* counts, uint32_t world, uint32_t percent, uint32_t* capacities);
+/* Measurement (tools/wire_emulation.py): a frame of several ranks that the in-process harness has driven so far (comm NULL) —
+ * its receive buffers hold what real peers send, the hit segments laid out by vkrh_hit_capacities(counts) — continues natively
+ * (vkrh_tiled_step) on `comm`, made by vkr_comm_create_emulated: every exchange holds the exchange stream for its wire time and
+ * delivers what is already there.  With a static scene that is what the peers would send again.                             */
+int   vkrh_tiled_emulate_wire(void* tiled, void* comm, const uint32_t* counts);
 /* 1: the trace runs in two stages around the depth all-gather (VKRH_STAGE_SSR_TRACE_HEAD / _RESUME) and the TAA after GTAO */
 int   vkrh_tiled_local_first(void* tiled);
 /* requests of the last frame that this rank could not answer from its window (0 unless the ranks' strips disagree); synchronises */

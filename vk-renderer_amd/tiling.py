@@ -614,18 +614,26 @@ def _move_p2p(ranks, lists):
             _bytes_at(ranks, recv, recv_bytes).copy_(_bytes_at(ranks, send[0][1], recv_bytes))
 
 
-def _hit_exchange(ranks):
-    """the hit-colour request / reply of frame.hpp between in-process ranks: counts -> requests -> replies -> scatter"""
+def _hit_exchange(ranks, in_capacities=False):
+    """the hit-colour request / reply of frame.hpp between in-process ranks: counts -> requests -> replies -> scatter.
+    in_capacities: the segments are laid out by host.hit_capacities(counts) — the room the native frame gives them when it
+    enqueues the round on the previous frame's counts — instead of by the exact counts (unused slots say "no request")."""
     world = len(ranks)
     matrix = [c for t in ranks for c in t.frame.tiled_hit_counts(world)]
-    _move_p2p(ranks, [t.frame.tiled_hit_requests(matrix) for t in ranks])
+    if in_capacities:
+        from . import host
+
+        layout = host.hit_capacities(matrix, world)
+    else:
+        layout = matrix
+    _move_p2p(ranks, [t.frame.tiled_hit_requests(layout) for t in ranks])
     _move_p2p(ranks, [t.frame.tiled_hit_replies() for t in ranks])
     for t in ranks:
         t.frame.tiled_hit_finish()
     return matrix
 
 
-def native_lockstep_frame(ranks):
+def native_lockstep_frame(ranks, hit_in_capacities=False):
     """One frame of every in-process rank of a strip grid (C++ tiled frames made with native=True, comm=None), advanced
     phase by phase; between phases the harness copies exactly the buffers the RCCL calls would move."""
     by_gather = ranks[0].frame.albedo_by_gather or len(ranks) == 1
@@ -644,7 +652,7 @@ def native_lockstep_frame(ranks):
                 _move_halo(ranks, 0)
             _move_halo(ranks, 1)
             if not by_gather:
-                ranks[0].hit_matrix = _hit_exchange(ranks)
+                ranks[0].hit_matrix = _hit_exchange(ranks, hit_in_capacities)
         elif p == 4:
             _move_halo(ranks, 2)
     for t in ranks:
