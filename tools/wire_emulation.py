@@ -11,6 +11,8 @@ moves nothing.  Measured: ms per frame of each rank with everything the schedule
 compute stream stood still for each exchange.  The frame of the N-GPU job takes the slowest rank's time.
 
     python tools/wire_emulation.py --world 8 --frame 15360x8640 --link-gbps 60 45 [--bounds-from profiles/r04_final_strip_balance_c4.json]
+
+(one child process per rank; the parent never touches the GPU)
 """
 import argparse
 import json
@@ -29,8 +31,11 @@ from vk_renderer_amd.camera import FrameSetup  # noqa: E402
 from vk_renderer_amd.tiling import TiledFrame, native_lockstep_frame  # noqa: E402
 
 
-def prepared_ranks(W, H, world, bounds, device, warm):
-    ranks = [TiledFrame(FrameSetup(W, H), r, world, 1, world, device, native=True, comm=None, row_bounds=bounds) for r in range(world)]
+def prepared_ranks(W, H, world, bounds, device, warm, first=None):
+    # (`first`: the rank whose frame — images, streams, events — is made before the others')
+    order = list(range(world)) if first is None else [first] + [r for r in range(world) if r != first]
+    made = {r: TiledFrame(FrameSetup(W, H), r, world, 1, world, device, native=True, comm=None, row_bounds=bounds) for r in order}
+    ranks = [made[r] for r in range(world)]
     for t in ranks:
         t.prepare()
     # the SSR frame counter (frame_random, advanced_ssr.cpp:168-171) is pinned before every frame: every frame then traces the same
@@ -56,11 +61,18 @@ def steps_of(t, n):
     t.frame.tiled_flush()
 
 
-def measure(W, H, world, bounds, device, gbps, launch_us, steps, warm):
-    ranks = prepared_ranks(W, H, world, bounds, device, warm)
+def measure_rank(W, H, world, bounds, device, r, rates, launch_us, steps, warm, per_frame=False):
+    """rank r of the decomposition, its frame made first in this process (with eight frames in one process the ones made
+    fourth and fifth ran every small kernel ten times slower — an artefact of that set-up, not of the rank: made first they
+    are as fast as the others; on a node every process holds one rank)"""
+    ranks = prepared_ranks(W, H, world, bounds, device, warm, r)
     counts = ranks[0].hit_matrix
+    for q, t in enumerate(ranks):
+        if q != r:
+            t.frame.close()
+    t = ranks[r]
     out = []
-    for r, t in enumerate(ranks):
+    for gbps in rates:
         comm = abi.Comm.emulated(r, world, gbps, launch_us)
         t.frame.tiled_emulate_wire(comm.handle, counts)
         steps_of(t, 3)
@@ -73,12 +85,17 @@ def measure(W, H, world, bounds, device, gbps, launch_us, steps, warm):
         steps_of(t, steps)
         waits = {k: v / steps for k, v in t.frame.tiled_wait_times().items()}
         t.frame.tiled_time_waits(False)
-        rounds = list(t.frame.tiled_hit_rounds())
-        errors = t.frame.tiled_hit_errors()
-        out.append({"rank": r, "rows": t.th, "ms_per_frame": ms, "exposed_wait_ms": waits, "hit_rounds": rounds, "hit_errors": errors})
-        print(f"  rank {r} ({t.th} rows): {ms:.3f} ms per frame, exposed " + " ".join(f"{k} {v:.3f}" for k, v in waits.items()) + f", rounds {rounds}", file=sys.stderr)
-        t.frame.close()
-        comm.close()
+        tasks = None
+        if per_frame:  # what the nine passes themselves take on this schedule (HIP events around every task)
+            t.frame.enable_task_timing(True)
+            steps_of(t, steps)
+            torch.cuda.synchronize()
+            tasks = {k: v[0] / steps for k, v in t.frame.collect_task_times().items()}
+            t.frame.enable_task_timing(False)
+        out.append({"rank": r, "rows": t.th, "link_gbps": gbps, "ms_per_frame": ms, "exposed_wait_ms": waits, "hit_rounds": list(t.frame.tiled_hit_rounds()),
+                    "hit_errors": t.frame.tiled_hit_errors(), "task_ms": tasks})
+        print(f"  rank {r} ({t.th} rows) at {gbps:g} GB/s: {ms:.3f} ms per frame, exposed " + " ".join(f"{k} {v:.3f}" for k, v in waits.items()), file=sys.stderr)
+    t.frame.close()
     return out
 
 
@@ -92,6 +109,8 @@ def main():
     ap.add_argument("--warm", type=int, default=2)
     ap.add_argument("--bounds-from", default=None, help="a tools/lockstep_profile.py JSON: the strips of its last balancing pass")
     ap.add_argument("--one-gpu-ms", type=float, default=None, help="ms per frame of the same frame on one GPU (for the speed-up column)")
+    ap.add_argument("--rank", type=int, default=None, help="(child) measure this rank and print its JSON")
+    ap.add_argument("--task-times", action="store_true", help="also the per-pass times on the native schedule")
     args = ap.parse_args()
     W, H = (int(v) for v in args.frame.split("x"))
     world = args.world
@@ -100,16 +119,30 @@ def main():
         with open(args.bounds_from) as f:
             bounds = json.load(f)["passes"][-1]["bounds"]
         assert len(bounds) == world + 1
-    device = torch.device("cuda", 0)
+    if args.rank is not None:  # child: one rank, every link rate
+        device = torch.device("cuda", 0)
+        print(json.dumps(measure_rank(W, H, world, bounds, device, args.rank, args.link_gbps, args.launch_us, args.steps, args.warm, args.task_times)))
+        return
+    # parent: one child process per rank (this process never touches the GPU)
+    import subprocess
+
+    per_rank = []
+    for r in range(world):
+        cmd = [sys.executable, os.path.abspath(__file__), "--rank", str(r)] + [a for a in sys.argv[1:]]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        sys.stderr.write("".join(l for l in p.stderr.splitlines(True) if l.startswith("  rank")))
+        if p.returncode != 0:
+            sys.stderr.write(p.stderr[-3000:])
+            raise SystemExit(f"rank {r}: the child exited {p.returncode}")
+        per_rank.append(json.loads(p.stdout.strip().splitlines()[-1]))
     result = {"frame": [W, H], "world": world, "bounds": bounds, "launch_us": args.launch_us, "runs": []}
-    for gbps in args.link_gbps:
-        print(f"link {gbps:g} GB/s per direction:", file=sys.stderr)
-        ranks = measure(W, H, world, bounds, device, gbps, args.launch_us, args.steps, args.warm)
+    for i, gbps in enumerate(args.link_gbps):
+        ranks = [x[i] for x in per_rank]
         slowest = max(x["ms_per_frame"] for x in ranks)
-        run = {"link_gbps": gbps, "ranks": ranks, "frame_ms": slowest}
+        run = {"link_gbps": gbps, "ranks": ranks, "frame_ms": slowest, "mean_rank_ms": sum(x["ms_per_frame"] for x in ranks) / world}
         if args.one_gpu_ms:
             run["speedup_vs_one_gpu"] = args.one_gpu_ms / slowest
-        print(f"  frame {slowest:.3f} ms" + (f" = {args.one_gpu_ms / slowest:.2f} x" if args.one_gpu_ms else ""), file=sys.stderr)
+        print(f"link {gbps:g} GB/s: frame {slowest:.3f} ms (slowest rank), mean rank {run['mean_rank_ms']:.3f}" + (f" = {args.one_gpu_ms / slowest:.2f} x" if args.one_gpu_ms else ""), file=sys.stderr)
         result["runs"].append(run)
     print(json.dumps(result))
 

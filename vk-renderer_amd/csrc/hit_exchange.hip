@@ -53,7 +53,7 @@ static_assert(HIT_BLOCKS * HIT_MAX_WORLD == VKR_HIT_WORKSPACE_WORDS, "the worksp
 #define HIT_BATCH 4
 #define HIT_TILE_H 16
 struct HitTile { int tiles_x, tiles_y; };  // tiles of the window plus one apron row of tiles (see hit_emit)
-struct HitRay { uint2 v; uint32_t pending; int lx, ly; bool inside, apron; };
+struct HitRay { uint2 v; uint32_t pending; int lx, ly; bool inside, apron; float2 hit_uv; };  // hit_uv: of a pending ray (pending data, texel 1)
 
 VKR_DEV HitRay hit_load(const HitReqArgs& a, const HitTile& g, int tile, int tid) {
   HitRay r;
@@ -99,7 +99,7 @@ VKR_DEV int hit_emit(const HitReqArgs& a, const HitRay& r, uint32_t* code, uint3
   }
   if (r.pending != 0u) {
     // texture(normal, hit uv) of the deferred test: sample<FmtRG16U>() on the half-res frame, the uv as the trace had it
-    const float4 hv = texel_ptr<float4>(a.pend_data, 2 * r.lx, r.ly)[1];
+    const float2 hv = r.hit_uv;
     const float fx = cfma(hv.x, (float)a.nw, -0.5f), fy = cfma(hv.y, (float)a.nh, -0.5f);
     const int x0 = f2i(floorf(fx)), y0 = f2i(floorf(fy));
     emit((uint32_t)iclamp(y0, 0, a.nh - 1), (uint32_t)iclamp(y0 + 1, 0, a.nh - 1), (uint32_t)iclamp(x0, 0, a.nw - 2), a.nrow0, a.nrow1, VKR_HIT_NORMAL, 1u);
@@ -131,6 +131,13 @@ __global__ __launch_bounds__(1024) void k_hit_requests(HitReqArgs a, HitTile g) 
     HitRay r[HIT_BATCH];
 #pragma unroll
     for (int j = 0; j < HIT_BATCH; j++) r[j] = hit_load(a, g, first + j * gridDim.x, tid);
+    // second batch of loads, all in flight together: the hit uv of the pending rays (a load per ray inside the loop below would
+    // put up to HIT_BATCH more memory round trips on every pass over the tiles)
+#pragma unroll
+    for (int j = 0; j < HIT_BATCH; j++) {
+      r[j].hit_uv = make_float2(0.0f, 0.0f);
+      if (r[j].pending != 0u) r[j].hit_uv = *(const float2*)(texel_ptr<float4>(a.pend_data, 2 * r[j].lx, r[j].ly) + 1);
+    }
 #pragma unroll
     for (int j = 0; j < HIT_BATCH; j++) {
       const int n = hit_emit(a, r[j], code, owner);
@@ -138,6 +145,7 @@ __global__ __launch_bounds__(1024) void k_hit_requests(HitReqArgs a, HitTile g) 
         for (int k = 0; k < n; k++) atomicAdd(&s_n[owner[k]], 1u);
         continue;
       }
+      if (__syncthreads_or(n) == 0) continue;  // (most tiles ask for nothing: one barrier instead of the bookkeeping below)
       // Pass 2 hands out the slots of a segment in a FIXED order — tile, wave, request k of the ray, lane — so that the same
       // rays always produce the same bytes on the wire (a frame can be replayed; two runs can be compared request by request).
       // Per tile: every wave counts its requests per owner (ballots), then takes its range behind the waves before it.
@@ -151,9 +159,16 @@ __global__ __launch_bounds__(1024) void k_hit_requests(HitReqArgs a, HitTile g) 
       uint32_t total = 0u;  // (thread o: what the whole block adds to owner o with this tile)
       if (tid < (int)a.world)
         for (int w = 0; w < 16; w++) total += s_wcnt[w][tid];
+      // lane o of every wave: where owner o's requests of this wave start (the segment's base, what the block has written so far,
+      // the waves before this one)
+      uint32_t my_at = 0u;
+      if ((tid & 63) < (int)a.world) {
+        const int o = tid & 63;
+        my_at = s_base[o] + s_n[o];
+        for (int w = 0; w < wave; w++) my_at += s_wcnt[w][o];
+      }
       for (uint32_t o = 0; o < a.world; o++) {
-        uint32_t at = s_base[o] + s_n[o];
-        for (int w = 0; w < wave; w++) at += s_wcnt[w][o];
+        uint32_t at = (uint32_t)__shfl((int)my_at, (int)o);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const bool mine = k < n && owner[k] == o;

@@ -717,9 +717,12 @@ struct TiledFrame {
   // natively (vkrh_tiled_step) on `comm`, an emulated communicator (vkr_comm_create_emulated): the exchanges take their
   // time on the exchange stream and deliver what is already there.  `counts` is the world x world matrix of that last frame.
   void emulate_wire(void* comm, const uint32_t* counts) {
-    if (!tiled || cfg.world < 2 || !comm || cfg.comm) throw std::runtime_error {"vkrh_tiled_emulate_wire: needs a harness-driven frame of several ranks and a communicator"};
+    if (!tiled || cfg.world < 2 || !comm) throw std::runtime_error {"vkrh_tiled_emulate_wire: needs a harness-driven frame of several ranks and a communicator"};
     check(hipStreamSynchronize(compute), "synchronize");
+    if (xchg) check(hipStreamSynchronize(xchg), "synchronize");
+    const bool again = cfg.comm != nullptr;  // a second call only swaps the communicator (another link rate): the frame's state stays
     cfg.comm = (vkr_comm*)comm;
+    if (again) { flush(); check(hipStreamSynchronize(compute), "synchronize"); return; }
     if (by_request()) {
       if (!counts) throw std::runtime_error {"vkrh_tiled_emulate_wire: the counts of the last frame are needed (hit colours by request)"};
       const uint32_t w = cfg.world;

@@ -198,7 +198,8 @@ int   vkrh_hit_capacities(const uint32_t* counts, uint32_t world, uint32_t perce
 /* Measurement (tools/wire_emulation.py): a frame of several ranks that the in-process harness has driven so far (comm NULL) —
  * its receive buffers hold what real peers send, the hit segments laid out by vkrh_hit_capacities(counts) — continues natively
  * (vkrh_tiled_step) on `comm`, made by vkr_comm_create_emulated: every exchange holds the exchange stream for its wire time and
- * delivers what is already there.  With a static scene that is what the peers would send again.                             */
+ * delivers what is already there.  With a static scene that is what the peers would send again.  A second call swaps the
+ * communicator (another link rate; counts ignored).                                                                          */
 int   vkrh_tiled_emulate_wire(void* tiled, void* comm, const uint32_t* counts);
 /* 1: the trace runs in two stages around the depth all-gather (VKRH_STAGE_SSR_TRACE_HEAD / _RESUME) and the TAA after GTAO */
 int   vkrh_tiled_local_first(void* tiled);
