@@ -23,6 +23,9 @@ import time
 # ROCr reads HSA_* once, at hsa_init: this must be in the environment before anything touches the GPU
 # (the host driver only supports dmabuf IPC; without it RCCL fails with hipIpcGetMemHandle: invalid argument).
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# N > 1: two frames in flight (host/frame.cpp pipelined_step; VKR_TILED_PIPELINE=0 restores the one-frame order).  The synthetic
+# G-buffer is static, which is what the mode needs: the next frame's G-buffer resident when this frame's trace has run.
+os.environ.setdefault("VKR_TILED_PIPELINE", "1")
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     # one node: let RCCL bootstrap over the loopback interface (the container's hostname may not resolve, and by default
     # NCCL skips `lo` unless it is named); a launcher that knows better sets the variable itself
@@ -554,7 +557,10 @@ def main():
             "hit_rounds": list(frame.tiled_hit_rounds()) if (tiled.native and frame.tiled_handle is not None and comm is not None and not frame.albedo_by_gather) else None,
             "tiled_options": {"gather_mode": frame.gather_mode, "all_gather_v": "broadcast" if os.environ.get("VKR_GATHER_V_BROADCAST") == "1" else "point-to-point",
                               "trace_local_rows_first": frame.tiled_local_first(),
-                              "rows_computed": "whole window" if os.environ.get("VKR_TILED_WHOLE_WINDOW", "0") not in ("", "0") else "the rows that are read"} if (tiled.native and frame.tiled_handle is not None) else None,
+                              "rows_computed": "whole window" if os.environ.get("VKR_TILED_WHOLE_WINDOW", "0") not in ("", "0") else "the rows that are read",
+                              # 2: the next frame's downsample and depth all-gather start right after this frame's trace (host/frame.cpp:
+                              # pipelined_step; the benchmark's G-buffer is static, so the next frame's is resident); every step runs every pass once
+                              "frames_in_flight": 2 if frame.tiled_pipelined() else 1} if (tiled.native and frame.tiled_handle is not None) else None,
             "measured_read_gbps": measured_read,
         }
         if noskip_ms is not None:

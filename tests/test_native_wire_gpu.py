@@ -191,6 +191,10 @@ def _wire_log(path, world):
     # of round 4 was killed by the guard with seven counted; no case here needs more than four ranks.
     ([0, 160, 368, 592], True, 3, False),
     ([0, 160, 320, 480], True, 4, "overflow"),     # segments sized at 30 % of the previous frame's counts: every later frame overflows and repeats its round exactly
+    # two frames in flight (VKR_TILED_PIPELINE=1; the camera stands still: the next frame's G-buffer must be resident early): the
+    # next frame's downsample and depth gather start right after this frame's trace, the TAA runs behind GTAO — same images
+    ([0, 96, 168, 304, 480], False, 4, "pipelined"),
+    ([0, 160, 320], False, 3, "pipelined"),
 ])
 def test_native_tiled_frame_between_real_processes(bounds, moving, frames, by_broadcast, tmp_path):
     world = len(bounds) - 1
@@ -201,6 +205,9 @@ def test_native_tiled_frame_between_real_processes(bounds, moving, frames, by_br
                VKR_MOVING="1" if moving else "0", VKR_FRAMES=str(frames), HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("VKR_GATHER_V_BROADCAST", None)
     env.pop("VKR_HIT_CAP_PERCENT", None)
+    env["VKR_TILED_PIPELINE"] = "1" if by_broadcast == "pipelined" else "0"
+    if by_broadcast == "pipelined":
+        by_broadcast = False
     env["VKR_TILED_LOCAL_FIRST"] = "1" if (world == 4 and moving) else "0"  # one case runs the trace in two stages around the gather
     if by_broadcast == "overflow":
         env["VKR_HIT_CAP_PERCENT"] = "30"

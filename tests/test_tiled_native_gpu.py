@@ -199,7 +199,8 @@ def test_one_rank_without_force_tiled_has_no_phases():
     b.frame.close()
 
 
-def test_native_frame_on_an_emulated_wire_receives_what_its_peers_would_send():
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_native_frame_on_an_emulated_wire_receives_what_its_peers_would_send(pipelined, monkeypatch):
     """tools/wire_emulation.py in small: three ranks are driven in lockstep with real data (the SSR frame counter pinned, so every
     frame asks for the same hit texels; the last frame's hit segments in the native layout, host.hit_capacities), then every rank
     goes on NATIVELY — its own exchange stream, events, the hit round enqueued on the previous frame's counts — on an emulated
@@ -207,8 +208,12 @@ def test_native_frame_on_an_emulated_wire_receives_what_its_peers_would_send():
     a history produce (rays, raw, reflections, filtered) must still be the plain frame's, bit for bit: the stale receive buffers
     are what the peers would send — vkr_hit_requests hands out the slots of a segment in a fixed order, so this frame's requests
     sit where the replies of the last lockstep frame answer them —, no request names a texel its owner does not hold, every
-    round goes out on the seeded capacities, and nothing runs ahead of the exchange it needs."""
+    round goes out on the seeded capacities, and nothing runs ahead of the exchange it needs.
+    pipelined (VKR_TILED_PIPELINE=1): two frames in flight — the next frame's downsample (into the G-buffer's second set) and depth
+    all-gather start right after this frame's trace, the TAA runs behind GTAO (host/frame.cpp: pipelined_step); same images."""
     import torch
+
+    monkeypatch.setenv("VKR_TILED_PIPELINE", "1" if pipelined else "0")
 
     from vk_renderer_amd import abi
     from vk_renderer_amd.camera import FrameSetup
@@ -239,6 +244,7 @@ def test_native_frame_on_an_emulated_wire_receives_what_its_peers_would_send():
     bad = 0
     for r, t in enumerate(ranks):
         comm = abi.Comm.emulated(r, world, 60.0, 5.0)
+        assert t.frame.tiled_pipelined() == pipelined
         t.frame.tiled_emulate_wire(comm.handle, counts)
         for _ in range(3):
             t.frame.pin_randoms(0.0, 0, 0)

@@ -92,7 +92,7 @@ def measure_rank(W, H, world, bounds, device, r, rates, launch_us, steps, warm, 
             torch.cuda.synchronize()
             tasks = {k: v[0] / steps for k, v in t.frame.collect_task_times().items()}
             t.frame.enable_task_timing(False)
-        out.append({"rank": r, "rows": t.th, "link_gbps": gbps, "ms_per_frame": ms, "exposed_wait_ms": waits, "hit_rounds": list(t.frame.tiled_hit_rounds()),
+        out.append({"rank": r, "rows": t.th, "link_gbps": gbps, "pipelined": t.frame.tiled_pipelined(), "ms_per_frame": ms, "exposed_wait_ms": waits, "hit_rounds": list(t.frame.tiled_hit_rounds()),
                     "hit_errors": t.frame.tiled_hit_errors(), "task_ms": tasks})
         print(f"  rank {r} ({t.th} rows) at {gbps:g} GB/s: {ms:.3f} ms per frame, exposed " + " ".join(f"{k} {v:.3f}" for k, v in waits.items()), file=sys.stderr)
     t.frame.close()

@@ -414,6 +414,10 @@ class HostFrame:
         self._check(lib().vkrh_tiled_hit_rounds(self.tiled_handle, r))
         return int(r[0]), int(r[1]), int(r[2])
 
+    def tiled_pipelined(self):
+        lib().vkrh_tiled_pipelined.argtypes = [C.c_void_p]
+        return bool(lib().vkrh_tiled_pipelined(self.tiled_handle))
+
     def tiled_local_first(self):
         return bool(lib().vkrh_tiled_local_first(self.tiled_handle))
 

@@ -110,6 +110,11 @@ struct PostFxFrame {
     if (mask & VKRH_STAGE_DOWNSAMPLE)  // main.cpp:347
       downsample_pass.run(graph, gbuffer.normal, gbuffer.velocity_vectors, gbuffer.depth, gbuffer.downsampled_normals,
                           gbuffer.downsampled_velocity_vectors);
+    if (mask & VKRH_STAGE_DOWNSAMPLE_NEXT) {
+      if (!gbuffer.pipelined) throw std::runtime_error{"vkrh_run: VKRH_STAGE_DOWNSAMPLE_NEXT without the G-buffer's second set"};
+      downsample_pass.run(graph, gbuffer.normal, gbuffer.velocity_vectors, gbuffer.depth_next, gbuffer.downsampled_normals_next,
+                          gbuffer.downsampled_velocity_vectors_next);
+    }
     if ((mask & VKRH_STAGE_HIZ_TAIL) && gbuffer.tiled) {
       // the launcher gathered whole-frame mips 0..k of frame_hiz; finish the chain locally
       downsample_pass.run_downsample_depth(graph, gbuffer.frame_hiz, hiz_gathered_mips - 1);
@@ -159,10 +164,19 @@ struct PostFxFrame {
     }
     if (mask & VKRH_STAGE_TAA) taa_pass.run(graph, gbuffer, (mask & VKRH_STAGE_SHADING) ? color_out_tex : gbuffer.albedo, draw_params);
     graph.submit();
+    if ((mask & (VKRH_STAGE_GBUFFER | VKRH_STAGE_RASTER)) && gbuffer.pipelined) copy_depth_to_next_set();
     task_names.clear();
     for (const auto& n : graph.last_submitted_tasks()) { task_names += n; task_names += '\n'; }
     task_lanes.clear();
     for (uint32_t l : graph.last_submitted_lanes()) { task_lanes += std::to_string(l); task_lanes += ' '; }
+  }
+
+  // pipelined: the G-buffer's depth (mip 0 of the depth image) also into the second set — the G-buffer of the benchmark is one
+  // static frame; a renderer with two frames in flight draws every frame's depth into the set that frame will use
+  void copy_depth_to_next_set() {
+    const vkr_img a = graph.get_image(gbuffer.depth)->describe(0, 1), b = graph.get_image(gbuffer.depth_next)->describe(0, 1);
+    if (hipMemcpy2DAsync(b.base, b.pitch_bytes[0], a.base, a.pitch_bytes[0], size_t(a.width) * 4, a.height, hipMemcpyDeviceToDevice, (hipStream_t)cfg.stream) != hipSuccess)
+      throw std::runtime_error{"pipelined frame: copy of the depth into the second set failed"};
   }
 
   // TraceParams as run() hands them to the SSR passes (main.cpp:368-373), for the tiled frame's deferred hit-normal test
@@ -266,6 +280,10 @@ struct TiledFrame {
     frame->hiz_gathered_mips = tiled ? k : 4;
     if (normals_by_request()) frame->gbuffer.enable_normal_requests(frame->graph, wy0 / 2, (wy0 + wh) / 2);
     if (tiled && c.world > 1 && !env_set("VKR_TILED_WHOLE_WINDOW")) clip_outputs();
+    // Two frames in flight (VKR_TILED_PIPELINE=1, native wire, hit colours by request): the next frame's downsample and depth
+    // all-gather start right after this frame's trace and travel while its GTAO, TAA, resolve and blur run (pipelined_step).
+    pipeline_enabled = tiled && c.world > 1 && by_request() && env_set("VKR_TILED_PIPELINE");
+    if (pipeline_enabled) frame->gbuffer.enable_pipelining(frame->graph);
     if (tiled) {
       // the exchanges' kernels (a few workgroups each) must not queue behind a frame's worth of compute waves
       int prio_low = 0, prio_high = 0;
@@ -284,6 +302,7 @@ struct TiledFrame {
         }
     }
   }
+  bool pipeline_enabled = false, primed = false;
   static bool env_set(const char* name) { const char* v = getenv(name); return v && *v && *v != '0'; }
   // Which rows of its window a rank has to COMPUTE (gpu::Image::set_store_rows; VKR_TILED_WHOLE_WINDOW=1 keeps round 3's "every
   // pass on the whole window").  The three history surfaces and the filtered AO: the strip itself — the halo rows of a history
@@ -370,7 +389,7 @@ struct TiledFrame {
   }
   // A strip's rows of a whole-frame surface are contiguous in the window image AND in the frame image (same width, same
   // pitch), so every surface is gathered in place: send = the tile's rows where they lie, recv = the frame image.
-  uint32_t gather_parts(int which, vkr_gather_part* out) {
+  uint32_t gather_parts(int which, vkr_gather_part* out, bool next_set = false) {
     auto& offs = gather_offsets[which];
     offs.clear();
     auto part = [&](rendergraph::ImageResourceId src, uint32_t src_mip, rendergraph::ImageResourceId dst, uint32_t dst_mip, uint32_t dv) {
@@ -386,9 +405,9 @@ struct TiledFrame {
     };
     uint32_t n = 0;
     auto& g = frame->gbuffer;
-    if (which == VKRH_GATHER_HIZ) {
-      for (uint32_t m = 1; m <= cfg.gathered_mips; m++) out[n++] = part(g.depth, m, g.frame_hiz, m - 1, m);
-      if (!normals_by_request()) out[n++] = part(g.downsampled_normals, 0, g.frame_normals, 0, 1);
+    if (which == VKRH_GATHER_HIZ) {  // (next_set: what the pipelined frame has just downsampled for the frame after this one)
+      for (uint32_t m = 1; m <= cfg.gathered_mips; m++) out[n++] = part(next_set ? g.depth_next : g.depth, m, g.frame_hiz, m - 1, m);
+      if (!normals_by_request()) out[n++] = part(next_set ? g.downsampled_normals_next : g.downsampled_normals, 0, g.frame_normals, 0, 1);
     } else {
       out[n++] = part(g.albedo, 0, g.frame_albedo, 0, 0);
     }
@@ -435,11 +454,11 @@ struct TiledFrame {
       wait_marks[s].clear();
     }
   }
-  void start_gather(int which) {
+  void start_gather(int which, bool next_set = false) {
     gpu::TraceRange range {which == VKRH_GATHER_HIZ ? "all-gather Hi-Z" : "all-gather albedo"};
     start(which, [&] {
       vkr_gather_part p[8];
-      const uint32_t n = gather_parts(which, p);
+      const uint32_t n = gather_parts(which, p, next_set);
       if (uniform) return vkr_all_gather(cfg.comm, p, n, xchg);
       vkr_gather_v_part v[8];  // strips of different heights: every share at its own offset of the frame image
       for (uint32_t i = 0; i < n; i++) v[i] = vkr_gather_v_part {p[i].send, p[i].recv, gather_offsets[which][i].data()};
@@ -795,9 +814,46 @@ struct TiledFrame {
     copy_halo(VKRH_HALO_TAA, true);
     start_halo(VKRH_HALO_TAA);
   }
+  // Two frames in flight.  The depth pyramid is the one surface every rank needs whole, its all-gather the longest exchange of
+  // the frame, and in the plain order only the TAA runs between the downsample that produces it and the trace that needs it.
+  // Here the downsample of frame f + 1 (into the G-buffer's second set) and its all-gather start right after the trace of
+  // frame f — the last reader of the whole-frame pyramid — and travel while GTAO, TAA, resolve and blur of frame f run; the TAA
+  // moves behind GTAO, where it covers the hit-colour round.  Every step still runs every pass once.  Needs the next frame's
+  // G-buffer to be resident when this frame's trace has run (the benchmark's is static; a renderer double-buffers it).
+  void pipelined_step() {
+    PostFxFrame& f = *frame;
+    if (!primed) {  // the first frame's own downsample and gather
+      f.run(VKRH_STAGE_DOWNSAMPLE_NEXT);
+      start_gather(VKRH_GATHER_HIZ, true);
+      f.gbuffer.swap_sets(f.graph);
+      hit_local_rows(compute);
+      primed = true;
+    }
+    wait(VKRH_GATHER_HIZ);
+    f.run(VKRH_STAGE_HIZ_TAIL | VKRH_STAGE_SSR_TRACE);
+    hit_exchange_native();
+    f.run(VKRH_STAGE_DOWNSAMPLE_NEXT);          // frame f + 1
+    start_gather(VKRH_GATHER_HIZ, true);
+    finish_halo(VKRH_HALO_AO);
+    f.run(VKRH_STAGE_GTAO);
+    if (!hit.speculative) hit_exchange_complete();  // first frame: the host round trip, with GTAO queued
+    copy_halo(VKRH_HALO_AO, true);
+    start_halo(VKRH_HALO_AO);
+    taa_and_halo();
+    hit_exchange_complete();
+    wait(VKRH_GATHER_ALBEDO);
+    finish_halo(VKRH_HALO_SSR);
+    f.run(VKRH_STAGE_SSR_RESOLVE);
+    copy_halo(VKRH_HALO_SSR, true);
+    start_halo(VKRH_HALO_SSR);
+    f.end_frame(false);
+    f.gbuffer.swap_sets(f.graph);               // what was downsampled for frame f + 1 becomes the current set
+    hit_local_rows(compute);                    // its own rows of the whole-frame albedo / normals (after this frame's resolve has read them)
+  }
   void step() {
     if (!tiled) { frame->run(VKRH_STAGE_CHAIN); frame->end_frame(false); return; }
     if (!cfg.comm && cfg.world > 1) throw std::runtime_error {"vkrh_tiled_step: no communicator (drive vkrh_tiled_phase from a harness instead)"};
+    if (pipeline_enabled && cfg.comm) { pipelined_step(); return; }
     if (!cfg.comm) {  // one rank, no wire: the gathers degenerate to copies of the tile into the frame images
       for (uint32_t p = 0; p < VKRH_TILED_PHASES; p++) {
         if (p == 2) local_gather(VKRH_GATHER_HIZ);
@@ -1181,6 +1237,7 @@ int vkrh_hit_capacities(const uint32_t* counts, uint32_t world, uint32_t percent
 int vkrh_tiled_emulate_wire(void* tiled, void* comm, const uint32_t* counts) {
   return guarded([&] { tiled_ref(tiled, "vkrh_tiled_emulate_wire").emulate_wire(comm, counts); });
 }
+int vkrh_tiled_pipelined(void* tiled) { return tiled && ((TiledFrame*)tiled)->pipeline_enabled ? 1 : 0; }
 int vkrh_tiled_local_first(void* tiled) { return tiled && ((TiledFrame*)tiled)->local_first() ? 1 : 0; }
 int vkrh_tiled_time_waits(void* tiled, uint32_t on) {
   return guarded([&] {

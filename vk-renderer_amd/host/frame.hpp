@@ -50,6 +50,7 @@ enum {
    * pyramid (after VKRH_STAGE_HIZ_TAIL).  HEAD + RESUME leave what VKRH_STAGE_SSR_TRACE leaves.                          */
   VKRH_STAGE_SSR_TRACE_HEAD     = 1u << 18,
   VKRH_STAGE_SSR_TRACE_RESUME   = 1u << 19,
+  VKRH_STAGE_DOWNSAMPLE_NEXT    = 1u << 20,  /* the downsample of the NEXT frame into the G-buffer's second set (pipelined tiled frame) */
   VKRH_STAGE_CHAIN      = (1u << 3) | (1u << 5) | (1u << 6) | (1u << 7)
 };
 
@@ -201,6 +202,9 @@ int   vkrh_hit_capacities(const uint32_t* counts, uint32_t world, uint32_t perce
  * delivers what is already there.  With a static scene that is what the peers would send again.  A second call swaps the
  * communicator (another link rate; counts ignored).                                                                          */
 int   vkrh_tiled_emulate_wire(void* tiled, void* comm, const uint32_t* counts);
+/* 1: two frames in flight (VKR_TILED_PIPELINE=1): vkrh_tiled_step downsamples the NEXT frame and starts its depth all-gather
+ * right after this frame's trace; the TAA runs behind GTAO (host/frame.cpp: pipelined_step)                                 */
+int   vkrh_tiled_pipelined(void* tiled);
 /* 1: the trace runs in two stages around the depth all-gather (VKRH_STAGE_SSR_TRACE_HEAD / _RESUME) and the TAA after GTAO */
 int   vkrh_tiled_local_first(void* tiled);
 /* requests of the last frame that this rank could not answer from its window (0 unless the ranks' strips disagree); synchronises */

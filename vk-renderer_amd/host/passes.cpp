@@ -89,6 +89,24 @@ void Gbuffer::enable_normal_requests(RenderGraph &graph, uint32_t row0, uint32_t
   pend_data = graph.create_image(VK_IMAGE_TYPE_2D, gpu::ImageInfo {VK_FORMAT_R32G32B32A32_SFLOAT, COLOR, 2 * (w/2), h/2}, VK_IMAGE_TILING_OPTIMAL, usage);
 }
 
+void Gbuffer::enable_pipelining(RenderGraph &graph) {
+  if (pipelined) return;
+  const auto color_usage = VK_IMAGE_USAGE_COLOR_ATTACHMENT_BIT|VK_IMAGE_USAGE_SAMPLED_BIT|VK_IMAGE_USAGE_TRANSFER_SRC_BIT;
+  const auto depth_usage = VK_IMAGE_USAGE_DEPTH_STENCIL_ATTACHMENT_BIT|VK_IMAGE_USAGE_SAMPLED_BIT|VK_IMAGE_USAGE_TRANSFER_SRC_BIT;
+  const uint32_t depth_mips = uint32_t(std::floor(std::log2(std::max(w, h)))) + 1;
+  depth_next = make_image(graph, VK_FORMAT_D24_UNORM_S8_UINT, w, h, depth_usage|VK_IMAGE_USAGE_TRANSFER_DST_BIT, DEPTH|VK_IMAGE_ASPECT_STENCIL_BIT, depth_mips);
+  downsampled_normals_next = make_image(graph, VK_FORMAT_R16G16_UNORM, w/2, h/2, color_usage);
+  downsampled_velocity_vectors_next = make_image(graph, VK_FORMAT_R16G16_SFLOAT, w/2, h/2, color_usage);
+  pipelined = true;
+}
+
+void Gbuffer::swap_sets(RenderGraph &graph) {
+  if (!pipelined) throw std::runtime_error {"Gbuffer::swap_sets: pipelining is not enabled"};
+  graph.remap(depth, depth_next);  // (untiled, frame_hiz / frame_normals ARE these ids and follow the swap)
+  graph.remap(downsampled_normals, downsampled_normals_next);
+  graph.remap(downsampled_velocity_vectors, downsampled_velocity_vectors_next);
+}
+
 // ==== DownsamplePass (downsample_pass.cpp) ================================================================
 #ifndef VKR_REFERENCE_PASSES  // defined by the reference's own source in the drop-in build (Makefile: refpasses)
 DownsamplePass::DownsamplePass() : sampler {default_sampler()} {

@@ -147,6 +147,14 @@ struct Gbuffer {
   uint32_t normal_row0 = 0, normal_row1 = 0;
   rendergraph::ImageResourceId pend_mask, pend_data;
   void enable_normal_requests(rendergraph::RenderGraph &graph, uint32_t row0, uint32_t row1);
+  // Two frames in flight (multi-GPU, host/frame.cpp: pipelined_step): a second set of everything the downsample WRITES — the
+  // depth image (its mip 0 is the G-buffer's depth: the caller keeps both copies current), the downsampled normals and
+  // velocities — so that frame f + 1 can be downsampled, and its depth pyramid sent to the other ranks, while the later passes
+  // of frame f still read theirs.  swap_sets() makes the next set the current one (the ids stay, the images behind them swap).
+  bool pipelined = false;
+  rendergraph::ImageResourceId depth_next, downsampled_normals_next, downsampled_velocity_vectors_next;
+  void enable_pipelining(rendergraph::RenderGraph &graph);
+  void swap_sets(rendergraph::RenderGraph &graph);
 };
 
 struct DrawTAAParams {
