@@ -149,36 +149,50 @@ __global__ __launch_bounds__(1024) void k_hit_requests(HitReqArgs a, HitTile g) 
       // Pass 2 hands out the slots of a segment in a FIXED order — tile, wave, request k of the ray, lane — so that the same
       // rays always produce the same bytes on the wire (a frame can be replayed; two runs can be compared request by request).
       // Per tile: every wave counts its requests per owner (ballots), then takes its range behind the waves before it.
-      for (uint32_t o = 0; o < a.world; o++) {
-        uint32_t c = 0u;
+      // (a wave without a request writes zeros and skips the ballots; a wave with requests visits only the owners its lanes name)
+      const bool wave_has = __ballot(n > 0) != 0ull;
+      if ((tid & 63) < (int)a.world) s_wcnt[wave][tid & 63] = 0u;
+      if (wave_has) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) c += (uint32_t)__popcll(__ballot(k < n && owner[k] == o));
-        if ((tid & 63) == 0) s_wcnt[wave][o] = c;
+        for (int k = 0; k < 4; k++) {
+          uint64_t todo = __ballot(k < n);
+          while (todo) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)owner[k], (int)__builtin_ctzll(todo));
+            const uint64_t m = __ballot(k < n && owner[k] == o);
+            if ((tid & 63) == 0) s_wcnt[wave][o] += (uint32_t)__popcll(m);
+            todo &= ~m;
+          }
+        }
       }
       __syncthreads();
       uint32_t total = 0u;  // (thread o: what the whole block adds to owner o with this tile)
       if (tid < (int)a.world)
         for (int w = 0; w < 16; w++) total += s_wcnt[w][tid];
-      // lane o of every wave: where owner o's requests of this wave start (the segment's base, what the block has written so far,
-      // the waves before this one)
-      uint32_t my_at = 0u;
-      if ((tid & 63) < (int)a.world) {
-        const int o = tid & 63;
-        my_at = s_base[o] + s_n[o];
-        for (int w = 0; w < wave; w++) my_at += s_wcnt[w][o];
-      }
-      for (uint32_t o = 0; o < a.world; o++) {
-        uint32_t at = (uint32_t)__shfl((int)my_at, (int)o);
+      if (wave_has) {
+        // lane o of the wave: where owner o's requests of this wave start (the segment's base, what the block has written so far,
+        // the waves before this one); within the wave: request k of the ray, then lane
+        uint32_t my_at = 0u;
+        if ((tid & 63) < (int)a.world) {
+          const int o = tid & 63;
+          my_at = s_base[o] + s_n[o];
+          for (int w = 0; w < wave; w++) my_at += s_wcnt[w][o];
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const bool mine = k < n && owner[k] == o;
-          const uint64_t m = __ballot(mine);
-          if (mine) {
-            const uint32_t slot = at + (uint32_t)wave_rank_of(m);
-            if (slot < s_end[o]) a.out[slot] = code[k];
-            else if (a.dropped) *a.dropped = 1u;  // a bounded segment drops what does not fit, and says so
+          uint64_t todo = __ballot(k < n);
+          while (todo) {
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)owner[k], (int)__builtin_ctzll(todo));
+            const bool mine = k < n && owner[k] == o;
+            const uint64_t m = __ballot(mine);
+            const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)my_at, (int)o);
+            if (mine) {
+              const uint32_t slot = at + (uint32_t)wave_rank_of(m);
+              if (slot < s_end[o]) a.out[slot] = code[k];
+              else if (a.dropped) *a.dropped = 1u;  // a bounded segment drops what does not fit, and says so
+            }
+            if ((tid & 63) == (int)o) my_at += (uint32_t)__popcll(m);
+            todo &= ~m;
           }
-          at += (uint32_t)__popcll(m);
         }
       }
       __syncthreads();
