@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--warm", type=int, default=2)
     ap.add_argument("--bounds-from", default=None, help="a tools/lockstep_profile.py JSON: the strips of its last balancing pass")
     ap.add_argument("--one-gpu-ms", type=float, default=None, help="ms per frame of the same frame on one GPU (for the speed-up column)")
+    ap.add_argument("--rebalance", type=int, default=0, help="re-cut the strips this many times by the ranks' frame times at the first link rate")
     ap.add_argument("--rank", type=int, default=None, help="(child) measure this rank and print its JSON")
     ap.add_argument("--task-times", action="store_true", help="also the per-pass times on the native schedule")
     args = ap.parse_args()
@@ -125,16 +126,40 @@ def main():
         return
     # parent: one child process per rank (this process never touches the GPU)
     import subprocess
+    import tempfile
 
-    per_rank = []
-    for r in range(world):
-        cmd = [sys.executable, os.path.abspath(__file__), "--rank", str(r)] + [a for a in sys.argv[1:]]
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-        sys.stderr.write("".join(l for l in p.stderr.splitlines(True) if l.startswith("  rank")))
-        if p.returncode != 0:
-            sys.stderr.write(p.stderr[-3000:])
-            raise SystemExit(f"rank {r}: the child exited {p.returncode}")
-        per_rank.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    def run_all(bounds):
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            json.dump({"passes": [{"bounds": bounds}]}, f)
+        argv = [a for a in sys.argv[1:]]
+        if "--bounds-from" in argv:
+            i = argv.index("--bounds-from")
+            del argv[i:i + 2]
+        per_rank = []
+        for r in range(world):
+            cmd = [sys.executable, os.path.abspath(__file__), "--rank", str(r), "--bounds-from", f.name] + argv
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            sys.stderr.write("".join(l for l in p.stderr.splitlines(True) if l.startswith("  rank")))
+            if p.returncode != 0:
+                sys.stderr.write(p.stderr[-3000:])
+                raise SystemExit(f"rank {r}: the child exited {p.returncode}")
+            per_rank.append(json.loads(p.stdout.strip().splitlines()[-1]))
+        os.unlink(f.name)
+        return per_rank
+
+    per_rank = run_all(bounds)
+    # --rebalance K: re-cut the strips K times by what a rank's FRAME takes at the first link rate (its passes and what it waits
+    # for), not by its passes alone — the balance a job on real links would find if it fed its per-rank frame times back
+    for it in range(args.rebalance):
+        from vk_renderer_amd import host
+
+        ms = [x[0]["ms_per_frame"] for x in per_rank]
+        new = host.balance_rows(ms, bounds, align=16, min_rows=max(256, H // (4 * world) // 16 * 16))
+        print(f"re-cut by frame time at {args.link_gbps[0]:g} GB/s: {[new[r + 1] - new[r] for r in range(world)]} (slowest was {max(ms):.3f} ms)", file=sys.stderr)
+        if new == bounds:
+            break
+        bounds = new
+        per_rank = run_all(bounds)
     result = {"frame": [W, H], "world": world, "bounds": bounds, "launch_us": args.launch_us, "runs": []}
     for i, gbps in enumerate(args.link_gbps):
         ranks = [x[i] for x in per_rank]
