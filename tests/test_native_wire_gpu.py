@@ -251,6 +251,8 @@ def test_bench_native_branch_between_real_processes(world, balance, tmp_path):
     assert sum(d["config"]["strip_rows"]) == H and len(d["config"]["strip_rows"]) == world
     assert d["exchange_wait_ms"] is not None and all(len(v) == world for v in d["exchange_wait_ms"].values())
     assert d["exchange_bytes_per_rank"] is not None and len(d["exchange_bytes_per_rank"]) == world
+    # bench.py keeps two frames in flight at N > 1 (VKR_TILED_PIPELINE defaults to 1 there) and says so
+    assert d["tiled_options"]["frames_in_flight"] == 2 and d["tiled_options"]["rows_computed"] == "the rows that are read"
     rows = _wire_log(log, world)
     if balance:
         assert len(d["config"]["strip_balance"]) >= 1
