@@ -215,3 +215,21 @@ def test_comm_entries_refuse_null(lib):
     lib.vkr_set_switches(abi.SWITCH_BLUR_NO_SKIP | abi.SWITCH_TAA_GENERIC)
     assert lib.vkr_get_switches() == abi.SWITCH_BLUR_NO_SKIP | abi.SWITCH_TAA_GENERIC
     lib.vkr_set_switches(before)
+
+
+def test_emulated_communicator_rules(lib):
+    """vkr_comm_create_emulated: argument rules, rank / world read back, the self check refuses it (it moves no bytes), and
+    destroying it needs no RCCL.  (No device call: the exchanges themselves are covered on the GPU.)"""
+    h = C.c_void_p(0)
+    assert lib.vkr_comm_create_emulated(0, 4, 60.0, 15.0, None) == ERR_NULL
+    for rank, world, gbps, us in ((4, 4, 60.0, 15.0), (-1, 4, 60.0, 15.0), (0, 0, 60.0, 15.0), (0, 4, 0.0, 15.0), (0, 4, 60.0, -1.0)):
+        assert lib.vkr_comm_create_emulated(rank, world, gbps, us, C.byref(h)) == ERR_EXTENT, (rank, world, gbps, us)
+        assert b"comm_create_emulated" in lib.vkr_last_error()
+    assert lib.vkr_comm_create_emulated(2, 4, 60.0, 15.0, C.byref(h)) == 0 and h.value
+    lib.vkr_comm_rank.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    r, w = C.c_int(-1), C.c_int(-1)
+    assert lib.vkr_comm_rank(h, C.byref(r), C.byref(w)) == 0 and (r.value, w.value) == (2, 4)
+    lib.vkr_comm_selfcheck.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    scratch = (C.c_uint8 * 16)()
+    assert lib.vkr_comm_selfcheck(h, scratch, None) != 0 and b"emulated" in lib.vkr_last_error()
+    assert lib.vkr_comm_destroy(h) == 0
